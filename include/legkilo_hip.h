@@ -1,0 +1,271 @@
+/*
+ * legkilo_hip.h — C-ABI of liblegkilo_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of Leg-KILO: the per-time-bucket LiDAR ESKF
+ * update, i.e. KILO::predictUpdatePoint (legkilo/src/core/slam/KILO.cc:108-233)
+ * and what it calls in eskf.cc / voxel_map.cc, plus the bucket loop around it
+ * (KILO.cc:367-396).  The reference has no FFI of its own; the boundary is the
+ * C++ class surface KILO consumes (eskf.h:46-109, voxel_map.h:180-244).  The
+ * C++ mirror of that surface lives in leg-kilo_amd/host/ and calls only the
+ * functions declared here.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative lk_status; nothing
+ *     throws across the ABI; lk_last_error() gives the text of the last error.
+ *   - plain pointers and sizes only.  Arrays are caller-owned.  Matrices are
+ *     ROW-MAJOR fp64 unless a comment says otherwise.  Points are f32.
+ *   - a handle = one device + one HIP stream + one voxel map + n_slots filter
+ *     slots (slot 0 is "the" filter of the reference; slots >0 exist for batch
+ *     replay).  A handle is NOT thread-safe (the reference path is single
+ *     threaded: leg_kilo_node.cc:35-38).
+ *   - calls are synchronous on return unless the name ends in _async.
+ *   - pointers named d_* are DEVICE pointers (HBM-resident); all others host.
+ *
+ * State vector layout (eskf.h:15-32), LK_STATE_DOUBLES = 36:
+ *   x[0..8]  rot_ (3x3 row-major)   x[9..11]  pos_     x[12..14] vel_
+ *   x[15..17] ba_   x[18..20] bw_   x[21..23] grav_    x[24..26] imu_a_
+ *   x[27..29] imu_w_   x[30..32] bv_   x[33..35] contact_
+ * Error-state order (30): rot0 pos3 vel6 ba9 bw12 grav15 imu_a18 imu_w21 bv24 contact27.
+ */
+#ifndef LEGKILO_HIP_H_
+#define LEGKILO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_DIM_STATE 30
+#define LK_STATE_DOUBLES 36
+#define LK_ABI_VERSION 1
+
+typedef enum lk_status {
+    LK_OK = 0,
+    LK_ERR_INVALID = -1,   /* bad argument */
+    LK_ERR_HIP = -2,       /* HIP runtime error (text in lk_last_error) */
+    LK_ERR_CAPACITY = -3,  /* a device pool (hash / nodes / point blocks / scan) overflowed */
+    LK_ERR_NO_DEVICE = -4, /* no gfx950 device visible; there is NO CPU fallback */
+    LK_ERR_STATE = -5      /* call order violated (e.g. update before set_state) */
+} lk_status;
+
+/* ESKF::Config (eskf.h:49-65) + VoxelMapConfig (voxel_map.h:41-57) + extrinsics
+ * (KILO.cc:74-79) + device capacities.  YAML key names are those of
+ * legkilo/config/leg_fusion.yaml. */
+typedef struct lk_config {
+    /* ESKF::Config, declaration order */
+    double vel_process_cov;
+    double imu_acc_process_cov;
+    double imu_gyr_process_cov;
+    double contact_process_cov;
+    double acc_bias_process_cov;
+    double gyr_bias_process_cov;
+    double kin_bias_process_cov;
+    double imu_acc_meas_noise;
+    double imu_acc_z_meas_noise;
+    double imu_gyr_meas_noise;
+    double kin_meas_noise;
+    double chd_meas_noise;          /* loaded, never used by the reference */
+    double contact_meas_noise;      /* loaded, never used by the reference */
+    double lidar_point_meas_ratio;
+    /* VoxelMapConfig */
+    double max_voxel_size;          /* yaml voxel_size */
+    double planner_threshold;       /* yaml min_eigen_value */
+    double beam_err;                /* degrees */
+    double dept_err;                /* metres */
+    double sigma_num;
+    int32_t max_layer;
+    int32_t max_iterations;         /* unused by the reference (voxel_map.h:44) */
+    int32_t layer_init_num[5];
+    int32_t max_points_num;
+    /* extrinsics: p_imu = ext_R * p_lidar + ext_T (KILO.cc:128) */
+    double ext_R[9];
+    double ext_T[3];
+    double gravity;                 /* KILO.cc:50 */
+    /* device side */
+    int32_t device_id;              /* HIP device ordinal */
+    uint32_t n_slots;               /* filter slots (>=1); >1 only for batch replay */
+    uint32_t max_roots;             /* root voxels the hash must hold (table = next pow2 of 2x) */
+    uint32_t max_nodes;             /* octree nodes (roots + children) */
+    uint32_t max_point_blocks;      /* per-leaf point blocks of LK_BLOCK_PTS points */
+    uint32_t max_scan_points;       /* points of the largest scan / bucket batch */
+} lk_config;
+
+/* PointType fields the path reads (pcl_types.h:11; x,y,z @0 and curvature @36 of
+ * the 48-byte pcl::PointXYZINormal): body-frame xyz + per-point time offset. */
+typedef struct lk_point {
+    float x, y, z;
+    float curvature;
+} lk_point;
+
+/* sensor_msgs::Imu fields predictUpdateImu reads (KILO.cc:235-258) */
+typedef struct lk_imu {
+    double stamp;
+    double acc[3];
+    double gyr[3];
+} lk_imu;
+
+/* common::KinImuMeas (sensor_types.hpp:19-27); contact as int32 (bool in the reference) */
+typedef struct lk_kin_imu {
+    double time_stamp;
+    double foot_pos[4][3];
+    double foot_vel[4][3];
+    int32_t contact[4];
+    double acc[3];
+    double gyr[3];
+} lk_kin_imu;
+
+/* result of one scan / one replay unit */
+typedef struct lk_pose {
+    double rot[9];   /* row-major */
+    double pos[3];
+    double vel[3];
+    uint64_t n_effect;   /* success_pts_size_out (KILO.cc:180) */
+    uint32_t n_buckets;
+    uint32_t n_updates;  /* buckets whose N>0 */
+} lk_pose;
+
+/* ---- map blob (lk_map_export / lk_map_import; also the RCCL broadcast payload) ----
+ * blob = lk_blob_header | roots[n_roots] | nodes[n_nodes] | planes[n_nodes] | blocks[n_blocks]
+ * All little-endian PODs below; node ids index nodes[]/planes[]; block ids index blocks[]. */
+#define LK_BLOB_MAGIC 0x4C4B4D50u /* 'LKMP' */
+#define LK_BLOCK_PTS 52           /* >= max_points_num + 1 (voxel_map.cc:199,232) */
+
+typedef struct lk_blob_header {
+    uint32_t magic, version;
+    uint32_t n_roots, n_nodes, n_blocks, block_pts;
+    double voxel_size;
+    int32_t max_layer, max_points_num;
+    uint64_t bytes;              /* total blob size */
+} lk_blob_header;
+
+typedef struct lk_root_rec {     /* one hash entry: Vec3i key -> root node (voxel_map.h:186) */
+    int32_t key[3];
+    int32_t node;
+} lk_root_rec;
+
+/* VoxelPlane (voxel_map.h:96-119), 256 B, the record the residual kernel streams */
+#define LK_PLANE_IS_PLANE 1u
+#define LK_PLANE_IS_INIT 2u
+typedef struct lk_plane_rec {
+    double center[3];
+    double normal[3];
+    float d;
+    float radius;
+    uint32_t flags;
+    int32_t points_size;
+    double plane_var[21];        /* upper triangle of the 6x6, row-major: (0,0)(0,1)..(0,5)(1,1).. */
+    float min_eigen_value, mid_eigen_value, max_eigen_value;
+    uint32_t pad_[3];
+} lk_plane_rec;
+
+/* VoxelOctoTree (voxel_map.h:129-176) minus the plane, 128 B */
+#define LK_NODE_INIT_OCTO 1u
+#define LK_NODE_UPDATE_ENABLE 2u
+#define LK_NODE_OCTO_STATE 4u
+#define LK_NODE_PTS_DROPPED 8u   /* >LK_BLOCK_PTS first-frame points: only the count is kept */
+typedef struct lk_node_rec {
+    int32_t child[8];            /* -1 = nullptr */
+    double voxel_center[3];
+    float quater_length;
+    int32_t layer;
+    int32_t npts;                /* temp_points_.size() */
+    int32_t new_points;
+    uint32_t state;
+    int32_t block;               /* point block id, -1 = none */
+    int32_t key[3];              /* root key (roots only) */
+    int32_t list_head;           /* device scratch, always -1 at rest */
+    uint32_t pad_[8];
+} lk_node_rec;
+
+typedef struct lk_pt_rec {       /* pointWithVar fields the map keeps: point_w + var (sym) */
+    double pw[3];
+    double var[6];               /* xx xy xz yy yz zz */
+} lk_pt_rec;
+
+typedef struct lk_block_rec {
+    lk_pt_rec pts[LK_BLOCK_PTS];
+} lk_block_rec;
+
+typedef struct lk_handle lk_handle;
+
+/* ---- lifetime ---- */
+int lk_abi_version(void);
+int lk_create(const lk_config* cfg, lk_handle** out);                  /* ESKF(const Config&) + VoxelMapManager(VoxelMapConfig&) */
+void lk_destroy(lk_handle* h);
+const char* lk_last_error(const lk_handle* h);                         /* h may be NULL */
+
+/* ---- ESKF surface (eskf.h:46-109); slot = filter slot, 0 for the reference's single filter ---- */
+int lk_set_state(lk_handle* h, uint32_t slot, const double* x36, const double* P900);  /* setState + cov() */
+int lk_get_state(lk_handle* h, uint32_t slot, double* x36, double* P900);              /* state(), cov() */
+int lk_set_Q(lk_handle* h, const double* Q900);                        /* setQ */
+int lk_get_Q(lk_handle* h, double* Q900);                              /* Q() */
+int lk_init_process_cov_q(lk_handle* h);                               /* initProcessCovQ, eskf.cc:47-62 */
+int lk_set_times(lk_handle* h, uint32_t slot, double last_predict_t, double last_update_t); /* KILO.cc:350-351 */
+int lk_get_times(lk_handle* h, uint32_t slot, double* last_predict_t, double* last_update_t);
+int lk_set_acc_norm(lk_handle* h, double acc_norm);                    /* KILO.cc:349 */
+int lk_get_fx(lk_handle* h, uint32_t slot, double dt, double* Fx900);   /* getFx, eskf.cc:72-81 */
+int lk_get_function_f(lk_handle* h, uint32_t slot, double dt, double* f30); /* getFunctionf, eskf.cc:64-70 */
+int lk_predict(lk_handle* h, uint32_t slot, double dt, int prop_state, int prop_cov);   /* predict, eskf.cc:83-89 */
+/* updateByPoints(ObsShared&), eskf.cc:91-113; h6 is N x 6 ROW-major */
+int lk_update_by_points(lk_handle* h, uint32_t slot, const double* h6, const double* z, const double* R, size_t N);
+/* updateByImu / updateByKinImu (eskf.cc:125-145): ki_h is M x 30 row-major */
+int lk_update_by_imu(lk_handle* h, uint32_t slot, const double* ki_z6, const double* ki_R6);
+int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const double* ki_z, const double* ki_R, size_t M);
+
+/* ---- VoxelMapManager surface (voxel_map.h:180-244) ---- */
+/* BuildVoxelMap(rot, rot_cov, pos_cov) with feats_down_world_/feats_down_body_ = the two clouds
+ * (xyz f32, n x 3); rot/rot_cov/pos_cov are taken from slot 0 (KILO.cc:339). */
+int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, size_t n);
+/* UpdateVoxelMap(const std::vector<pointWithVar>&): pw n x 3, var n x 9 (row-major 3x3) fp64 */
+int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n);
+/* Residual build of KILO.cc:122-210 with the CURRENT state of slot 0, no predict, no update, no
+ * insert (config 2).  Outputs per input point: h6 n x 6 row-major, z, R, valid (0/1). */
+int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, double* z, double* R, uint8_t* valid);
+int lk_map_stats(lk_handle* h, uint32_t* n_roots, uint32_t* n_nodes, uint32_t* n_blocks);
+int lk_map_export(lk_handle* h, void* blob, size_t* bytes);            /* blob==NULL: size query */
+int lk_map_import(lk_handle* h, const void* blob, size_t bytes);
+/* device-resident blob for the RCCL broadcast (no host staging) */
+int lk_map_export_dev(lk_handle* h, void* d_blob, size_t* bytes);
+int lk_map_import_dev(lk_handle* h, const void* d_blob, size_t bytes);
+
+/* ---- KILO path (KILO.cc) ---- */
+/* predictUpdatePoint (KILO.cc:108-233) on slot 0: xyz_body n x 3 f32 (one time bucket),
+ * xyz_world_out n x 3 f32 (cloud_down_world), intensity_out n f32 (0 / 255), *n_effect += N. */
+int lk_update_points(lk_handle* h, double t, const float* xyz_body, size_t n, float* xyz_world_out,
+                     float* intensity_out, size_t* n_effect);
+int lk_update_imu(lk_handle* h, const lk_imu* imu);                    /* predictUpdateImu, KILO.cc:235-258 */
+int lk_update_kin_imu(lk_handle* h, const lk_kin_imu* kin);            /* predictUpdateKinImu, KILO.cc:260-314 */
+/* bucket loop of KILO::process (KILO.cc:367-396) on a time-SORTED scan: buckets are runs of
+ * exactly equal curvature; IMU (imu_mode_only) or kin+IMU messages with stamp < bucket time are
+ * consumed first.  n_imu>0 and n_kin>0 together is invalid.  world_out may be NULL. */
+int lk_process_scan(lk_handle* h, const lk_point* sorted_pts, size_t n, double t_begin, const lk_imu* imus,
+                    size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out);
+/* same with the scan already resident in HBM (d_pts: n x lk_point) and bucket bounds given by the
+ * caller: bucket b covers [bucket_off[b], bucket_off[b+1]) at time t_begin + bucket_dt[b]. */
+int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_begin, const uint32_t* bucket_off,
+                        const double* bucket_dt, size_t n_buckets, lk_pose* out);
+
+/* ---- batch replay (config 5): scans are independent units against the handle's FROZEN map ----
+ * scan s uses filter slot s (n_scans <= n_slots); all scans have n_pts points laid out
+ * d_pts[s * n_pts + i]; bucket bounds are shared by all scans.  Inserts are disabled. */
+int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, size_t n_scans); /* per-scan priors */
+int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
+                        const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
+
+/* ---- measurement hooks ---- */
+int lk_profile_enable(lk_handle* h, int on);                           /* HIP-event timing around each kernel */
+int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms);
+int lk_profile_reset(lk_handle* h);
+int lk_device_malloc(lk_handle* h, void** d_ptr, size_t bytes);
+int lk_device_free(lk_handle* h, void* d_ptr);
+int lk_memcpy_h2d(lk_handle* h, void* d_dst, const void* src, size_t bytes);
+int lk_memcpy_d2h(lk_handle* h, void* dst, const void* d_src, size_t bytes);
+int lk_synchronize(lk_handle* h);
+void* lk_stream(lk_handle* h);                                         /* the handle's hipStream_t */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEGKILO_HIP_H_ */

@@ -1,0 +1,243 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes wrapper over oracle/liblegkilo_oracle.so.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (leg-kilo_amd/) never imports this module.  PARITY UNPINNED (see smallmat.hpp).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import lk_pkg
+
+lk_pkg.load()
+from legkilo_amd import abi  # noqa: E402  (ABI struct declarations only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liblegkilo_oracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cc", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "legkilo_hip.h"))
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liblegkilo_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.lko_create.restype = C.c_void_p
+        _lib.lko_get_acc_norm.restype = C.c_double
+        _lib.lko_hash_vec3.restype = C.c_size_t
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """Same call surface as legkilo_amd.binding.LegKiloHip (lko_ instead of lk_)."""
+
+    def __init__(self, cfg, imu_mode_only=True):
+        self.cfg = cfg
+        self.L = lib()
+        self.h = C.c_void_p(self.L.lko_create(C.byref(cfg), int(imu_mode_only)))
+
+    def close(self):
+        if self.h:
+            self.L.lko_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ESKF ----
+    def set_state(self, x36=None, P=None):
+        x36 = None if x36 is None else _f64(x36).reshape(36)
+        P = None if P is None else _f64(P).reshape(900)
+        self.L.lko_set_state(self.h, _p(x36), _p(P))
+
+    def get_state(self):
+        x = np.zeros(36)
+        P = np.zeros(900)
+        self.L.lko_get_state(self.h, _p(x), _p(P))
+        return x, P.reshape(30, 30)
+
+    def set_Q(self, Q):
+        Q = _f64(Q).reshape(900)
+        self.L.lko_set_Q(self.h, _p(Q))
+
+    def get_Q(self):
+        Q = np.zeros(900)
+        self.L.lko_get_Q(self.h, _p(Q))
+        return Q.reshape(30, 30)
+
+    def init_process_cov_q(self):
+        self.L.lko_init_process_cov_q(self.h)
+
+    def set_times(self, last_predict_t, last_update_t):
+        self.L.lko_set_times(self.h, C.c_double(last_predict_t), C.c_double(last_update_t))
+
+    def get_times(self):
+        a, b = C.c_double(), C.c_double()
+        self.L.lko_get_times(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_acc_norm(self, a):
+        self.L.lko_set_acc_norm(self.h, C.c_double(a))
+
+    def get_acc_norm(self):
+        return self.L.lko_get_acc_norm(self.h)
+
+    def set_literal_max_n(self, n):
+        self.L.lko_set_literal_max_n(self.h, int(n))
+
+    def set_map_insert(self, on):
+        self.L.lko_set_map_insert(self.h, int(on))
+
+    def get_fx(self, dt):
+        F = np.zeros(900)
+        self.L.lko_get_fx(self.h, C.c_double(dt), _p(F))
+        return F.reshape(30, 30)
+
+    def get_function_f(self, dt):
+        f = np.zeros(30)
+        self.L.lko_get_function_f(self.h, C.c_double(dt), _p(f))
+        return f
+
+    def predict(self, dt, prop_state, prop_cov):
+        self.L.lko_predict(self.h, C.c_double(dt), int(prop_state), int(prop_cov))
+
+    def update_by_points(self, h6, z, R):
+        h6, z, R = _f64(h6), _f64(z), _f64(R)
+        self.L.lko_update_by_points(self.h, _p(h6), _p(z), _p(R), C.c_size_t(len(z)))
+
+    def update_by_imu(self, z6, R6):
+        z6, R6 = _f64(z6), _f64(R6)
+        self.L.lko_update_by_imu(self.h, _p(z6), _p(R6))
+
+    def update_by_kin_imu(self, ki_h, ki_z, ki_R):
+        ki_h, ki_z, ki_R = _f64(ki_h), _f64(ki_z), _f64(ki_R)
+        self.L.lko_update_by_kin_imu(self.h, _p(ki_h), _p(ki_z), _p(ki_R), C.c_size_t(len(ki_z)))
+
+    # ---- map ----
+    def map_build(self, xyz_world, xyz_body):
+        w = np.ascontiguousarray(xyz_world, dtype=np.float32)
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        self.L.lko_map_build(self.h, _p(w), _p(b), C.c_size_t(len(w)))
+
+    def map_update(self, pw, var9):
+        pw, var9 = _f64(pw), _f64(var9)
+        self.L.lko_map_update(self.h, _p(pw), _p(var9), C.c_size_t(len(pw)))
+
+    def residuals(self, xyz_body):
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        n = len(b)
+        h6, z, R, valid = np.zeros((n, 6)), np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        self.L.lko_residuals(self.h, _p(b), C.c_size_t(n), _p(h6), _p(z), _p(R), _p(valid))
+        return h6, z, R, valid
+
+    def map_export(self):
+        nbytes = C.c_size_t(0)
+        self.L.lko_map_export(self.h, None, C.byref(nbytes))
+        buf = np.zeros(nbytes.value, dtype=np.uint8)
+        rc = self.L.lko_map_export(self.h, _p(buf), C.byref(nbytes))
+        assert rc == 0
+        return buf
+
+    def map_stats(self):
+        n = C.c_uint32()
+        self.L.lko_map_stats(self.h, C.byref(n))
+        return n.value
+
+    # ---- KILO path ----
+    def update_points(self, t, xyz_body):
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        n = len(b)
+        w = np.zeros((n, 3), dtype=np.float32)
+        inten = np.zeros(n, dtype=np.float32)
+        ne = C.c_size_t(0)
+        self.L.lko_update_points(self.h, C.c_double(t), _p(b), C.c_size_t(n), _p(w), _p(inten), C.byref(ne))
+        return w, inten, ne.value
+
+    def update_imu(self, imu_rec):
+        a = np.ascontiguousarray(imu_rec)
+        self.L.lko_update_imu(self.h, _p(a))
+
+    def update_kin_imu(self, kin_rec):
+        a = np.ascontiguousarray(kin_rec)
+        self.L.lko_update_kin_imu(self.h, _p(a))
+
+    def first_frame(self, raw_pts, end_time, imus=None, kins=None):
+        raw = np.ascontiguousarray(raw_pts)
+        ni = 0 if imus is None else len(imus)
+        nk = 0 if kins is None else len(kins)
+        imus = None if imus is None else np.ascontiguousarray(imus)
+        kins = None if kins is None else np.ascontiguousarray(kins)
+        self.L.lko_first_frame(self.h, _p(raw), C.c_size_t(len(raw)), C.c_double(end_time), _p(imus), C.c_size_t(ni),
+                               _p(kins), C.c_size_t(nk))
+
+    def process_scan(self, sorted_pts, t_begin, imus=None, kins=None, want_world=False, with_sort=False):
+        pts = np.ascontiguousarray(sorted_pts)
+        ni = 0 if imus is None else len(imus)
+        nk = 0 if kins is None else len(kins)
+        imus = None if imus is None else np.ascontiguousarray(imus)
+        kins = None if kins is None else np.ascontiguousarray(kins)
+        w = np.zeros((len(pts), 3), dtype=np.float32) if want_world else None
+        pose = abi.lk_pose()
+        self.L.lko_process_scan(self.h, _p(pts), C.c_size_t(len(pts)), C.c_double(t_begin), _p(imus), C.c_size_t(ni),
+                                _p(kins), C.c_size_t(nk), _p(w), C.byref(pose), int(with_sort))
+        return pose, w
+
+
+# ---- unit-level hooks ----
+def calc_body_cov(pb, range_inc, degree_inc):
+    pb = _f64(pb)
+    cov = np.zeros(9)
+    lib().lko_calc_body_cov(_p(pb), C.c_float(range_inc), C.c_float(degree_inc), _p(cov))
+    return cov.reshape(3, 3)
+
+
+def eig_sym3(A):
+    A = _f64(A).reshape(9)
+    ev, V = np.zeros(3), np.zeros(9)
+    lib().lko_eig_sym3(_p(A), _p(ev), _p(V))
+    return ev, V.reshape(3, 3)
+
+
+def init_plane(pw, var9, planer_threshold=0.01):
+    pw, var9 = _f64(pw), _f64(var9)
+    rec = np.zeros(1, dtype=abi.blob_dtypes()[2])
+    pv = np.zeros(36)
+    lib().lko_init_plane(_p(pw), _p(var9), C.c_size_t(len(pw)), C.c_float(planer_threshold), _p(rec), _p(pv))
+    return rec[0], pv.reshape(6, 6)
+
+
+def exp_log(v):
+    v = _f64(v)
+    a, b, l = np.zeros(9), np.zeros(9), np.zeros(3)
+    lib().lko_exp_log(_p(v), _p(a), _p(b), _p(l))
+    return a.reshape(3, 3), b.reshape(3, 3), l
+
+
+def hash_vec3(x, y, z):
+    return lib().lko_hash_vec3(C.c_int(x), C.c_int(y), C.c_int(z))

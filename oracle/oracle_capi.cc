@@ -1,0 +1,411 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// extern "C" surface of liblegkilo_oracle.so, loaded with ctypes by tests/, by
+// __graft_entry__.smoke() and by bench.py's cpu_baseline leg — nowhere else.
+// Mirrors the lk_* calls of include/legkilo_hip.h with an lko_ prefix so a parity
+// test is the same call sequence on both sides.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "oracle_kilo.hpp"
+
+using namespace lko;
+
+struct lko_handle {
+    lk_config cfg;
+    std::unique_ptr<KILO> kilo;
+    std::string err;
+};
+
+static void state_to_x36(const State& s, double* x) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) x[3 * i + j] = s.rot_(i, j);
+    const Vec3* v[9] = {&s.pos_, &s.vel_, &s.ba_, &s.bw_, &s.grav_, &s.imu_a_, &s.imu_w_, &s.bv_, &s.contact_};
+    for (int k = 0; k < 9; ++k)
+        for (int c = 0; c < 3; ++c) x[9 + 3 * k + c] = (*v[k])[c];
+}
+static void x36_to_state(const double* x, State& s) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) s.rot_(i, j) = x[3 * i + j];
+    Vec3* v[9] = {&s.pos_, &s.vel_, &s.ba_, &s.bw_, &s.grav_, &s.imu_a_, &s.imu_w_, &s.bv_, &s.contact_};
+    for (int k = 0; k < 9; ++k)
+        for (int c = 0; c < 3; ++c) (*v[k])[c] = x[9 + 3 * k + c];
+}
+
+extern "C" {
+
+lko_handle* lko_create(const lk_config* cfg, int imu_mode_only) {
+    lko_handle* h = new lko_handle;
+    h->cfg = *cfg;
+    h->kilo = std::make_unique<KILO>(*cfg);
+    h->kilo->imu_mode_only_ = imu_mode_only != 0;
+    return h;
+}
+void lko_destroy(lko_handle* h) { delete h; }
+
+int lko_set_state(lko_handle* h, const double* x36, const double* P900) {
+    if (x36) x36_to_state(x36, h->kilo->eskf_->state());
+    if (P900)
+        for (int i = 0; i < 30; ++i)
+            for (int j = 0; j < 30; ++j) h->kilo->eskf_->cov()(i, j) = P900[30 * i + j];
+    return 0;
+}
+int lko_get_state(lko_handle* h, double* x36, double* P900) {
+    if (x36) state_to_x36(h->kilo->eskf_->state(), x36);
+    if (P900)
+        for (int i = 0; i < 30; ++i)
+            for (int j = 0; j < 30; ++j) P900[30 * i + j] = h->kilo->eskf_->cov()(i, j);
+    return 0;
+}
+int lko_set_Q(lko_handle* h, const double* Q900) {
+    for (int i = 0; i < 30; ++i)
+        for (int j = 0; j < 30; ++j) h->kilo->eskf_->Q()(i, j) = Q900[30 * i + j];
+    return 0;
+}
+int lko_get_Q(lko_handle* h, double* Q900) {
+    for (int i = 0; i < 30; ++i)
+        for (int j = 0; j < 30; ++j) Q900[30 * i + j] = h->kilo->eskf_->Q()(i, j);
+    return 0;
+}
+int lko_init_process_cov_q(lko_handle* h) {
+    h->kilo->eskf_->initProcessCovQ();
+    return 0;
+}
+int lko_set_times(lko_handle* h, double last_predict_t, double last_update_t) {
+    h->kilo->last_state_predict_time_ = last_predict_t;
+    h->kilo->last_state_update_time_ = last_update_t;
+    return 0;
+}
+int lko_get_times(lko_handle* h, double* last_predict_t, double* last_update_t) {
+    *last_predict_t = h->kilo->last_state_predict_time_;
+    *last_update_t = h->kilo->last_state_update_time_;
+    return 0;
+}
+int lko_set_acc_norm(lko_handle* h, double a) {
+    h->kilo->acc_norm_ = a;
+    return 0;
+}
+double lko_get_acc_norm(lko_handle* h) { return h->kilo->acc_norm_; }
+int lko_set_literal_max_n(lko_handle* h, int n) {
+    h->kilo->eskf_->literal_max_n = n;
+    return 0;
+}
+int lko_set_map_insert(lko_handle* h, int on) {
+    h->kilo->map_insert_enabled_ = on != 0;
+    return 0;
+}
+int lko_get_fx(lko_handle* h, double dt, double* Fx900) {
+    StateCov F = h->kilo->eskf_->getFx(dt);
+    for (int i = 0; i < 30; ++i)
+        for (int j = 0; j < 30; ++j) Fx900[30 * i + j] = F(i, j);
+    return 0;
+}
+int lko_get_function_f(lko_handle* h, double dt, double* f30) {
+    StateVec f = h->kilo->eskf_->getFunctionf(dt);
+    for (int i = 0; i < 30; ++i) f30[i] = f[i];
+    return 0;
+}
+int lko_predict(lko_handle* h, double dt, int prop_state, int prop_cov) {
+    h->kilo->eskf_->predict(dt, prop_state != 0, prop_cov != 0);
+    return 0;
+}
+int lko_update_by_points(lko_handle* h, const double* h6, const double* z, const double* R, size_t N) {
+    ObsShared o;
+    o.pt_h.assign(h6, h6 + 6 * N);
+    o.pt_z.assign(z, z + N);
+    o.pt_R.assign(R, R + N);
+    h->kilo->eskf_->updateByPoints(o);
+    return 0;
+}
+int lko_update_by_imu(lko_handle* h, const double* z6, const double* R6) {
+    ObsShared o;
+    o.ki_z.assign(z6, z6 + 6);
+    o.ki_R.assign(R6, R6 + 6);
+    h->kilo->eskf_->updateByImu(o);
+    return 0;
+}
+int lko_update_by_kin_imu(lko_handle* h, const double* ki_h, const double* ki_z, const double* ki_R, size_t M) {
+    ObsShared o;
+    o.ki_h.assign(ki_h, ki_h + 30 * M);
+    o.ki_z.assign(ki_z, ki_z + M);
+    o.ki_R.assign(ki_R, ki_R + M);
+    h->kilo->eskf_->updateByKinImu(o);
+    return 0;
+}
+
+int lko_map_build(lko_handle* h, const float* xyz_world, const float* xyz_body, size_t n) {
+    auto& m = *h->kilo->map_manager_;
+    m.feats_down_world_.assign(xyz_world, xyz_world + 3 * n);
+    m.feats_down_body_.assign(xyz_body, xyz_body + 3 * n);
+    auto& e = *h->kilo->eskf_;
+    m.BuildVoxelMap(e.getRot(), e.getRotCov(), e.getPosCov());
+    return 0;
+}
+int lko_map_update(lko_handle* h, const double* pw, const double* var9, size_t n) {
+    std::vector<pointWithVar> pv(n);
+    for (size_t i = 0; i < n; ++i) {
+        pv[i].point_w = vec3(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) pv[i].var(r, c) = var9[9 * i + 3 * r + c];
+    }
+    h->kilo->map_manager_->UpdateVoxelMap(pv);
+    return 0;
+}
+int lko_residuals(lko_handle* h, const float* xyz_body, size_t n, double* h6, double* z, double* R, uint8_t* valid) {
+    std::vector<ResidualRow> rows;
+    h->kilo->residualsOnly(xyz_body, n, rows);
+    for (size_t i = 0; i < n; ++i) {
+        valid[i] = rows[i].valid ? 1 : 0;
+        for (int c = 0; c < 6; ++c) h6[6 * i + c] = rows[i].h[c];
+        z[i] = rows[i].z;
+        R[i] = rows[i].R;
+    }
+    return 0;
+}
+int lko_update_points(lko_handle* h, double t, const float* xyz_body, size_t n, float* xyz_world_out,
+                      float* intensity_out, size_t* n_effect) {
+    std::vector<lk_point> pts(n);
+    for (size_t i = 0; i < n; ++i) pts[i] = lk_point{xyz_body[3 * i], xyz_body[3 * i + 1], xyz_body[3 * i + 2], 0.f};
+    std::vector<float> w(4 * n, 0.f);
+    size_t ne = n_effect ? *n_effect : 0;
+    h->kilo->predictUpdatePoint(t, 0, n, pts.data(), w.data(), ne);
+    if (n_effect) *n_effect = ne;
+    for (size_t i = 0; i < n; ++i) {
+        if (xyz_world_out)
+            for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+        if (intensity_out) intensity_out[i] = w[4 * i + 3];
+    }
+    return 0;
+}
+int lko_update_imu(lko_handle* h, const lk_imu* imu) {
+    h->kilo->predictUpdateImu(*imu);
+    return 0;
+}
+int lko_update_kin_imu(lko_handle* h, const lk_kin_imu* kin) {
+    h->kilo->predictUpdateKinImu(*kin);
+    return 0;
+}
+int lko_first_frame(lko_handle* h, const lk_point* raw, size_t n, double end_time, const lk_imu* imus, size_t n_imu,
+                    const lk_kin_imu* kins, size_t n_kin) {
+    h->kilo->firstFrame(raw, n, end_time, imus, n_imu, kins, n_kin);
+    return 0;
+}
+// with_sort != 0 additionally runs the reference's std::sort (KILO.cc:369-370) on a private copy
+// first so that the timed region matches the reference's Timer lambda; results are unaffected
+// because the copy is discarded and the caller's (already sorted) order is the one processed.
+int lko_process_scan(lko_handle* h, const lk_point* sorted_pts, size_t n, double t_begin, const lk_imu* imus,
+                     size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out,
+                     int with_sort) {
+    if (with_sort) {
+        std::vector<lk_point> tmp(sorted_pts, sorted_pts + n);
+        std::sort(tmp.begin(), tmp.end(), [](const lk_point& a, const lk_point& b) { return a.curvature < b.curvature; });
+        volatile float sink = tmp.empty() ? 0.f : tmp[n / 2].x;
+        (void)sink;
+    }
+    std::deque<lk_imu> qi(imus, imus + n_imu);
+    std::deque<lk_kin_imu> qk(kins, kins + n_kin);
+    std::vector<float> w(4 * n, 0.f);
+    size_t ne = 0;
+    uint32_t nb = 0, nu = 0;
+    h->kilo->processSorted(sorted_pts, n, t_begin, qi, qk, w.data(), ne, &nb, &nu);
+    if (xyz_world_out)
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+    if (out) {
+        const State& s = h->kilo->eskf_->state();
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) out->rot[3 * i + j] = s.rot_(i, j);
+            out->pos[i] = s.pos_[i];
+            out->vel[i] = s.vel_[i];
+        }
+        out->n_effect = ne;
+        out->n_buckets = nb;
+        out->n_updates = nu;
+    }
+    return 0;
+}
+
+// ---- blob export in the format of include/legkilo_hip.h (canonical order: roots sorted by key,
+//      nodes in DFS pre-order, children by octant index) ----
+namespace {
+struct Exporter {
+    std::vector<lk_root_rec> roots;
+    std::vector<lk_node_rec> nodes;
+    std::vector<lk_plane_rec> planes;
+    std::vector<lk_block_rec> blocks;
+    int max_layer;
+
+    int add(const VoxelOctoTree* t, const Vec3i* key) {
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        planes.emplace_back();
+        lk_node_rec n;
+        std::memset(&n, 0, sizeof(n));
+        lk_plane_rec p;
+        std::memset(&p, 0, sizeof(p));
+        for (int c = 0; c < 3; ++c) n.voxel_center[c] = t->voxel_center_[c];
+        n.quater_length = t->quater_length_;
+        n.layer = t->layer_;
+        n.npts = (int)t->temp_points_.size();
+        n.new_points = t->new_points_;
+        n.state = (t->init_octo_ ? LK_NODE_INIT_OCTO : 0u) | (t->update_enable_ ? LK_NODE_UPDATE_ENABLE : 0u) |
+                  (t->octo_state_ ? LK_NODE_OCTO_STATE : 0u);
+        n.block = -1;
+        n.list_head = -1;
+        if (key)
+            for (int c = 0; c < 3; ++c) n.key[c] = (*key)[c];
+        const VoxelPlane& pl = *t->plane_ptr_;
+        bool dead = t->init_octo_ && !pl.is_plane_ && t->layer_ < max_layer;  // points never read again
+        if (!dead && n.npts > 0) {
+            if (n.npts <= LK_BLOCK_PTS) {
+                n.block = (int)blocks.size();
+                blocks.emplace_back();
+                lk_block_rec& b = blocks.back();
+                std::memset(&b, 0, sizeof(b));
+                for (int i = 0; i < n.npts; ++i) {
+                    const pointWithVar& pv = t->temp_points_[i];
+                    for (int c = 0; c < 3; ++c) b.pts[i].pw[c] = pv.point_w[c];
+                    b.pts[i].var[0] = pv.var(0, 0), b.pts[i].var[1] = pv.var(0, 1), b.pts[i].var[2] = pv.var(0, 2);
+                    b.pts[i].var[3] = pv.var(1, 1), b.pts[i].var[4] = pv.var(1, 2), b.pts[i].var[5] = pv.var(2, 2);
+                }
+            } else {
+                n.state |= LK_NODE_PTS_DROPPED;
+            }
+        }
+        for (int c = 0; c < 3; ++c) p.center[c] = pl.center_[c], p.normal[c] = pl.normal_[c];
+        p.d = pl.d_;
+        p.radius = pl.radius_;
+        p.flags = (pl.is_plane_ ? LK_PLANE_IS_PLANE : 0u) | (pl.is_init_ ? LK_PLANE_IS_INIT : 0u);
+        p.points_size = pl.points_size_;
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) p.plane_var[k++] = pl.plane_var_(r, c);
+        p.min_eigen_value = pl.min_eigen_value_;
+        p.mid_eigen_value = pl.mid_eigen_value_;
+        p.max_eigen_value = pl.max_eigen_value_;
+        for (int l = 0; l < 8; ++l) n.child[l] = -1;
+        nodes[id] = n;
+        planes[id] = p;
+        for (int l = 0; l < 8; ++l)
+            if (t->leaves_[l]) {
+                int cid = add(t->leaves_[l], nullptr);
+                nodes[id].child[l] = cid;
+            }
+        return id;
+    }
+};
+}  // namespace
+
+int lko_map_export(lko_handle* h, void* blob, size_t* bytes) {
+    auto& m = *h->kilo->map_manager_;
+    std::map<Vec3i, VoxelOctoTree*> sorted(m.voxel_map_.begin(), m.voxel_map_.end());
+    Exporter ex;
+    ex.max_layer = m.config_setting_.max_layer_;
+    for (auto& kv : sorted) {
+        int id = ex.add(kv.second, &kv.first);
+        ex.roots.push_back(lk_root_rec{{kv.first[0], kv.first[1], kv.first[2]}, id});
+    }
+    lk_blob_header hd;
+    std::memset(&hd, 0, sizeof(hd));
+    hd.magic = LK_BLOB_MAGIC;
+    hd.version = LK_ABI_VERSION;
+    hd.n_roots = (uint32_t)ex.roots.size();
+    hd.n_nodes = (uint32_t)ex.nodes.size();
+    hd.n_blocks = (uint32_t)ex.blocks.size();
+    hd.block_pts = LK_BLOCK_PTS;
+    hd.voxel_size = m.config_setting_.max_voxel_size_;
+    hd.max_layer = m.config_setting_.max_layer_;
+    hd.max_points_num = m.config_setting_.max_points_num_;
+    size_t total = sizeof(hd) + ex.roots.size() * sizeof(lk_root_rec) + ex.nodes.size() * sizeof(lk_node_rec) +
+                   ex.planes.size() * sizeof(lk_plane_rec) + ex.blocks.size() * sizeof(lk_block_rec);
+    hd.bytes = total;
+    if (!blob) {
+        *bytes = total;
+        return 0;
+    }
+    if (*bytes < total) return -1;
+    char* p = (char*)blob;
+    std::memcpy(p, &hd, sizeof(hd));
+    p += sizeof(hd);
+    std::memcpy(p, ex.roots.data(), ex.roots.size() * sizeof(lk_root_rec));
+    p += ex.roots.size() * sizeof(lk_root_rec);
+    std::memcpy(p, ex.nodes.data(), ex.nodes.size() * sizeof(lk_node_rec));
+    p += ex.nodes.size() * sizeof(lk_node_rec);
+    std::memcpy(p, ex.planes.data(), ex.planes.size() * sizeof(lk_plane_rec));
+    p += ex.planes.size() * sizeof(lk_plane_rec);
+    std::memcpy(p, ex.blocks.data(), ex.blocks.size() * sizeof(lk_block_rec));
+    *bytes = total;
+    return 0;
+}
+
+int lko_map_stats(lko_handle* h, uint32_t* n_roots) {
+    *n_roots = (uint32_t)h->kilo->map_manager_->voxel_map_.size();
+    return 0;
+}
+
+// ---- unit-level hooks for tests ----
+int lko_calc_body_cov(const double* pb3, float range_inc, float degree_inc, double* cov9) {
+    Vec3 pb = vec3(pb3[0], pb3[1], pb3[2]);
+    Mat3 cov;
+    calcBodyCov(pb, range_inc, degree_inc, cov);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) cov9[3 * i + j] = cov(i, j);
+    return 0;
+}
+int lko_eig_sym3(const double* A9, double* evals3, double* evecs9) {
+    Mat3 A, V;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A(i, j) = A9[3 * i + j];
+    eig_sym3(A, evals3, V);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) evecs9[3 * i + j] = V(i, j);
+    return 0;
+}
+int lko_init_plane(const double* pw, const double* var9, size_t n, float planer_threshold, lk_plane_rec* out,
+                   double* plane_var36) {
+    VoxelOctoTree t(2, 0, 5, 50, planer_threshold);
+    std::vector<pointWithVar> pts(n);
+    for (size_t i = 0; i < n; ++i) {
+        pts[i].point_w = vec3(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) pts[i].var(r, c) = var9[9 * i + 3 * r + c];
+    }
+    t.init_plane(pts, t.plane_ptr_);
+    const VoxelPlane& pl = *t.plane_ptr_;
+    std::memset(out, 0, sizeof(*out));
+    for (int c = 0; c < 3; ++c) out->center[c] = pl.center_[c], out->normal[c] = pl.normal_[c];
+    out->d = pl.d_;
+    out->radius = pl.radius_;
+    out->flags = pl.is_plane_ ? LK_PLANE_IS_PLANE : 0u;
+    out->points_size = pl.points_size_;
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) out->plane_var[k++] = pl.plane_var_(r, c);
+    out->min_eigen_value = pl.min_eigen_value_;
+    out->mid_eigen_value = pl.mid_eigen_value_;
+    out->max_eigen_value = pl.max_eigen_value_;
+    if (plane_var36)
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) plane_var36[6 * r + c] = pl.plane_var_(r, c);
+    return 0;
+}
+int lko_exp_log(const double* v3, double* R9_exp3, double* R9_expvec, double* log3) {
+    Mat3 a = Exp3(v3[0], v3[1], v3[2]);
+    Mat3 b = ExpVec(vec3(v3[0], v3[1], v3[2]));
+    Vec3 l = LogSO3(a);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R9_exp3[3 * i + j] = a(i, j), R9_expvec[3 * i + j] = b(i, j);
+        log3[i] = l[i];
+    }
+    return 0;
+}
+size_t lko_hash_vec3(int x, int y, int z) { return hash_vec3()(Vec3i{x, y, z}); }
+int lko_abi_sizes(size_t* out8) {
+    out8[0] = sizeof(lk_config), out8[1] = sizeof(lk_point), out8[2] = sizeof(lk_imu), out8[3] = sizeof(lk_kin_imu);
+    out8[4] = sizeof(lk_pose), out8[5] = sizeof(lk_plane_rec), out8[6] = sizeof(lk_node_rec), out8[7] = sizeof(lk_block_rec);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product; nothing under
+// leg-kilo_amd/ may include, link or call this.  PARITY UNPINNED: the reference
+// cannot be built here (no Eigen/PCL/ROS) and ships no golden vectors.
+//
+// Minimal dependency-free fp64 dense helpers standing in for the Eigen
+// operations the reference path uses (Eigen::Matrix products, PartialPivLU
+// inverse behind MatrixXd::inverse(), EigenSolver<Matrix3d> on a symmetric
+// input).  Plain triple loops, no FMA contraction (built with -ffp-contract=off,
+// matching the reference's plain -O3 x86-64 build, legkilo/CMakeLists.txt:14-15).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace lko {
+
+template <int R, int C>
+struct Mat {
+    double m[R][C];
+    static Mat Zero() {
+        Mat a;
+        std::memset(a.m, 0, sizeof(a.m));
+        return a;
+    }
+    static Mat Identity() {
+        Mat a = Zero();
+        for (int i = 0; i < (R < C ? R : C); ++i) a.m[i][i] = 1.0;
+        return a;
+    }
+    double& operator()(int i, int j) { return m[i][j]; }
+    double operator()(int i, int j) const { return m[i][j]; }
+    // vector access for C==1
+    double& operator[](int i) { return m[i][0]; }
+    double operator[](int i) const { return m[i][0]; }
+    Mat<C, R> T() const {
+        Mat<C, R> t;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < C; ++j) t.m[j][i] = m[i][j];
+        return t;
+    }
+};
+
+using Vec3 = Mat<3, 1>;
+using Mat3 = Mat<3, 3>;
+using Mat6 = Mat<6, 6>;
+
+template <int R, int K, int C>
+inline Mat<R, C> operator*(const Mat<R, K>& a, const Mat<K, C>& b) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += a.m[i][k] * b.m[k][j];
+            c.m[i][j] = s;
+        }
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C> operator+(const Mat<R, C>& a, const Mat<R, C>& b) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) c.m[i][j] = a.m[i][j] + b.m[i][j];
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C> operator-(const Mat<R, C>& a, const Mat<R, C>& b) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) c.m[i][j] = a.m[i][j] - b.m[i][j];
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C> operator-(const Mat<R, C>& a) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) c.m[i][j] = -a.m[i][j];
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C> operator*(double s, const Mat<R, C>& a) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) c.m[i][j] = s * a.m[i][j];
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C> operator*(const Mat<R, C>& a, double s) {
+    return s * a;
+}
+template <int R, int C>
+inline Mat<R, C> operator/(const Mat<R, C>& a, double s) {
+    Mat<R, C> c;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) c.m[i][j] = a.m[i][j] / s;
+    return c;
+}
+template <int R, int C>
+inline Mat<R, C>& operator+=(Mat<R, C>& a, const Mat<R, C>& b) {
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) a.m[i][j] += b.m[i][j];
+    return a;
+}
+
+inline Vec3 vec3(double x, double y, double z) {
+    Vec3 v;
+    v[0] = x, v[1] = y, v[2] = z;
+    return v;
+}
+inline double dot(const Vec3& a, const Vec3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(const Vec3& a) { return std::sqrt(dot(a, a)); }
+inline Vec3 cross(const Vec3& a, const Vec3& b) {
+    return vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+// Eigen normalize(): divide by the norm when squaredNorm > 0
+inline void normalize(Vec3& a) {
+    double z = dot(a, a);
+    if (z > 0) {
+        double n = std::sqrt(z);
+        a[0] /= n, a[1] /= n, a[2] /= n;
+    }
+}
+
+// math_utils.hpp:12-17
+inline Mat3 skew(const Vec3& v) {
+    Mat3 m;
+    m(0, 0) = 0.0, m(0, 1) = -v[2], m(0, 2) = v[1];
+    m(1, 0) = v[2], m(1, 1) = 0.0, m(1, 2) = -v[0];
+    m(2, 0) = -v[1], m(2, 1) = v[0], m(2, 2) = 0.0;
+    return m;
+}
+
+// Rodrigues body shared by the three Exp overloads (math_utils.hpp:19-68):
+//   Eye3 + sin(a)*K + (1-cos(a))*K*K,  K = skew(axis)
+inline Mat3 rodrigues(const Vec3& axis, double ang) {
+    Mat3 K = skew(axis);
+    return Mat3::Identity() + std::sin(ang) * K + (1.0 - std::cos(ang)) * (K * K);
+}
+// math_utils.hpp:19-32  Exp(vec&&): threshold 1e-7
+inline Mat3 ExpVec(const Vec3& ang) {
+    double n = norm(ang);
+    if (n > 0.0000001) return rodrigues(ang / n, n);
+    return Mat3::Identity();
+}
+// math_utils.hpp:54-68  Exp(v1,v2,v3): threshold 1e-5
+inline Mat3 Exp3(double v1, double v2, double v3) {
+    double n = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    if (n > 0.00001) return rodrigues(vec3(v1 / n, v2 / n, v3 / n), n);
+    return Mat3::Identity();
+}
+// math_utils.hpp:71-76
+inline Vec3 LogSO3(const Mat3& R) {
+    double tr = R(0, 0) + R(1, 1) + R(2, 2);
+    double theta = (tr > 3.0 - 1e-6) ? 0.0 : std::acos(0.5 * (tr - 1));
+    Vec3 K = vec3(R(2, 1) - R(1, 2), R(0, 2) - R(2, 0), R(1, 0) - R(0, 1));
+    return (std::abs(theta) < 0.001) ? (0.5 * K) : ((0.5 * theta / std::sin(theta)) * K);
+}
+
+// ---- dynamic matrix (row-major) for the literal N x N update (eskf.cc:105-112) ----
+struct MatX {
+    int r = 0, c = 0;
+    std::vector<double> d;
+    MatX() = default;
+    MatX(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+};
+inline MatX matmul(const MatX& a, const MatX& b) {
+    MatX o(a.r, b.c);
+    for (int i = 0; i < a.r; ++i)
+        for (int k = 0; k < a.c; ++k) {
+            double aik = a(i, k);
+            const double* bk = &b.d[(size_t)k * b.c];
+            double* oi = &o.d[(size_t)i * o.c];
+            for (int j = 0; j < b.c; ++j) oi[j] += aik * bk[j];
+        }
+    return o;
+}
+// Inverse by LU with partial pivoting (what Eigen's MatrixXd::inverse() does for n > 4).
+inline MatX inverse(const MatX& a_in) {
+    int n = a_in.r;
+    if (a_in.c != n) throw std::runtime_error("inverse: not square");
+    MatX a = a_in;
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::abs(a(k, k));
+        for (int i = k + 1; i < n; ++i)
+            if (std::abs(a(i, k)) > best) best = std::abs(a(i, k)), p = i;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(a(k, j), a(p, j));
+            std::swap(perm[k], perm[p]);
+        }
+        double piv = a(k, k);
+        for (int i = k + 1; i < n; ++i) {
+            double f = a(i, k) / piv;
+            a(i, k) = f;
+            if (f != 0.0)
+                for (int j = k + 1; j < n; ++j) a(i, j) -= f * a(k, j);
+        }
+    }
+    MatX inv(n, n);
+    std::vector<double> y(n);
+    for (int col = 0; col < n; ++col) {
+        // solve L U x = P e_col
+        for (int i = 0; i < n; ++i) {
+            double s = (perm[i] == col) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s -= a(i, j) * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < n; ++j) s -= a(i, j) * inv(j, col);
+            inv(i, col) = s / a(i, i);
+        }
+    }
+    return inv;
+}
+template <int N>
+inline Mat<N, N> inverse(const Mat<N, N>& a) {
+    MatX x(N, N);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) x(i, j) = a(i, j);
+    MatX xi = inverse(x);
+    Mat<N, N> o;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) o(i, j) = xi(i, j);
+    return o;
+}
+
+// Eigen-decomposition of a SYMMETRIC 3x3 by cyclic Jacobi rotations.  Stands in for
+// Eigen::EigenSolver<Matrix3d> at voxel_map.cc:55 (the input covariance is exactly
+// symmetric, so the real parts the reference takes are the symmetric eigenpairs; any
+// correct solver agrees to rounding; eigenvector sign/order is not relied upon).
+// evecs columns are unit eigenvectors; evals[k] belongs to column k.
+inline void eig_sym3(const Mat3& A, double evals[3], Mat3& evecs) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) a[i][j] = A(i, j);
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-300 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = ((theta >= 0) ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
+                double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {  // A <- A * J
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {  // A <- J^T * A
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int k = 0; k < 3; ++k) evals[k] = a[k][k];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) evecs(i, j) = v[i][j];
+}
+
+}  // namespace lko
