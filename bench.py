@@ -1,0 +1,312 @@
+#!/usr/bin/env python
+"""bench.py — LiDAR scans/s through the per-time-bucket ESKF update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+
+Workload (BASELINE.json metric "LiDAR scans/sec (per-point ESKF update), 100k-pt scan, 1->8 MI355X"):
+  primary   config 5 per-GPU shard with config 3's per-scan semantics: one step = one batch of
+            `--scans-per-gpu` (default 128 -> 1024 scans at 8 GPUs) independent 100 000-point scans, each
+            run through the full per-bucket ESKF update (5 time buckets x 20 000 points: predict ->
+            voxel-hash plane matching + residual rows + A/b reduction -> 6x6 information-form update)
+            against ONE shared voxel map, frozen (inserts disabled on both GPU and oracle), each scan from
+            its own perturbed prior.  Scans are resident in HBM before the timed region.
+            N>1: rank 0 builds the map and broadcasts the device blob over RCCL; scans are sharded
+            (weak scaling: per-GPU work fixed); per-step results are all-gathered.
+  extra     config 3 as one sequential stream with map insert (the reference's own semantics):
+            latency-bound, reported as `stream_scans_per_s`.
+The JSON line carries `roofline` (dominant kernel = lk_residual_kernel, HBM bound, algorithmic
+288 B/point, duration from HIP events on the handle's stream) and `cpu_baseline` (the oracle — a
+port, the reference cannot be built here — single thread, bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import lk_pkg  # noqa: E402
+
+lk_pkg.load()
+from legkilo_amd import binding, config, synth  # noqa: E402
+
+ALG_BYTES_RESIDUAL = 288   # scan pt 16 + hash slot 16 + plane record 240 + world pt 16
+ALG_BYTES_FULL = 1016      # + update pass 728 (re-projection write, map append, amortised refit)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+N_PTS = 100_000
+N_BUCKETS = 5
+
+
+class Frozen:
+    def __init__(self, tr, t):
+        self.tr, self.t = tr, t
+
+    def rot(self, tt):
+        return self.tr.rot(np.full(np.shape(tt), self.t))
+
+    def pos(self, tt):
+        return self.tr.pos(np.full(np.shape(tt), self.t))
+
+
+def xyz_of(pts):
+    return np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
+
+
+def world_of(x36, xyz_body, P):
+    R = x36[:9].reshape(3, 3)
+    E = np.array(P["extrinsic_R"], float).reshape(3, 3)
+    T = np.array(P["extrinsic_T"], float)
+    return ((xyz_body.astype(np.float64) @ E.T + T) @ R.T + x36[9:12]).astype(np.float32)
+
+
+def build_map(obj, world, traj, P, t0, n_warm):
+    """First frame (dense static cloud) + n_warm dense scans through the full path with inserts."""
+    x0 = synth.initial_state(traj, t0, P)
+    obj.set_state(x0, 1e-6 * np.eye(30))
+    obj.init_process_cov_q()
+    obj.set_acc_norm(9.81)
+    obj.set_times(t0, t0)
+    raw = synth.dense_scan(world, Frozen(traj, t0), t0, P, n=N_PTS, n_buckets=1, seed_scan=777)
+    xb = xyz_of(raw)
+    obj.map_build(world_of(x0, xb, P), xb)
+    for k in range(n_warm):
+        tb = t0 + 0.1 * k
+        pts = synth.dense_scan(world, traj, tb, P, n=N_PTS, n_buckets=N_BUCKETS, seed_scan=2002 + k, seed_noise=3003 + k)
+        obj.process_scan(pts, tb)
+    return t0 + 0.1 * n_warm
+
+
+def make_batch(world, traj, P, t_start, n_scans, rank):
+    rng = np.random.default_rng(5005 + 7919 * rank)
+    scans, xs = [], []
+    for s in range(n_scans):
+        tb = t_start + 0.05 * (s + n_scans * rank)
+        scans.append(synth.dense_scan(world, traj, tb, P, n=N_PTS, n_buckets=N_BUCKETS, seed_scan=5005 + s + 100000 * rank,
+                                      seed_noise=6006 + s + 100000 * rank))
+        xs.append(synth.initial_state(traj, tb, P, rng, 0.02, 0.5))
+    off, dt = synth.buckets_of(scans[0])
+    return scans, np.array(xs), off, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scans-per-gpu", type=int, default=128)
+    ap.add_argument("--unique-scans", type=int, default=16, help="distinct synthetic scans generated per GPU (tiled to the batch)")
+    ap.add_argument("--map-warm", type=int, default=6)
+    ap.add_argument("--stream-scans", type=int, default=6)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="scans the oracle replays for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_size}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    P = config.LEG_FUSION
+    S = args.scans_per_gpu
+    world, traj = synth.World(), synth.Trajectory()
+    cfg = config.make_config(P, device_id=local_rank, n_slots=S, max_roots=1 << 17, max_nodes=1 << 18,
+                             max_point_blocks=1 << 17, max_scan_points=1 << 17)
+    g = binding.LegKiloHip(cfg)  # raises without the HIP library / a gfx950 device
+
+    # ---- shared map: rank 0 builds, RCCL broadcast of the device blob over xGMI
+    t0 = 5.0
+    t_map0 = time.time()
+    if rank == 0:
+        t_after = build_map(g, world, traj, P, t0, args.map_warm)
+    else:
+        g.init_process_cov_q()
+        t_after = t0 + 0.1 * args.map_warm
+    bcast_ms = None
+    if world_size > 1:
+        nbytes = torch.tensor([g.map_export_dev_size() if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(nbytes, 0)
+        blob = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            g.map_export_dev(blob.data_ptr(), blob.numel())
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb0 = time.time()
+        dist.broadcast(blob, 0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.time() - tb0) * 1e3
+        if rank != 0:
+            g.map_import_dev(blob.data_ptr(), blob.numel())
+        map_bytes = blob.numel()
+        del blob
+    else:
+        map_bytes = g.map_export_dev_size()
+    n_roots, n_nodes, n_blocks = g.map_stats()
+    map_build_s = time.time() - t_map0
+
+    # ---- resident batch: U unique scans tiled to S slots (each slot still gets its own prior)
+    U = min(args.unique_scans, S)
+    scans, xs_u, off, dt = make_batch(world, traj, P, t_after, U, rank)
+    rngp = np.random.default_rng(9009 + rank)
+    tile = np.arange(S) % U
+    xs = xs_u[tile].copy()
+    xs[:, 9:12] += rngp.normal(0, 0.005, (S, 3))  # de-duplicate the tiled priors
+    Ps = np.tile((1e-4 * np.eye(30)).reshape(1, 900), (S, 1))
+    allpts = np.concatenate([scans[u] for u in tile])
+    d_batch = torch.empty(allpts.nbytes, dtype=torch.uint8, device=dev)
+    g.h2d(d_batch.data_ptr(), allpts)
+
+    def step():
+        g.batch_set_priors(xs, Ps)
+        poses = g.batch_replay_dev(d_batch.data_ptr(), S, N_PTS, 0.0, off, dt)
+        if dist is not None:
+            res = torch.from_numpy(np.array([[p.pos[0], p.pos[1], p.pos[2], float(p.n_effect)] for p in poses])).to(dev)
+            out = [torch.empty_like(res) for _ in range(world_size)]
+            dist.all_gather(out, res)
+        return poses
+
+    def sync_all():
+        g.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        poses = step()
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        poses = step()
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_eff = float(np.mean([p.n_effect for p in poses]))
+    total_scans = S * world_size * args.steps
+    value = total_scans / elapsed
+
+    # ---- kernel-level timing pass (HIP events on the handle's stream), outside the timed region
+    g.profile_reset()
+    g.profile_enable(1)
+    step()
+    g.profile_enable(0)
+    prof = {k: g.profile_get(k) for k in ("predict", "residual", "update")}
+    n_res, ms_res = prof["residual"]
+    avg_res_ms = ms_res / max(n_res, 1)
+    pts_per_launch = S * (N_PTS // N_BUCKETS)
+    achieved = ALG_BYTES_RESIDUAL * pts_per_launch / (avg_res_ms * 1e-3) / 1e9 if n_res else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_residual.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "kernel": "lk_residual_kernel<false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "alg_bytes_per_point": ALG_BYTES_RESIDUAL, "points_per_launch": pts_per_launch,
+        "avg_launch_ms": round(avg_res_ms, 4), "launches": n_res,
+        "whole_scan_alg_GBs": round(ALG_BYTES_RESIDUAL * N_PTS * value / 1e9, 1),
+        "other_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items() if k != "residual"},
+    }
+
+    # ---- extra: config 3 as one sequential stream with map insert (rank 0 only, after the batch bench)
+    extra = {"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
+             "mean_n_effect": n_eff, "rccl_map_broadcast_ms": bcast_ms}
+    cpu_baseline = None
+    if rank == 0:
+        g.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30), slot=0)
+        g.set_times(t_after, t_after)
+        ns = args.stream_scans
+        sscans = [synth.dense_scan(world, traj, t_after + 0.1 * k, P, n=N_PTS, n_buckets=N_BUCKETS, seed_scan=8008 + k,
+                                   seed_noise=8108 + k) for k in range(ns)]
+        d_s = torch.empty(ns * N_PTS * 16, dtype=torch.uint8, device=dev)
+        g.h2d(d_s.data_ptr(), np.concatenate(sscans))
+        g.process_scan_dev(d_s.data_ptr(), N_PTS, t_after, off, dt)  # warm
+        g.synchronize()
+        ts = time.perf_counter()
+        for k in range(1, ns):
+            g.process_scan_dev(d_s.data_ptr() + k * N_PTS * 16, N_PTS, t_after + 0.1 * k, off, dt)
+        g.synchronize()
+        stream_s = (time.perf_counter() - ts) / (ns - 1)
+        extra["stream_scans_per_s"] = round(1.0 / stream_s, 1)
+        extra["stream_ms_per_scan"] = round(stream_s * 1e3, 3)
+        extra["stream_alg_GBs"] = round(ALG_BYTES_FULL * N_PTS / stream_s / 1e9, 1)
+
+        # ---- CPU baseline: the oracle (port), 1 pinned thread, bounded sample of the SAME primary workload
+        if args.cpu_sample > 0 and world_size == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_binding as ob
+
+            try:
+                os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})
+            except Exception:
+                pass
+            o = ob.Oracle(cfg, imu_mode_only=True)
+            build_map(o, world, traj, P, t0, args.map_warm)
+            o.set_map_insert(False)
+            tcs = []
+            for s in range(args.cpu_sample):
+                o.set_state(xs[s], Ps[s])
+                o.set_times(0.0, 0.0)
+                tc = time.perf_counter()
+                o.process_scan(scans[tile[s]], 0.0, with_sort=True)
+                tcs.append(time.perf_counter() - tc)
+            # and the full config-3 path with insert (the reference's own timed lambda, KILO.cc:367-396)
+            o.set_map_insert(True)
+            o.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30))
+            o.set_times(t_after, t_after)
+            tfull = []
+            for k in range(min(3, ns)):
+                tc = time.perf_counter()
+                o.process_scan(sscans[k], t_after + 0.1 * k, with_sort=True)
+                tfull.append(time.perf_counter() - tc)
+            cpu_baseline = {
+                "value": round(1.0 / float(np.median(tcs)), 3), "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": f"{args.cpu_sample} of the batch's 100k-pt scans (5 buckets, frozen map, 6x6-form update), "
+                          "median, sort included (KILO.cc:367-396)",
+                "full_path_with_insert_scans_per_s": round(1.0 / float(np.median(tfull)), 3),
+                "host_cores_available": os.cpu_count(),
+            }
+            extra["speedup_vs_cpu_port"] = round(value / cpu_baseline["value"], 1)
+            extra["stream_speedup_vs_cpu_port"] = round(extra["stream_scans_per_s"] / cpu_baseline["full_path_with_insert_scans_per_s"], 1)
+            o.close()
+
+    if rank == 0:
+        line = {
+            "metric": "LiDAR scans/sec (per-point ESKF update), 100k-pt scan", "value": round(value, 2), "unit": "scans/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config5 shard: batch replay of 100k-pt scans, 5 buckets x 20k, full ESKF update, "
+                                   "shared frozen voxel map (RCCL broadcast when N>1)",
+                       "scans_per_gpu": S, "points_per_scan": N_PTS, "buckets": N_BUCKETS, "parallelism": f"replay-shard x{world_size}"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
+        }
+        print(json.dumps(line))
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

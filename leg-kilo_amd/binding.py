@@ -1,0 +1,283 @@
+"""ctypes wrapper over liblegkilo_hip.so (the C-ABI of include/legkilo_hip.h).
+
+There is no fallback: if the shared library is missing or no gfx950 device is visible the
+constructor raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblegkilo_hip.so")
+
+EXPORTS = [
+    "lk_abi_version", "lk_create", "lk_destroy", "lk_last_error", "lk_set_state", "lk_get_state", "lk_set_Q", "lk_get_Q",
+    "lk_init_process_cov_q", "lk_set_times", "lk_get_times", "lk_set_acc_norm", "lk_get_fx", "lk_get_function_f",
+    "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
+    "lk_residuals", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
+    "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
+    "lk_batch_set_priors", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
+]
+
+
+class LegKiloError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_HERE, "..", "include", "legkilo_hip.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps):
+        subprocess.check_call(["make", "-C", csrc, "-B"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LegKiloError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.lk_last_error.restype = C.c_char_p
+        L.lk_last_error.argtypes = [C.c_void_p]
+        L.lk_stream.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class LegKiloHip:
+    def __init__(self, cfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.L.lk_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.lk_last_error(None)
+            self.h = None
+            raise LegKiloError(f"lk_create failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.L.lk_last_error(self.h)
+            raise LegKiloError(f"liblegkilo_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ESKF surface ----
+    def set_state(self, x36=None, P=None, slot=0):
+        x36 = None if x36 is None else _f64(x36).reshape(36)
+        P = None if P is None else _f64(P).reshape(900)
+        self._chk(self.L.lk_set_state(self.h, C.c_uint32(slot), _p(x36), _p(P)))
+
+    def get_state(self, slot=0):
+        x, P = np.zeros(36), np.zeros(900)
+        self._chk(self.L.lk_get_state(self.h, C.c_uint32(slot), _p(x), _p(P)))
+        return x, P.reshape(30, 30)
+
+    def set_Q(self, Q):
+        Q = _f64(Q).reshape(900)
+        self._chk(self.L.lk_set_Q(self.h, _p(Q)))
+
+    def get_Q(self):
+        Q = np.zeros(900)
+        self._chk(self.L.lk_get_Q(self.h, _p(Q)))
+        return Q.reshape(30, 30)
+
+    def init_process_cov_q(self):
+        self._chk(self.L.lk_init_process_cov_q(self.h))
+
+    def set_times(self, last_predict_t, last_update_t, slot=0):
+        self._chk(self.L.lk_set_times(self.h, C.c_uint32(slot), C.c_double(last_predict_t), C.c_double(last_update_t)))
+
+    def get_times(self, slot=0):
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.L.lk_get_times(self.h, C.c_uint32(slot), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_acc_norm(self, a):
+        self._chk(self.L.lk_set_acc_norm(self.h, C.c_double(a)))
+
+    def get_fx(self, dt, slot=0):
+        F = np.zeros(900)
+        self._chk(self.L.lk_get_fx(self.h, C.c_uint32(slot), C.c_double(dt), _p(F)))
+        return F.reshape(30, 30)
+
+    def get_function_f(self, dt, slot=0):
+        f = np.zeros(30)
+        self._chk(self.L.lk_get_function_f(self.h, C.c_uint32(slot), C.c_double(dt), _p(f)))
+        return f
+
+    def predict(self, dt, prop_state, prop_cov, slot=0):
+        self._chk(self.L.lk_predict(self.h, C.c_uint32(slot), C.c_double(dt), int(prop_state), int(prop_cov)))
+
+    def update_by_points(self, h6, z, R, slot=0):
+        h6, z, R = _f64(h6), _f64(z), _f64(R)
+        self._chk(self.L.lk_update_by_points(self.h, C.c_uint32(slot), _p(h6), _p(z), _p(R), C.c_size_t(len(z))))
+
+    def update_by_imu(self, z6, R6, slot=0):
+        z6, R6 = _f64(z6), _f64(R6)
+        self._chk(self.L.lk_update_by_imu(self.h, C.c_uint32(slot), _p(z6), _p(R6)))
+
+    def update_by_kin_imu(self, ki_h, ki_z, ki_R, slot=0):
+        ki_h, ki_z, ki_R = _f64(ki_h), _f64(ki_z), _f64(ki_R)
+        self._chk(self.L.lk_update_by_kin_imu(self.h, C.c_uint32(slot), _p(ki_h), _p(ki_z), _p(ki_R), C.c_size_t(len(ki_z))))
+
+    # ---- VoxelMapManager surface ----
+    def map_build(self, xyz_world, xyz_body):
+        w = np.ascontiguousarray(xyz_world, dtype=np.float32)
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        self._chk(self.L.lk_map_build(self.h, _p(w), _p(b), C.c_size_t(len(w))))
+
+    def map_update(self, pw, var9):
+        pw, var9 = _f64(pw), _f64(var9)
+        self._chk(self.L.lk_map_update(self.h, _p(pw), _p(var9), C.c_size_t(len(pw))))
+
+    def residuals(self, xyz_body):
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        n = len(b)
+        h6, z, R, valid = np.zeros((n, 6)), np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.lk_residuals(self.h, _p(b), C.c_size_t(n), _p(h6), _p(z), _p(R), _p(valid)))
+        return h6, z, R, valid
+
+    def map_stats(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.lk_map_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def map_export(self):
+        nbytes = C.c_size_t(0)
+        self._chk(self.L.lk_map_export(self.h, None, C.byref(nbytes)))
+        buf = np.zeros(nbytes.value, dtype=np.uint8)
+        self._chk(self.L.lk_map_export(self.h, _p(buf), C.byref(nbytes)))
+        return buf
+
+    def map_import(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self.L.lk_map_import(self.h, _p(blob), C.c_size_t(blob.size)))
+
+    def map_export_dev_size(self):
+        nbytes = C.c_size_t(0)
+        self._chk(self.L.lk_map_export_dev(self.h, None, C.byref(nbytes)))
+        return nbytes.value
+
+    def map_export_dev(self, d_ptr, nbytes):
+        nb = C.c_size_t(nbytes)
+        self._chk(self.L.lk_map_export_dev(self.h, C.c_void_p(d_ptr), C.byref(nb)))
+        return nb.value
+
+    def map_import_dev(self, d_ptr, nbytes):
+        self._chk(self.L.lk_map_import_dev(self.h, C.c_void_p(d_ptr), C.c_size_t(nbytes)))
+
+    # ---- KILO path ----
+    def update_points(self, t, xyz_body):
+        b = np.ascontiguousarray(xyz_body, dtype=np.float32)
+        n = len(b)
+        w = np.zeros((n, 3), dtype=np.float32)
+        inten = np.zeros(n, dtype=np.float32)
+        ne = C.c_size_t(0)
+        self._chk(self.L.lk_update_points(self.h, C.c_double(t), _p(b), C.c_size_t(n), _p(w), _p(inten), C.byref(ne)))
+        return w, inten, ne.value
+
+    def update_imu(self, imu_rec):
+        a = np.ascontiguousarray(imu_rec)
+        self._chk(self.L.lk_update_imu(self.h, _p(a)))
+
+    def update_kin_imu(self, kin_rec):
+        a = np.ascontiguousarray(kin_rec)
+        self._chk(self.L.lk_update_kin_imu(self.h, _p(a)))
+
+    def process_scan(self, sorted_pts, t_begin, imus=None, kins=None, want_world=False):
+        pts = np.ascontiguousarray(sorted_pts)
+        ni = 0 if imus is None else len(imus)
+        nk = 0 if kins is None else len(kins)
+        imus = None if imus is None else np.ascontiguousarray(imus)
+        kins = None if kins is None else np.ascontiguousarray(kins)
+        w = np.zeros((len(pts), 3), dtype=np.float32) if want_world else None
+        pose = abi.lk_pose()
+        self._chk(self.L.lk_process_scan(self.h, _p(pts), C.c_size_t(len(pts)), C.c_double(t_begin), _p(imus), C.c_size_t(ni),
+                                         _p(kins), C.c_size_t(nk), _p(w), C.byref(pose)))
+        return pose, w
+
+    def process_scan_dev(self, d_pts, n, t_begin, bucket_off, bucket_dt):
+        off = np.ascontiguousarray(bucket_off, dtype=np.uint32)
+        dt = _f64(bucket_dt)
+        pose = abi.lk_pose()
+        self._chk(self.L.lk_process_scan_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n), C.c_double(t_begin), _p(off), _p(dt),
+                                             C.c_size_t(len(dt)), C.byref(pose)))
+        return pose
+
+    # ---- batch replay ----
+    def batch_set_priors(self, x36, P900):
+        x36 = _f64(x36).reshape(-1, 36)
+        P900 = _f64(P900).reshape(-1, 900)
+        assert len(x36) == len(P900)
+        self._chk(self.L.lk_batch_set_priors(self.h, _p(x36), _p(P900), C.c_size_t(len(x36))))
+
+    def batch_replay_dev(self, d_pts, n_scans, n_pts, t_begin, bucket_off, bucket_dt, want_poses=True):
+        off = np.ascontiguousarray(bucket_off, dtype=np.uint32)
+        dt = _f64(bucket_dt)
+        poses = (abi.lk_pose * n_scans)() if want_poses else None
+        self._chk(self.L.lk_batch_replay_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts),
+                                             C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
+        return poses
+
+    # ---- measurement / memory hooks ----
+    def profile_enable(self, on):
+        self._chk(self.L.lk_profile_enable(self.h, int(on)))
+
+    def profile_get(self, name):
+        n, ms = C.c_uint64(), C.c_double()
+        self._chk(self.L.lk_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def profile_reset(self):
+        self._chk(self.L.lk_profile_reset(self.h))
+
+    def device_malloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.L.lk_device_malloc(self.h, C.byref(p), C.c_size_t(nbytes)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._chk(self.L.lk_device_free(self.h, C.c_void_p(ptr)))
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.lk_memcpy_h2d(self.h, C.c_void_p(d_ptr), _p(arr), C.c_size_t(arr.nbytes)))
+
+    def d2h(self, arr, d_ptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._chk(self.L.lk_memcpy_d2h(self.h, _p(arr), C.c_void_p(d_ptr), C.c_size_t(arr.nbytes)))
+
+    def synchronize(self):
+        self._chk(self.L.lk_synchronize(self.h))
+
+    def stream(self):
+        return self.L.lk_stream(self.h)

