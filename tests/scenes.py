@@ -78,7 +78,7 @@ def vlp_scan_input(scene, tb, k):
     return ds
 
 
-def replay_vlp(obj, scene, t0, n_scans, use_kin=False, start=0, collect=None):
+def replay_vlp(obj, scene, t0, n_scans, use_kin=False, start=0, collect=None):  # noqa: C901
     """Replay n_scans 10 Hz scans through obj.process_scan; returns list of (pose, x36)."""
     out = []
     for k in range(start, start + n_scans):
@@ -145,8 +145,8 @@ def _expand21(v):
     return M
 
 
-def compare_planes(pa, pb, rtol, where):
-    assert np.allclose(pa["center"], pb["center"], rtol=0, atol=1e-9), (where, pa["center"], pb["center"])
+def compare_planes(pa, pb, rtol, where, ptol=1e-9):
+    assert np.allclose(pa["center"], pb["center"], rtol=0, atol=ptol), (where, pa["center"], pb["center"])
     s = 1.0 if np.dot(pa["normal"], pb["normal"]) > 0 else -1.0
     assert np.allclose(pa["normal"], s * pb["normal"], rtol=0, atol=1e-7), (where, pa["normal"], pb["normal"])
     assert abs(pa["d"] - s * pb["d"]) <= 1e-5 * max(1.0, abs(pa["d"])), (where, pa["d"], pb["d"])
@@ -166,7 +166,7 @@ def compare_nodes(a, b, where, rtol=1e-6, stats=None, ptol=1e-9):
     assert (a["state"] & keep) == (b["state"] & keep), (where, "state", a["state"], b["state"])
     assert np.array_equal(a["center"], b["center"]) and a["quater"] == b["quater"], (where, "geometry")
     if a["is_plane"]:
-        compare_planes(a["plane"], b["plane"], rtol, where)
+        compare_planes(a["plane"], b["plane"], rtol, where, ptol)
     assert (a["pts"] is None) == (b["pts"] is None), (where, "points presence", a["npts"], a["state"], b["state"])
     if a["pts"] is not None:
         dpw = np.abs(a["pts"]["pw"] - b["pts"]["pw"]).max()

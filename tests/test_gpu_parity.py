@@ -247,22 +247,31 @@ def test_update_points_bucket_and_insert(pair, scene):
 
 
 # ----------------------------------------------------------------------------- full sequences
-def test_sequence_imu_mode(pair, scene):
-    """Config 1 shape: first-frame build + 12 real-like scans (hundreds of small buckets each), IMU-only mode."""
+@pytest.mark.parametrize("literal", [True, False])
+def test_sequence_imu_mode(pair, scene, literal):
+    """Config 1 shape: first-frame build + 12 real-like scans (hundreds of small buckets each), IMU-only mode.
+    literal=True : the oracle runs the reference's literal N x N inverse (eskf.cc:105-112) for every bucket;
+    literal=False: the oracle uses the algebraically identical 6 x 6 form -> only summation order differs,
+                   so the tolerance is two orders tighter."""
     o, g = pair
+    o.set_literal_max_n(512 if literal else 0)
+    tol = 1e-6 if literal else 1e-7
     t0 = 1.0
     for obj in pair:
         x0 = scenes.init_filter(obj, scene, t0)
         scenes.first_frame(obj, scene, t0, x0)
     ro = scenes.replay_vlp(o, scene, t0, 12)
     rg = scenes.replay_vlp(g, scene, t0, 12)
+    worst = 0.0
     for k, ((po, xo), (pg, xg)) in enumerate(zip(ro, rg)):
         assert (po.n_buckets, po.n_updates, po.n_effect) == (pg.n_buckets, pg.n_updates, pg.n_effect), k
-        assert np.abs(xo[9:12] - xg[9:12]).max() < 1e-7, (k, np.abs(xo[9:12] - xg[9:12]).max())
+        worst = max(worst, np.abs(xo[9:12] - xg[9:12]).max())
+    assert worst < tol, worst
     ate = scenes.ate([x[9:12] for _, x in ro], [x[9:12] for _, x in rg])
-    assert ate < 1e-7, ate
-    # after 12 scans the stored points carry the accumulated (<=1e-7 m) state delta
-    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+    assert ate < tol, ate  # north star: ATE delta < 1 mm
+    print(f"literal={literal}: worst position delta {worst:.3e} m, ATE delta {ate:.3e} m")
+    # the stored points / plane centres carry the accumulated state delta
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=tol)
 
 
 def test_sequence_kin_mode(scene, oracle_lib, hip_lib):
