@@ -35,7 +35,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import lk_pkg  # noqa: E402
 
 lk_pkg.load()
-from legkilo_amd import binding, config, synth  # noqa: E402
+from legkilo_amd import binding, config, replay, synth  # noqa: E402
 
 ALG_BYTES_RESIDUAL = 288   # scan pt 16 + hash slot 16 + plane record 240 + world pt 16
 ALG_BYTES_FULL = 1016      # + update pass 728 (re-projection write, map append, amortised refit)
@@ -137,25 +137,15 @@ def main():
     else:
         g.init_process_cov_q()
         t_after = t0 + 0.1 * args.map_warm
-    bcast_ms = None
+    map_bytes, bsecs = replay.broadcast_map(g, dist, rank, world_size, dev, src=0, algo="broadcast")
+    bcast_ms = bsecs * 1e3 if world_size > 1 else None
+    bcast2_ms = None
     if world_size > 1:
-        nbytes = torch.tensor([g.map_export_dev_size() if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(nbytes, 0)
-        blob = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            g.map_export_dev(blob.data_ptr(), blob.numel())
-        torch.cuda.synchronize()
-        dist.barrier()
-        tb0 = time.time()
-        dist.broadcast(blob, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - tb0) * 1e3
-        if rank != 0:
-            g.map_import_dev(blob.data_ptr(), blob.numel())
-        map_bytes = blob.numel()
-        del blob
-    else:
-        map_bytes = g.map_export_dev_size()
+        try:  # same payload again as scatter + all-gather (all xGMI links of the root busy); timing only
+            _, s2 = replay.broadcast_map(g, dist, rank, world_size, dev, src=0, algo="scatter_allgather")
+            bcast2_ms = s2 * 1e3
+        except Exception as e:  # noqa: BLE001
+            bcast2_ms = f"unavailable: {type(e).__name__}"
     n_roots, n_nodes, n_blocks = g.map_stats()
     map_build_s = time.time() - t_map0
 
@@ -175,9 +165,7 @@ def main():
         g.batch_set_priors(xs, Ps)
         poses = g.batch_replay_dev(d_batch.data_ptr(), S, N_PTS, 0.0, off, dt)
         if dist is not None:
-            res = torch.from_numpy(np.array([[p.pos[0], p.pos[1], p.pos[2], float(p.n_effect)] for p in poses])).to(dev)
-            out = [torch.empty_like(res) for _ in range(world_size)]
-            dist.all_gather(out, res)
+            replay.gather_results(dist, replay.pose_rows(poses), world_size, dev)
         return poses
 
     def sync_all():
@@ -231,7 +219,8 @@ def main():
 
     # ---- extra: config 3 as one sequential stream with map insert (rank 0 only, after the batch bench)
     extra = {"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
-             "mean_n_effect": n_eff, "rccl_map_broadcast_ms": bcast_ms}
+             "mean_n_effect": n_eff, "rccl_map_broadcast_ms": bcast_ms,
+             "rccl_map_scatter_allgather_ms": bcast2_ms}
     cpu_baseline = None
     if rank == 0:
         g.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30), slot=0)

@@ -1,0 +1,54 @@
+// Minimal use of the C++ mirror, written the way KILO.cc drives the reference classes: first-frame
+// BuildVoxelMap on a synthetic floor + wall, then one predictUpdatePoint bucket.  Needs a gfx950 device
+// to RUN (exit code 3 otherwise); tests/test_abi_and_host.py only checks that it compiles and links.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "legkilo_host.hpp"
+
+using namespace legkilo;
+
+int main() {
+    ESKF::Config ec{20, 500, 1000, 20, 0.001, 0.001, 0.001, 0.1, 1.0, 0.01, 0.1, 0.1, 0.001, 10};
+    VoxelMapConfig vc;
+    DeviceCaps caps;
+    caps.max_roots = 1u << 14, caps.max_nodes = 1u << 15, caps.max_point_blocks = 1u << 14, caps.max_scan_points = 1u << 15;
+    std::unique_ptr<KiloPath> kilo;
+    try {
+        kilo = std::make_unique<KiloPath>(ec, vc, Mat3D::Identity(), Vec3D{0, 0, 0.2}, 9.81, caps);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "no device: %s\n", e.what());
+        return 3;
+    }
+    State s;
+    s.pos_ = {0, 0, 0.5};
+    kilo->eskf().setState(s);
+    StateCov P;
+    for (int i = 0; i < DIM_STATE; ++i) P(i, i) = 1e-6;
+    kilo->eskf().setCov(P);
+    kilo->eskf().initProcessCovQ();
+    kilo->setTimes(0.0, 0.0);
+
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> u(-4.f, 4.f);
+    std::normal_distribution<float> nz(0.f, 0.01f);
+    auto body = std::make_shared<PointCloudType>(), world = std::make_shared<PointCloudType>();
+    for (int i = 0; i < 20000; ++i) {  // floor z=0 (world) seen from the sensor at z = 0.5 + 0.2
+        PointType w;
+        w.x = u(rng), w.y = u(rng), w.z = nz(rng);
+        PointType b = w;
+        b.z = w.z - 0.7f;
+        world->push_back(w), body->push_back(b);
+    }
+    kilo->map_manager().feats_down_body_ = body;
+    kilo->map_manager().feats_down_world_ = world;
+    kilo->map_manager().BuildVoxelMap(kilo->eskf().getRot(), kilo->eskf().getRotCov(), kilo->eskf().getPosCov());
+
+    PointCloudType bucket(body->begin(), body->begin() + 2000), bucket_world(2000);
+    size_t n_success = 0;
+    bool updated = kilo->predictUpdatePoint(0.01, 0, bucket.size(), bucket, bucket_world, n_success);
+    Vec3D p = kilo->eskf().getPos();
+    std::printf("updated=%d matched=%zu pos=(%.4f %.4f %.4f)\n", (int)updated, n_success, p[0], p[1], p[2]);
+    return (updated && n_success > 500 && std::fabs(p[2] - 0.5) < 0.05) ? 0 : 1;
+}

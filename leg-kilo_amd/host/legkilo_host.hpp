@@ -1,0 +1,324 @@
+// legkilo_host.hpp — C++ mirror of the reference class surface that KILO consumes, implemented purely on
+// the C-ABI of include/legkilo_hip.h (no HIP, no torch, no Eigen in this header).
+//
+//   legkilo::ESKF              <- legkilo/src/core/slam/eskf.h:46-109
+//   legkilo::VoxelMapManager   <- legkilo/src/core/slam/voxel_map.h:180-244 (live members)
+//   legkilo::KiloPath          <- KILO::predictUpdatePoint / predictUpdateImu / predictUpdateKinImu and the
+//                                 bucket loop of KILO::process (KILO.cc:108-399)
+//
+// Same method names, argument meaning and (void / bool) error behaviour as the reference.  Differences forced
+// by the state living in HBM: state()/cov()/Q() return COPIES (use setState/setCov/setQ to write back), and
+// build_single_residual is not a per-point host call — BuildResidualList() runs the whole bucket on the GPU.
+// Configuration errors throw std::runtime_error like YamlHelper does (yaml_helper.hpp:42,50).
+#pragma once
+#include <array>
+#include <cstddef>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "legkilo_hip.h"
+
+namespace legkilo {
+
+constexpr int DIM_STATE = LK_DIM_STATE;
+using Vec3D = std::array<double, 3>;
+struct Mat3D {
+    double m[9];  // row-major
+    double& operator()(int i, int j) { return m[3 * i + j]; }
+    double operator()(int i, int j) const { return m[3 * i + j]; }
+    static Mat3D Identity() { return Mat3D{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+};
+using StateVec = std::array<double, DIM_STATE>;
+struct StateCov {
+    std::vector<double> d = std::vector<double>(DIM_STATE * DIM_STATE, 0.0);  // row-major
+    double& operator()(int i, int j) { return d[i * DIM_STATE + j]; }
+    double operator()(int i, int j) const { return d[i * DIM_STATE + j]; }
+    Mat3D block3(int o) const {
+        Mat3D b;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) b(i, j) = (*this)(o + i, o + j);
+        return b;
+    }
+};
+using StateF = StateCov;
+using StateQ = StateCov;
+
+// eskf.h:15-32
+struct State {
+    Mat3D rot_ = Mat3D::Identity();
+    Vec3D pos_{}, vel_{}, ba_{}, bw_{}, grav_{{0.0, 0.0, -9.81}}, imu_a_{}, imu_w_{}, bv_{}, contact_{};
+    void to_x36(double* x) const {
+        std::memcpy(x, rot_.m, sizeof(rot_.m));
+        const Vec3D* v[9] = {&pos_, &vel_, &ba_, &bw_, &grav_, &imu_a_, &imu_w_, &bv_, &contact_};
+        for (int k = 0; k < 9; ++k)
+            for (int c = 0; c < 3; ++c) x[9 + 3 * k + c] = (*v[k])[c];
+    }
+    void from_x36(const double* x) {
+        std::memcpy(rot_.m, x, sizeof(rot_.m));
+        Vec3D* v[9] = {&pos_, &vel_, &ba_, &bw_, &grav_, &imu_a_, &imu_w_, &bv_, &contact_};
+        for (int k = 0; k < 9; ++k)
+            for (int c = 0; c < 3; ++c) (*v[k])[c] = x[9 + 3 * k + c];
+    }
+};
+
+// eskf.h:34-44; pt_h is N x 6 and ki_h is M x 30, both row-major
+struct ObsShared {
+    std::vector<double> pt_z, pt_h, pt_R, ki_z, ki_h, ki_R;
+};
+
+// voxel_map.h:41-57
+struct VoxelMapConfig {
+    double max_voxel_size_ = 0.5;
+    int max_layer_ = 2;
+    int max_iterations_ = 0;
+    std::vector<int> layer_init_num_{5, 5, 5, 5, 5};
+    int max_points_num_ = 50;
+    double planner_threshold_ = 0.01, beam_err_ = 0.2, dept_err_ = 0.04, sigma_num_ = 3;
+    bool is_pub_plane_map_ = false;
+    double sliding_thresh = 8;      // loaded, never consulted by the reference (KILO.cc:68-70)
+    bool map_sliding_en = false;
+    int half_map_size = 100;
+};
+
+// voxel_map.h:59-78: the two fields UpdateVoxelMap reads
+struct pointWithVar {
+    Vec3D point_w{};
+    Mat3D var{};
+};
+
+// PointType (pcl_types.h:11) fields the path touches
+struct PointType {
+    float x = 0, y = 0, z = 0, intensity = 0, curvature = 0;
+};
+using PointCloudType = std::vector<PointType>;
+
+struct DeviceCaps {
+    int device_id = 0;
+    uint32_t n_slots = 1, max_roots = 1u << 18, max_nodes = 1u << 19, max_point_blocks = 1u << 18, max_scan_points = 1u << 17;
+};
+
+// One lk_handle shared by the ESKF and VoxelMapManager mirrors (they are two views of the same device state).
+class Device {
+   public:
+    Device(const lk_config& cfg) {
+        if (lk_create(&cfg, &h_) != LK_OK) throw std::runtime_error(std::string("lk_create: ") + lk_last_error(nullptr));
+        cfg_ = cfg;
+    }
+    ~Device() { lk_destroy(h_); }
+    Device(const Device&) = delete;
+    Device& operator=(const Device&) = delete;
+    lk_handle* h() const { return h_; }
+    const lk_config& cfg() const { return cfg_; }
+    void check(int rc) const {
+        if (rc != LK_OK) throw std::runtime_error(std::string("liblegkilo_hip: ") + lk_last_error(h_));
+    }
+
+   private:
+    lk_handle* h_ = nullptr;
+    lk_config cfg_;
+};
+
+class ESKF {
+   public:
+    // eskf.h:49-65
+    struct Config {
+        double vel_process_cov, imu_acc_process_cov, imu_gyr_process_cov, contact_process_cov, acc_bias_process_cov,
+            gyr_bias_process_cov, kin_bias_process_cov;
+        double imu_acc_meas_noise, imu_acc_z_meas_noise, imu_gyr_meas_noise, kin_meas_noise, chd_meas_noise,
+            contact_meas_noise, lidar_point_meas_ratio;
+    };
+    ESKF(const Config& config, std::shared_ptr<Device> dev) : config_(config), dev_(std::move(dev)) {}
+
+    State state() const {
+        double x[LK_STATE_DOUBLES];
+        dev_->check(lk_get_state(dev_->h(), 0, x, nullptr));
+        State s;
+        s.from_x36(x);
+        return s;
+    }
+    void setState(const State& s) {
+        double x[LK_STATE_DOUBLES];
+        s.to_x36(x);
+        dev_->check(lk_set_state(dev_->h(), 0, x, nullptr));
+    }
+    Mat3D getRot() const { return state().rot_; }
+    Vec3D getPos() const { return state().pos_; }
+    Vec3D getVel() const { return state().vel_; }
+    Mat3D getRotCov() const { return cov().block3(0); }
+    Mat3D getPosCov() const { return cov().block3(3); }
+    Mat3D getVelCov() const { return cov().block3(6); }
+    StateQ Q() const {
+        StateQ q;
+        dev_->check(lk_get_Q(dev_->h(), q.d.data()));
+        return q;
+    }
+    void setQ(const StateQ& q) { dev_->check(lk_set_Q(dev_->h(), q.d.data())); }
+    StateCov cov() const {
+        StateCov c;
+        dev_->check(lk_get_state(dev_->h(), 0, nullptr, c.d.data()));
+        return c;
+    }
+    void setCov(const StateCov& c) { dev_->check(lk_set_state(dev_->h(), 0, nullptr, c.d.data())); }
+    const Config& config() const { return config_; }
+
+    void initProcessCovQ() { dev_->check(lk_init_process_cov_q(dev_->h())); }
+    StateVec getFunctionf(double dt) {
+        StateVec f;
+        dev_->check(lk_get_function_f(dev_->h(), 0, dt, f.data()));
+        return f;
+    }
+    StateF getFx(double dt) {
+        StateF F;
+        dev_->check(lk_get_fx(dev_->h(), 0, dt, F.d.data()));
+        return F;
+    }
+    void predict(double dt, bool prop_state, bool prop_cov) { dev_->check(lk_predict(dev_->h(), 0, dt, prop_state, prop_cov)); }
+    void updateByPoints(ObsShared& o) {
+        dev_->check(lk_update_by_points(dev_->h(), 0, o.pt_h.data(), o.pt_z.data(), o.pt_R.data(), o.pt_z.size()));
+    }
+    void updateByImu(ObsShared& o) { dev_->check(lk_update_by_imu(dev_->h(), 0, o.ki_z.data(), o.ki_R.data())); }
+    void updateByKinImu(ObsShared& o) {
+        dev_->check(lk_update_by_kin_imu(dev_->h(), 0, o.ki_h.data(), o.ki_z.data(), o.ki_R.data(), o.ki_z.size()));
+    }
+
+   private:
+    Config config_;
+    std::shared_ptr<Device> dev_;
+};
+
+class VoxelMapManager {
+   public:
+    VoxelMapManager(VoxelMapConfig& config_setting, std::shared_ptr<Device> dev) : config_setting_(config_setting), dev_(std::move(dev)) {}
+    VoxelMapConfig config_setting_;
+    Mat3D extR_ = Mat3D::Identity();
+    Vec3D extT_{};
+    std::shared_ptr<PointCloudType> feats_down_body_, feats_down_world_;
+
+    // voxel_map.cc:287-334.  rot / rot_cov / pos_cov are those of the filter (KILO.cc:339) and already live on
+    // the device; the arguments are kept for source compatibility.
+    void BuildVoxelMap(const Mat3D&, const Mat3D&, const Mat3D&) {
+        if (!feats_down_body_ || !feats_down_world_ || feats_down_body_->size() != feats_down_world_->size())
+            throw std::runtime_error("BuildVoxelMap: feats_down_body_/feats_down_world_ not set");
+        std::vector<float> w, b;
+        for (size_t i = 0; i < feats_down_world_->size(); ++i) {
+            const PointType &pw = (*feats_down_world_)[i], &pb = (*feats_down_body_)[i];
+            w.insert(w.end(), {pw.x, pw.y, pw.z});
+            b.insert(b.end(), {pb.x, pb.y, pb.z});
+        }
+        dev_->check(lk_map_build(dev_->h(), w.data(), b.data(), feats_down_world_->size()));
+    }
+    // voxel_map.cc:336-361
+    void UpdateVoxelMap(const std::vector<pointWithVar>& input_points) {
+        std::vector<double> pw, var;
+        for (const auto& p : input_points) {
+            pw.insert(pw.end(), p.point_w.begin(), p.point_w.end());
+            var.insert(var.end(), p.var.m, p.var.m + 9);
+        }
+        dev_->check(lk_map_update(dev_->h(), pw.data(), var.data(), input_points.size()));
+    }
+    // Residual build of KILO.cc:122-210 for a whole bucket (replaces the per-point build_single_residual calls).
+    void BuildResidualList(const PointCloudType& body, size_t i0, size_t i1, ObsShared& obs, std::vector<uint8_t>& valid) {
+        size_t n = i1 - i0;
+        std::vector<float> b;
+        for (size_t i = i0; i < i1; ++i) b.insert(b.end(), {body[i].x, body[i].y, body[i].z});
+        std::vector<double> h(6 * n), z(n), R(n);
+        valid.assign(n, 0);
+        dev_->check(lk_residuals(dev_->h(), b.data(), n, h.data(), z.data(), R.data(), valid.data()));
+        obs.pt_h.clear(), obs.pt_z.clear(), obs.pt_R.clear();
+        for (size_t k = 0; k < n; ++k)
+            if (valid[k]) {
+                obs.pt_h.insert(obs.pt_h.end(), h.begin() + 6 * k, h.begin() + 6 * k + 6);
+                obs.pt_z.push_back(z[k]);
+                obs.pt_R.push_back(R[k]);
+            }
+    }
+
+   private:
+    std::shared_ptr<Device> dev_;
+};
+
+// The path of KILO (KILO.cc:108-399) with the reference's private method names.
+class KiloPath {
+   public:
+    KiloPath(const ESKF::Config& ec, VoxelMapConfig& vc, const Mat3D& ext_rot, const Vec3D& ext_t, double gravity,
+             const DeviceCaps& caps = DeviceCaps()) {
+        lk_config c;
+        std::memset(&c, 0, sizeof(c));
+        std::memcpy(&c.vel_process_cov, &ec, sizeof(ec));  // same 14 doubles, same order (eskf.h:49-65)
+        c.max_voxel_size = vc.max_voxel_size_;
+        c.planner_threshold = vc.planner_threshold_;
+        c.beam_err = vc.beam_err_;
+        c.dept_err = vc.dept_err_;
+        c.sigma_num = vc.sigma_num_;
+        c.max_layer = vc.max_layer_;
+        c.max_iterations = vc.max_iterations_;
+        if (vc.layer_init_num_.size() < 5) throw std::runtime_error("layer_init_num needs 5 entries");
+        for (int i = 0; i < 5; ++i) c.layer_init_num[i] = vc.layer_init_num_[i];
+        c.max_points_num = vc.max_points_num_;
+        std::memcpy(c.ext_R, ext_rot.m, sizeof(c.ext_R));
+        for (int i = 0; i < 3; ++i) c.ext_T[i] = ext_t[i];
+        c.gravity = gravity;
+        c.device_id = caps.device_id;
+        c.n_slots = caps.n_slots;
+        c.max_roots = caps.max_roots;
+        c.max_nodes = caps.max_nodes;
+        c.max_point_blocks = caps.max_point_blocks;
+        c.max_scan_points = caps.max_scan_points;
+        dev_ = std::make_shared<Device>(c);
+        eskf_ = std::make_unique<ESKF>(ec, dev_);
+        map_manager_ = std::make_unique<VoxelMapManager>(vc, dev_);
+        map_manager_->extR_ = ext_rot;
+        map_manager_->extT_ = ext_t;
+    }
+    ESKF& eskf() { return *eskf_; }
+    VoxelMapManager& map_manager() { return *map_manager_; }
+    void setTimes(double last_predict, double last_update) { dev_->check(lk_set_times(dev_->h(), 0, last_predict, last_update)); }
+    void setAccNorm(double a) { dev_->check(lk_set_acc_norm(dev_->h(), a)); }
+
+    // KILO.cc:108-233
+    bool predictUpdatePoint(double current_time, size_t idx_i, size_t idx_j, const PointCloudType& cloud_down_body,
+                            PointCloudType& cloud_down_world, size_t& success_pts_size_out) {
+        size_t n = idx_j - idx_i;
+        std::vector<float> b, w(3 * n), inten(n);
+        for (size_t i = idx_i; i < idx_j; ++i) b.insert(b.end(), {cloud_down_body[i].x, cloud_down_body[i].y, cloud_down_body[i].z});
+        size_t before = success_pts_size_out;
+        dev_->check(lk_update_points(dev_->h(), current_time, b.data(), n, w.data(), inten.data(), &success_pts_size_out));
+        for (size_t i = 0; i < n; ++i) {
+            PointType& p = cloud_down_world[idx_i + i];
+            p.x = w[3 * i], p.y = w[3 * i + 1], p.z = w[3 * i + 2], p.intensity = inten[i];
+        }
+        return success_pts_size_out > before;
+    }
+    bool predictUpdateImu(const lk_imu& imu) {  // KILO.cc:235-258
+        dev_->check(lk_update_imu(dev_->h(), &imu));
+        return true;
+    }
+    bool predictUpdateKinImu(const lk_kin_imu& kin) {  // KILO.cc:260-314
+        dev_->check(lk_update_kin_imu(dev_->h(), &kin));
+        return true;
+    }
+    // bucket loop of KILO::process (KILO.cc:367-396), fused on the device stream: one call per scan
+    bool processSorted(const PointCloudType& sorted_body, double begin_time, const std::vector<lk_imu>& imus,
+                       const std::vector<lk_kin_imu>& kins, PointCloudType* world_out, lk_pose* pose) {
+        std::vector<lk_point> pts(sorted_body.size());
+        for (size_t i = 0; i < pts.size(); ++i) pts[i] = lk_point{sorted_body[i].x, sorted_body[i].y, sorted_body[i].z, sorted_body[i].curvature};
+        std::vector<float> w(world_out ? 3 * pts.size() : 0);
+        dev_->check(lk_process_scan(dev_->h(), pts.data(), pts.size(), begin_time, imus.data(), imus.size(), kins.data(), kins.size(),
+                                    world_out ? w.data() : nullptr, pose));
+        if (world_out) {
+            world_out->resize(pts.size());
+            for (size_t i = 0; i < pts.size(); ++i) (*world_out)[i].x = w[3 * i], (*world_out)[i].y = w[3 * i + 1], (*world_out)[i].z = w[3 * i + 2];
+        }
+        return true;
+    }
+
+   private:
+    std::shared_ptr<Device> dev_;
+    std::unique_ptr<ESKF> eskf_;
+    std::unique_ptr<VoxelMapManager> map_manager_;
+};
+
+}  // namespace legkilo

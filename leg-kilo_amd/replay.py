@@ -1,0 +1,107 @@
+"""Many-scan batch replay across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The path has no exchange step inside it: scans are independent replay units against one
+shared, frozen voxel map.  Communication is therefore exactly
+  (1) once per map snapshot: the map blob from the rank that built it to every other rank;
+  (2) once per batch: an all-gather of the per-scan results (a few hundred bytes per scan).
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring broadcast is bound by ONE link, so for a
+large blob `scatter_allgather` sends a distinct 1/W slice to every peer (all links of the root carry
+different data) and then all-gathers the slices.
+
+`engine` is anything with the LegKiloHip map methods (map_export / map_import for host blobs,
+map_export_dev_size / map_export_dev / map_import_dev for HBM-resident blobs).
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block partition of n_total replay units: rank r owns [start, stop)."""
+    base, rem = divmod(n_total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _bcast_tensor(dist, t, src, algo, rank, world):
+    import torch
+
+    if algo == "broadcast" or world == 1:
+        dist.broadcast(t, src)
+        return t
+    # scatter + all-gather: pad to a multiple of world, root sends slice i to rank i, then all-gather
+    n = t.numel()
+    per = (n + world - 1) // world
+    padded = t if n == per * world else torch.cat([t, t.new_zeros(per * world - n)])
+    mine = torch.empty(per, dtype=t.dtype, device=t.device)
+    chunks = list(padded.split(per)) if rank == src else None
+    dist.scatter(mine, chunks, src=src)
+    out = torch.empty(per * world, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, mine)
+    t.copy_(out[:n])
+    return t
+
+
+def broadcast_map(engine, dist, rank, world, device, src=0, algo="broadcast"):
+    """Ship the voxel map of rank `src` to every rank.  Returns (bytes, seconds spent in the collective)."""
+    import time
+
+    import torch
+
+    on_gpu = device.type == "cuda"
+    if on_gpu:
+        size = engine.map_export_dev_size() if rank == src else 0
+    else:
+        host_blob = engine.map_export() if rank == src else None
+        size = int(host_blob.size) if rank == src else 0
+    nbytes = torch.tensor([size], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.broadcast(nbytes, src)
+    n = int(nbytes.item())
+    blob = torch.empty(n, dtype=torch.uint8, device=device)
+    if rank == src:
+        if on_gpu:
+            engine.map_export_dev(blob.data_ptr(), n)
+        else:
+            blob.copy_(torch.from_numpy(np.asarray(host_blob)))
+    if on_gpu:
+        torch.cuda.synchronize()
+    secs = 0.0
+    if world > 1:
+        dist.barrier()
+        t0 = time.perf_counter()
+        _bcast_tensor(dist, blob, src, algo, rank, world)
+        if on_gpu:
+            torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        if rank != src:
+            if on_gpu:
+                engine.map_import_dev(blob.data_ptr(), n)
+            else:
+                engine.map_import(blob.numpy())
+    return n, secs
+
+
+def gather_results(dist, local, world, device):
+    """All-gather per-scan result rows (float64 [n_local, k]); every rank gets [n_total, k] in rank order.
+    Shards may differ in length by one (shard_range), so rows are padded to the longest shard."""
+    import torch
+
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if world == 1:
+        return local
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    pad = np.zeros((m, local.shape[1]))
+    pad[: local.shape[0]] = local
+    t = torch.from_numpy(pad).to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)
+
+
+def pose_rows(poses):
+    """lk_pose array -> float64 rows [pos(3), vel(3), rot(9), n_effect, n_buckets, n_updates]."""
+    return np.array([[*p.pos, *p.vel, *p.rot, float(p.n_effect), float(p.n_buckets), float(p.n_updates)] for p in poses])

@@ -1,0 +1,83 @@
+"""Golden fixture tests/golden/path_small.npz (made by tests/golden/make_golden.py with the oracle).
+
+CPU : the oracle must keep reproducing it (guards the restatement against accidental edits).
+GPU : the HIP path, through the C-ABI, must reproduce it from the stored inputs alone."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from legkilo_amd import abi
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "path_small.npz")
+CAPS = dict(max_roots=1 << 14, max_nodes=1 << 15, max_point_blocks=1 << 14, max_scan_points=1 << 15)
+
+
+def replay(obj, g, P0=1e-6):
+    """The stored call sequence, identical for the oracle and the HIP library."""
+    obj.set_state(g["x0"], P0 * np.eye(30))
+    obj.init_process_cov_q()
+    obj.set_acc_norm(9.81)
+    t0 = float(g["t0"])
+    obj.set_times(t0, t0)
+    obj.map_build(g["build_world"], g["build_body"])
+    po = np.r_[0, np.cumsum(g["seq_len"])]
+    io = np.r_[0, np.cumsum(g["seq_imu_len"])]
+    out = []
+    for k in range(len(g["seq_len"])):
+        pose, _ = obj.process_scan(g["seq_pts"][po[k]:po[k + 1]], float(g["seq_tb"][k]), imus=g["seq_imus"][io[k]:io[k + 1]])
+        x, _ = obj.get_state()
+        out.append((pose, x))
+    return out
+
+
+def check(obj, g, tol_state, tol_rows):
+    out = replay(obj, g)
+    for k, (pose, x) in enumerate(out):
+        assert [pose.n_buckets, pose.n_updates, pose.n_effect] == list(g["seq_counts"][k]), k
+        assert np.allclose(x, g["seq_x"][k], rtol=0, atol=tol_state), (k, np.abs(x - g["seq_x"][k]).max())
+    scenes.compare_maps(g["map_blob"], obj.map_export(), rtol=1e-5, ptol=max(tol_state, 1e-9))
+    h6, z, R, valid = obj.residuals(g["q_body"])
+    assert np.array_equal(valid, g["q_valid"]), int((valid != g["q_valid"]).sum())
+    scenes.rows_close(h6, z, R, g["q_h6"], g["q_z"], g["q_R"], valid, rtol=tol_rows)
+    w, inten, ne = obj.update_points(float(g["bk_t"]), g["bk_body"])
+    assert ne == int(g["bk_n_effect"]) and np.array_equal(inten, g["bk_intensity"])
+    assert np.abs(w - g["bk_world"]).max() < 1e-5
+    x1, P1 = obj.get_state()
+    assert np.allclose(x1, g["x1"], rtol=0, atol=tol_state)
+    assert np.abs(P1 - g["P1"]).max() <= 1e-6 * np.abs(g["P1"]).max()
+
+
+def test_oracle_reproduces_golden(oracle_lib):
+    g = np.load(G)
+    sc = scenes.Scene(**CAPS)
+    o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=True)
+    check(o, g, tol_state=1e-11, tol_rows=1e-11)
+    assert o.map_stats() == int(g["n_roots_after"])
+    o.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(hip_lib):
+    g = np.load(G)
+    sc = scenes.Scene(**CAPS)
+    h = hip_lib.LegKiloHip(sc.cfg())
+    check(h, g, tol_state=1e-7, tol_rows=1e-8)
+    assert h.map_stats()[0] == int(g["n_roots_after"])
+    h.close()
+
+
+@pytest.mark.gpu
+def test_host_mirror_example_runs(hip_lib):
+    """The C++ mirror of the reference classes (leg-kilo_amd/host) drives the same library end to end."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = "/tmp/lk_host_example_gpu"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "leg-kilo_amd", "host"),
+                        os.path.join(root, "leg-kilo_amd", "host", "example_kilo_path.cc"), "-o", exe, "-L", os.path.join(root, "leg-kilo_amd"),
+                        "-llegkilo_hip", "-Wl,-rpath," + os.path.join(root, "leg-kilo_amd")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1500:])
