@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblegkilo_hip.so")
+LIB_PATH = os.environ.get("LEGKILO_HIP_LIB", os.path.join(_HERE, "liblegkilo_hip.so"))  # override: A/B builds
 
 EXPORTS = [
     "lk_abi_version", "lk_create", "lk_destroy", "lk_last_error", "lk_set_state", "lk_get_state", "lk_set_Q", "lk_get_Q",

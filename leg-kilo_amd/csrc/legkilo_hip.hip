@@ -156,6 +156,12 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
         pr.dir_var = sd * sd;
         pr.range_var = range_inc * range_inc;
     }
+    {
+        double inv = 1.0 / cfg->max_voxel_size;
+        int e = 0;
+        bool pow2 = std::frexp(cfg->max_voxel_size, &e) == 0.5;  // mantissa exactly 0.5 <=> power of two
+        pr.inv_vs_exact = pow2 ? inv : 0.0;
+    }
     pr.planer_threshold = (float)cfg->planner_threshold;
     pr.max_layer = cfg->max_layer;
     pr.max_points_num = cfg->max_points_num;
@@ -170,6 +176,7 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     m.max_scan = cfg->max_scan_points;
     HIPCHK(h, hipMalloc(&m.hash, sizeof(int4) * (size_t)h->hash_cap));
     HIPCHK(h, hipMalloc(&m.planes, sizeof(lk_plane_rec) * (size_t)m.max_nodes));
+    HIPCHK(h, hipMalloc(&m.match, sizeof(lk_match_rec) * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.nodes, sizeof(lk_node_rec) * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.blocks, sizeof(lk_block_rec) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&m.counters, sizeof(unsigned int) * LK_CTR_COUNT));
@@ -181,7 +188,7 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * 900));
     HIPCHK(h, hipMemsetAsync(h->d_Q, 0, sizeof(double) * 900, h->stream));
     size_t nblk_max = ((size_t)m.max_scan + LK_PB - 1) / LK_PB;
-    h->part_stride = nblk_max * LK_NPART;
+    h->part_stride = nblk_max * (LK_PB / LK_WAVE) * LK_NPART;  // one partial record per wave
     HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->part_stride * cfg->n_slots));
     HIPCHK(h, hipMalloc(&h->d_scan, sizeof(lk_point) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&h->d_world, sizeof(float) * 4 * (size_t)m.max_scan));
@@ -201,7 +208,7 @@ void lk_destroy(lk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->map.hash, h->map.planes, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched,
+    void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched,
                     h->map.next, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
@@ -369,7 +376,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
            hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, m, h->pr, h->d_filters,
                               d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
     LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                           h->d_partials, nblk, h->part_stride, t));
+                                           h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t));
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
@@ -601,6 +608,8 @@ int lk_map_import(lk_handle* h, const void* blob, size_t bytes) {
     if (hd.n_roots)
         hipLaunchKernelGGL(lk_hash_insert_kernel, dim3((hd.n_roots + 255) / 256), dim3(256), 0, h->stream, h->map, h->pr,
                            d_roots, (int)hd.n_roots);
+    if (hd.n_nodes)
+        hipLaunchKernelGGL(lk_derive_match_kernel, dim3((hd.n_nodes + 255) / 256), dim3(256), 0, h->stream, h->map, (int)hd.n_nodes);
     unsigned int ctr[LK_CTR_COUNT] = {0};
     ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
     // only the first three counters: the hash-insert kernel may raise the error word concurrently
@@ -667,6 +676,8 @@ int lk_map_import_dev(lk_handle* h, const void* d_blob, size_t bytes) {
     HIPCHK(h, hipMemcpyAsync(h->map.planes, p, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToDevice, h->stream));
     p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
     HIPCHK(h, hipMemcpyAsync(h->map.blocks, p, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToDevice, h->stream));
+    if (hd.n_nodes)
+        hipLaunchKernelGGL(lk_derive_match_kernel, dim3((hd.n_nodes + 255) / 256), dim3(256), 0, h->stream, h->map, (int)hd.n_nodes);
     unsigned int ctr[LK_CTR_COUNT] = {0};
     ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
     HIPCHK(h, hipMemcpyAsync(h->map.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, h->stream));
@@ -833,6 +844,12 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     HIPCHK(h, hipGetLastError());
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
+#ifdef LK_TIMING
+    static unsigned long long* d_ts = nullptr;
+    const size_t ts_waves = (size_t)S * ((h->map.max_scan + LK_PB - 1) / LK_PB) * (LK_PB / LK_WAVE);
+    if (!d_ts) hipMalloc(&d_ts, ts_waves * 10 * sizeof(unsigned long long));
+    ro.z = reinterpret_cast<double*>(d_ts);
+#endif
     for (size_t b = 0; b < n_buckets; ++b) {
         int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
         if (nb <= 0) continue;
@@ -844,8 +861,32 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_PB), 0, h->stream, h->map, h->pr,
                                   h->d_filters, d_pts + bucket_off[b], n_pts, nb, h->d_partials, h->part_stride, ro, (size_t)0));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                               h->d_partials, nblk, h->part_stride, t));
+                                               h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t));
     }
+#ifdef LK_TIMING
+    {
+        hipStreamSynchronize(h->stream);
+        int nb = (int)(bucket_off[n_buckets] - bucket_off[n_buckets - 1]);
+        size_t nw = (size_t)S * ((nb + LK_PB - 1) / LK_PB) * (LK_PB / LK_WAVE);
+        std::vector<unsigned long long> ts(nw * 10);
+        hipMemcpy(ts.data(), d_ts, ts.size() * 8, hipMemcpyDeviceToHost);
+        double acc[9] = {0};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            for (int k = 1; k <= 8; ++k) acc[k] += (double)(ts[w * 10 + k] - ts[w * 10 + k - 1]);
+            tmin = std::min(tmin, ts[w * 10]);
+            tmax = std::max(tmax, ts[w * 10 + 8]);
+        }
+        const char* nm[9] = {"", "load+geom", "key+hash", "stamp2", "root eval", "retry", "obs_row", "rows+ballot", "barrier..end"};
+        fprintf(stderr, "[LK_TIMING] waves %zu, kernel span %llu ticks; mean ticks per wave:", nw, tmax - tmin);
+        double tot = 0;
+        for (int k = 1; k <= 8; ++k) {
+            fprintf(stderr, " %s=%.0f", nm[k], acc[k] / nw);
+            tot += acc[k] / nw;
+        }
+        fprintf(stderr, " total=%.0f\n", tot);
+    }
+#endif
     if (out) {
         std::vector<lk_pose> tmp(n_scans);
         rc = fetch_poses(h, tmp.data(), S);

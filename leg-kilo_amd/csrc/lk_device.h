@@ -18,6 +18,15 @@
 
 #include "../../include/legkilo_hip.h"
 
+#ifndef LK_OPT_RECIP
+#define LK_OPT_RECIP 0
+#endif
+#ifndef LK_OPT_SLIM
+#define LK_OPT_SLIM 0
+#endif
+#ifndef LK_OPT_WAVES
+#define LK_OPT_WAVES 0
+#endif
 #define LK_WAVE 64
 #define LK_EMPTY (-1)
 #define LK_LOCKED (-2)
@@ -50,6 +59,7 @@ struct LkParams {                // immutable per handle, passed by value
     double sigma_num;
     double lidar_ratio;
     double dir_var;              // pow(sin(DEG2RAD(beam_err)),2), voxel_map.cc:27
+    double inv_vs_exact;         // 1/voxel_size when that is exact in fp64 (power of two), else 0
     float voxel_size_f;          // float use at voxel_map.cc:289,337
     float range_var;             // dept_err^2 in float, voxel_map.cc:25
     float planer_threshold;      // voxel_map.h:140
@@ -57,9 +67,44 @@ struct LkParams {                // immutable per handle, passed by value
     int layer_init_num[5];
 };
 
+// Compact, derived copy of a plane for the residual kernel (device-only, never exported): 144 B = 9 x 16-B
+// loads instead of the 15 of lk_plane_rec.  With J = [q, -n], q = p - center, and plane_var = [[S11 S12],[S21 S22]]
+//   J plane_var J^T = q^T S11 q - 2 q^T (S12 n) + n^T S22 n
+// so only S11 (6 unique), w = S12 n and s22 = n^T S22 n are needed per plane; they are written whenever the
+// plane is (re)fitted or imported.  Same value as the reference's (J PV) J^T up to fp64 rounding.
+struct lk_match_rec {
+    double center[3];
+    double normal[3];
+    float d, radius;
+    unsigned int flags, pad_;
+    double s11[6];               // xx xy xz yy yz zz
+    double w[3];
+    double s22;
+};
+static_assert(sizeof(lk_match_rec) == 144, "match record must be 144 B");
+
+__host__ __device__ inline void lk_derive_match(const lk_plane_rec* pl, lk_match_rec* mr) {
+    for (int k = 0; k < 3; ++k) mr->center[k] = pl->center[k], mr->normal[k] = pl->normal[k];
+    mr->d = pl->d, mr->radius = pl->radius, mr->flags = pl->flags, mr->pad_ = 0;
+    const double* v = pl->plane_var;  // upper triangle row-major of the 6x6: row r starts at r*6 - r*(r-1)/2
+    // S11 = rows/cols 0..2
+    mr->s11[0] = v[0], mr->s11[1] = v[1], mr->s11[2] = v[2], mr->s11[3] = v[6], mr->s11[4] = v[7], mr->s11[5] = v[11];
+    // S12 (3x3, rows 0..2, cols 3..5): row0 = v[3..5], row1 = v[8..10], row2 = v[12..14]
+    const double* n = pl->normal;
+    mr->w[0] = v[3] * n[0] + v[4] * n[1] + v[5] * n[2];
+    mr->w[1] = v[8] * n[0] + v[9] * n[1] + v[10] * n[2];
+    mr->w[2] = v[12] * n[0] + v[13] * n[1] + v[14] * n[2];
+    // S22 = rows/cols 3..5: (3,3)=v[15] (3,4)=v[16] (3,5)=v[17] (4,4)=v[18] (4,5)=v[19] (5,5)=v[20]
+    const double t0 = v[15] * n[0] + v[16] * n[1] + v[17] * n[2];
+    const double t1 = v[16] * n[0] + v[18] * n[1] + v[19] * n[2];
+    const double t2 = v[17] * n[0] + v[19] * n[1] + v[20] * n[2];
+    mr->s22 = t0 * n[0] + t1 * n[1] + t2 * n[2];
+}
+
 struct LkMap {                   // device pointers of one voxel map, passed by value
     int4* hash;
     lk_plane_rec* planes;
+    lk_match_rec* match;         // derived, same index as planes[]
     lk_node_rec* nodes;
     lk_block_rec* blocks;
     unsigned int* counters;      // LK_CTR_*
@@ -77,19 +122,25 @@ struct S3 {  // symmetric 3x3: xx xy xz yy yz zz
     double xx, xy, xz, yy, yz, zz;
 };
 
+// a*b + c*d + e*f with explicit FMAs.  The translation unit is built with -ffp-contract=off so that the
+// compiler never decides contraction per call site; where fusing pays it is spelled out here, and every kernel
+// that shares these helpers therefore computes identical bits (see the note at the top of this file).
+__device__ __forceinline__ double dot3(double a, double b, double c, double d, double e, double f) {
+    return __builtin_fma(e, f, __builtin_fma(c, d, a * b));
+}
 __device__ __forceinline__ V3 mat3_mul_v(const double* M, V3 v) {  // row-major 3x3
-    return V3{M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z,
-              M[6] * v.x + M[7] * v.y + M[8] * v.z};
+    return V3{dot3(M[0], v.x, M[1], v.y, M[2], v.z), dot3(M[3], v.x, M[4], v.y, M[5], v.z),
+              dot3(M[6], v.x, M[7], v.y, M[8], v.z)};
 }
 __device__ __forceinline__ V3 mat3T_mul_v(const double* M, V3 v) {
-    return V3{M[0] * v.x + M[3] * v.y + M[6] * v.z, M[1] * v.x + M[4] * v.y + M[7] * v.z,
-              M[2] * v.x + M[5] * v.y + M[8] * v.z};
+    return V3{dot3(M[0], v.x, M[3], v.y, M[6], v.z), dot3(M[1], v.x, M[4], v.y, M[7], v.z),
+              dot3(M[2], v.x, M[5], v.y, M[8], v.z)};
 }
 __device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = dot3(A[3 * i], B[j], A[3 * i + 1], B[3 + j], A[3 * i + 2], B[6 + j]);
 }
 // C = A * S * A^T for symmetric S, result symmetric (upper triangle evaluated once)
 __device__ __forceinline__ S3 congruence(const double* A, S3 s) {
@@ -97,24 +148,24 @@ __device__ __forceinline__ S3 congruence(const double* A, S3 s) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
-        T[3 * i + 0] = a0 * s.xx + a1 * s.xy + a2 * s.xz;
-        T[3 * i + 1] = a0 * s.xy + a1 * s.yy + a2 * s.yz;
-        T[3 * i + 2] = a0 * s.xz + a1 * s.yz + a2 * s.zz;
+        T[3 * i + 0] = dot3(a0, s.xx, a1, s.xy, a2, s.xz);
+        T[3 * i + 1] = dot3(a0, s.xy, a1, s.yy, a2, s.yz);
+        T[3 * i + 2] = dot3(a0, s.xz, a1, s.yz, a2, s.zz);
     }
     S3 r;
-    r.xx = T[0] * A[0] + T[1] * A[1] + T[2] * A[2];
-    r.xy = T[0] * A[3] + T[1] * A[4] + T[2] * A[5];
-    r.xz = T[0] * A[6] + T[1] * A[7] + T[2] * A[8];
-    r.yy = T[3] * A[3] + T[4] * A[4] + T[5] * A[5];
-    r.yz = T[3] * A[6] + T[4] * A[7] + T[5] * A[8];
-    r.zz = T[6] * A[6] + T[7] * A[7] + T[8] * A[8];
+    r.xx = dot3(T[0], A[0], T[1], A[1], T[2], A[2]);
+    r.xy = dot3(T[0], A[3], T[1], A[4], T[2], A[5]);
+    r.xz = dot3(T[0], A[6], T[1], A[7], T[2], A[8]);
+    r.yy = dot3(T[3], A[3], T[4], A[4], T[5], A[5]);
+    r.yz = dot3(T[3], A[6], T[4], A[7], T[5], A[8]);
+    r.zz = dot3(T[6], A[6], T[7], A[7], T[8], A[8]);
     return r;
 }
 __device__ __forceinline__ double quad3(S3 s, V3 n) {  // n^T S n, evaluated as (n^T S) n
-    double t0 = n.x * s.xx + n.y * s.xy + n.z * s.xz;
-    double t1 = n.x * s.xy + n.y * s.yy + n.z * s.yz;
-    double t2 = n.x * s.xz + n.y * s.yz + n.z * s.zz;
-    return t0 * n.x + t1 * n.y + t2 * n.z;
+    double t0 = dot3(n.x, s.xx, n.y, s.xy, n.z, s.xz);
+    double t1 = dot3(n.x, s.xy, n.y, s.yy, n.z, s.yz);
+    double t2 = dot3(n.x, s.xz, n.y, s.yz, n.z, s.zz);
+    return dot3(t0, n.x, t1, n.y, t2, n.z);
 }
 __device__ __forceinline__ void skew3(V3 v, double* K) {
     K[0] = 0.0, K[1] = -v.z, K[2] = v.y, K[3] = v.z, K[4] = 0.0, K[5] = -v.x, K[6] = -v.y, K[7] = v.x, K[8] = 0.0;
@@ -157,38 +208,29 @@ struct PointGeom {
     S3 var;   // world covariance incl. state covariance
 };
 
-// calcBodyCov, voxel_map.cc:22-40 (range / range_var in float as in the reference)
+// calcBodyCov, voxel_map.cc:22-40 (range / range_var in float as in the reference).
+// The reference builds two tangent vectors b1, b2 (3 normalisations) and A = range [d]x [b1 b2], then
+//   cov = d rv d^T + A dv A^T.
+// Because [b1 b2] is an orthonormal basis of the plane normal to the unit ray d,  N N^T = I - d d^T  and
+// [d]x d = 0, so  A dv A^T = range^2 dv [d]x (I - d d^T) [d]x^T = range^2 dv (I - d d^T)  identically.
+// The closed form below is that expression: same value to fp64 rounding (the reference's own result carries
+// the rounding of its three normalisations), ~20 VALU instructions instead of ~250 (3 sqrt + 10 fp64 divides).
 __device__ __forceinline__ S3 calc_body_cov(V3 pb, const LkParams& pr) {
     if (pb.z == 0) pb.z = 0.0001;
-    float range = (float)sqrt(pb.x * pb.x + pb.y * pb.y + pb.z * pb.z);
-    double nrm = sqrt(pb.x * pb.x + pb.y * pb.y + pb.z * pb.z);
-    V3 d = V3{pb.x / nrm, pb.y / nrm, pb.z / nrm};
-    V3 b1 = V3{1.0, 1.0, -(d.x + d.y) / d.z};
-    double n1 = sqrt(b1.x * b1.x + b1.y * b1.y + b1.z * b1.z);
-    b1 = V3{b1.x / n1, b1.y / n1, b1.z / n1};
-    V3 b2 = V3{b1.y * d.z - b1.z * d.y, b1.z * d.x - b1.x * d.z, b1.x * d.y - b1.y * d.x};
-    double n2sq = b2.x * b2.x + b2.y * b2.y + b2.z * b2.z;
-    if (n2sq > 0) {
-        double n2 = sqrt(n2sq);
-        b2 = V3{b2.x / n2, b2.y / n2, b2.z / n2};
-    }
-    // A = range * hat(d) * [b1 b2]   (3x2)
-    double r = (double)range;
-    double H[9];
-    skew3(d, H);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) H[i] = r * H[i];
-    V3 a1 = mat3_mul_v(H, b1), a2 = mat3_mul_v(H, b2);
-    double rv = (double)pr.range_var, dv = pr.dir_var;
-    V3 dr = V3{d.x * rv, d.y * rv, d.z * rv};
-    V3 a1v = V3{a1.x * dv, a1.y * dv, a1.z * dv}, a2v = V3{a2.x * dv, a2.y * dv, a2.z * dv};
+    const double n2 = dot3(pb.x, pb.x, pb.y, pb.y, pb.z, pb.z);
+    const double nrm = sqrt(n2);
+    const double r = (double)(float)nrm;                 // float range, voxel_map.cc:24
+    const double inrm = 1.0 / nrm;
+    const V3 d = V3{pb.x * inrm, pb.y * inrm, pb.z * inrm};
+    const double beta = (r * r) * pr.dir_var;            // range^2 * sin^2(beam_err)
+    const double alpha = (double)pr.range_var - beta;    // dept_err^2 - range^2 sin^2(beam_err)
     S3 c;
-    c.xx = dr.x * d.x + (a1v.x * a1.x + a2v.x * a2.x);
-    c.xy = dr.x * d.y + (a1v.x * a1.y + a2v.x * a2.y);
-    c.xz = dr.x * d.z + (a1v.x * a1.z + a2v.x * a2.z);
-    c.yy = dr.y * d.y + (a1v.y * a1.y + a2v.y * a2.y);
-    c.yz = dr.y * d.z + (a1v.y * a1.z + a2v.y * a2.z);
-    c.zz = dr.z * d.z + (a1v.z * a1.z + a2v.z * a2.z);
+    c.xx = __builtin_fma(alpha * d.x, d.x, beta);
+    c.xy = (alpha * d.x) * d.y;
+    c.xz = (alpha * d.x) * d.z;
+    c.yy = __builtin_fma(alpha * d.y, d.y, beta);
+    c.yz = (alpha * d.y) * d.z;
+    c.zz = __builtin_fma(alpha * d.z, d.z, beta);
     return c;
 }
 
@@ -229,8 +271,15 @@ __device__ __forceinline__ PointGeom point_geom(float bx, float by, float bz, co
 
 // ---------------------------------------------------------------- voxel keys and hash
 // residual-side key, KILO.cc:143-148: float cast, -1.0 for negatives, (int) truncation
-__device__ __forceinline__ void key_trunc(V3 pw, double vs, float* loc, int* key) {
-    double q[3] = {pw.x / vs, pw.y / vs, pw.z / vs};
+__device__ __forceinline__ void key_trunc(V3 pw, const LkParams& pr, float* loc, int* key) {
+    // x / voxel_size; when 1/voxel_size is exact (voxel_size a power of two, e.g. 0.5) the product is the
+    // same correctly rounded quotient and saves three fp64 divides per point
+    double q[3];
+    if (pr.inv_vs_exact != 0.0) {
+        q[0] = pw.x * pr.inv_vs_exact, q[1] = pw.y * pr.inv_vs_exact, q[2] = pw.z * pr.inv_vs_exact;
+    } else {
+        q[0] = pw.x / pr.voxel_size_d, q[1] = pw.y / pr.voxel_size_d, q[2] = pw.z / pr.voxel_size_d;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         float l = (float)q[j];

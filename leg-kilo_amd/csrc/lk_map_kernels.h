@@ -90,7 +90,7 @@ __device__ __forceinline__ void eig_sym3_dev(const double* Ain, double* ev, doub
 }
 
 // init_plane, voxel_map.cc:42-117.  Whole wave; returns is_plane (uniform).
-__device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, float planer_threshold, const lk_pt_rec* base,
+__device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, lk_match_rec* mr, float planer_threshold, const lk_pt_rec* base,
                                             const int* idx, int count) {
     const int lane = threadIdx.x & 63;
     double s[9];
@@ -192,8 +192,10 @@ __device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, float planer_thres
             pl->radius = (float)sqrt(emax);
             pl->d = (float)(-(vmin[0] * c[0] + vmin[1] * c[1] + vmin[2] * c[2]));
             pl->flags = LK_PLANE_IS_PLANE | LK_PLANE_IS_INIT;
+            lk_derive_match(pl, mr);  // compact copy for the residual kernel
         } else {
             pl->flags = pl->flags & ~LK_PLANE_IS_PLANE;
+            mr->flags = pl->flags;
         }
     }
     wave_fence();
@@ -238,6 +240,7 @@ __device__ __forceinline__ int create_child(const LkMap& m, int parent, int oct,
         nd->list_head = -1;
         nd->pad_[0] = 0;
         m.planes[id].flags = 0;
+        m.match[id].flags = 0;
         m.nodes[parent].child[oct] = id;
     }
     id = bcast0(id);
@@ -292,7 +295,7 @@ __device__ __noinline__ void dev_init_octo(const LkMap m, const LkParams pr, int
     NodeRegs r = node_load(nd);
     const int thr = pr.layer_init_num[L];
     if (!(r.npts > thr)) return;
-    const bool is_plane = dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+    const bool is_plane = dev_init_plane(&m.planes[node], &m.match[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
     if (is_plane) {
         r.state &= ~LK_NODE_OCTO_STATE;
         if (r.npts > pr.max_points_num) node_freeze(r);
@@ -357,7 +360,7 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
                 r.new_points += 1;
                 node_push(m, r, pt);
                 if (r.new_points > 5) {  // update_size_threshold_, voxel_map.h:158
-                    const bool still = dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+                    const bool still = dev_init_plane(&m.planes[node], &m.match[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
                     r.new_points = 0;
                     // a refit that turns the node into a non-plane below max_layer makes later points descend
                     // to children (voxel_map.cc:205-223): its own temp_points_ are never read again
@@ -384,7 +387,7 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
                 node_push(m, r, pt);
             }
             if (r.new_points > 5 && !(r.state & LK_NODE_PTS_DROPPED)) {
-                dev_init_plane(&m.planes[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
+                dev_init_plane(&m.planes[node], &m.match[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
                 r.new_points = 0;
             }
             if (r.npts > pr.max_points_num) {
@@ -535,7 +538,7 @@ __device__ __noinline__ void dev_build_node(const LkMap m, const LkParams pr, in
     r.new_points = count;
     bool keep = true;
     if (count > pr.layer_init_num[L]) {
-        const bool is_plane = dev_init_plane(&m.planes[node], pr.planer_threshold, bpts, idx_in + begin, count);
+        const bool is_plane = dev_init_plane(&m.planes[node], &m.match[node], pr.planer_threshold, bpts, idx_in + begin, count);
         if (is_plane) {
             r.state &= ~LK_NODE_OCTO_STATE;
             if (count > pr.max_points_num) {
@@ -638,8 +641,19 @@ __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned i
         nd->list_head = -1;
         for (int c = 0; c < 8; ++c) nd->pad_[c] = 0;
         map.planes[i].flags = 0;
+        map.match[i].flags = 0;
     }
     if (i < LK_CTR_COUNT) map.counters[i] = 0;
+}
+
+// derive the compact match records of imported planes (lk_map_import / lk_map_import_dev)
+__global__ void __launch_bounds__(256) lk_derive_match_kernel(LkMap map, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (map.planes[i].flags & LK_PLANE_IS_PLANE)
+        lk_derive_match(&map.planes[i], &map.match[i]);
+    else
+        map.match[i].flags = map.planes[i].flags;
 }
 
 // rebuild the hash from imported root records (lk_map_import)

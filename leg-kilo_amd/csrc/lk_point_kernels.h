@@ -20,118 +20,158 @@
 struct Match {
     int node;
     int layer;
+#if !LK_OPT_SLIM
     V3 n;          // plane normal
     V3 c;          // plane center
+#endif
     float dis;     // signed distance stored as float (voxel_map.h:92, .cc:401-402)
     double sig_pl; // J_nq * plane_var * J_nq^T
+    double lazy_d, lazy_sig;  // |d| and sigma_l of the first passing candidate (deferred probability)
 };
 
-// voxel_map.cc:371-413 for one plane node.  Returns nothing; updates success / prob / best.
-__device__ __forceinline__ void eval_plane(const lk_plane_rec* __restrict__ pl, int node, int layer, const PointGeom& g,
+// voxel_map.cc:371-413 for one plane node.  q0..q2 / tail = the first 64 B of the node's match record (center,
+// normal, d, radius, flags), already in registers; the remaining 80 B (S11, w, s22) are requested BEFORE the float
+// range gate is evaluated so that the whole record costs one memory round trip.
+__device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, double2 q0, double2 q1, double2 q2,
+                                           float pd, float pradius, int node, int layer, const PointGeom& g,
                                            double sigma_num, bool& success, double& prob, Match& best) {
-    const double2* q = reinterpret_cast<const double2*>(pl);
-    double2 q0 = q[0], q1 = q[1], q2 = q[2];   // center xyz, normal xyz
-    float2 dr = *reinterpret_cast<const float2*>(&pl->d);
+    const double2* sv = reinterpret_cast<const double2*>(mr->s11);  // byte offset 64, 16-B aligned
+    const double2 v0 = sv[0], v1 = sv[1], v2 = sv[2], v3 = sv[3], v4 = sv[4];
     V3 c = V3{q0.x, q0.y, q1.x}, n = V3{q1.y, q2.x, q2.y};
-    double sd = n.x * g.p_w.x + n.y * g.p_w.y + n.z * g.p_w.z + (double)dr.x;
+    double sd = dot3(n.x, g.p_w.x, n.y, g.p_w.y, n.z, g.p_w.z) + (double)pd;
     float dis_to_plane = (float)fabs(sd);
     float dis_to_center = (float)((c.x - g.p_w.x) * (c.x - g.p_w.x) + (c.y - g.p_w.y) * (c.y - g.p_w.y) +
                                   (c.z - g.p_w.z) * (c.z - g.p_w.z));
     float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);
-    if (!((double)range_dis <= 3.0 * (double)dr.y)) return;  // radius_k = 3
-    double J[6] = {g.p_w.x - c.x, g.p_w.y - c.y, g.p_w.z - c.z, -n.x, -n.y, -n.z};
-    // sigma = J * plane_var * J^T evaluated as (J * PV) * J^T with the symmetric upper triangle
-    double t[6] = {0, 0, 0, 0, 0, 0};
-    const double* pv = pl->plane_var;
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int cc = r; cc < 6; ++cc) {
-            double v = pv[k++];
-            t[cc] += J[r] * v;
-            if (cc != r) t[r] += J[cc] * v;
-        }
-    double sig_pl = t[0] * J[0] + t[1] * J[1] + t[2] * J[2] + t[3] * J[3] + t[4] * J[4] + t[5] * J[5];
+    if (!((double)range_dis <= 3.0 * (double)pradius)) return;  // radius_k = 3
+    const V3 q = V3{g.p_w.x - c.x, g.p_w.y - c.y, g.p_w.z - c.z};
+    const S3 s11 = S3{v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
+    // J plane_var J^T = q^T S11 q - 2 q.w + s22   (w = S12 n, s22 = n^T S22 n precomputed per plane)
+    double sig_pl = quad3(s11, q) - 2.0 * dot3(q.x, v3.x, q.y, v3.y, q.z, v4.x) + v4.y;
     double sigma_l = sig_pl + quad3(g.var, n);
     if (!((double)dis_to_plane < sigma_num * sqrt(sigma_l))) return;
+    // prob = exp(-d^2 / 2 sigma) / sqrt(sigma) only ranks candidates (voxel_map.cc:389-391).  The first passing
+    // candidate always wins against prob = 0 (the 3-sigma gate bounds the exponent by -4.5), so its value is
+    // only computed if a second candidate passes; `prob` < 0 encodes "first candidate, value not yet computed".
+    const double ssig = sqrt(sigma_l);
+    bool take;
+    if (!success) {
+        take = true;
+        prob = -1.0;
+        best.lazy_d = (double)dis_to_plane;
+        best.lazy_sig = sigma_l;
+    } else {
+        if (prob < 0.0)
+            prob = 1.0 / (sqrt(best.lazy_sig)) * exp(-0.5 * best.lazy_d * best.lazy_d / best.lazy_sig);
+        const double this_prob = 1.0 / ssig * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
+        take = this_prob > prob;
+        if (take) prob = this_prob;
+    }
     success = true;
-    double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
-    if (this_prob > prob) {
-        prob = this_prob;
+    if (take) {
         best.node = node;
         best.layer = layer;
+#if !LK_OPT_SLIM
         best.n = n;
         best.c = c;
+#endif
         best.dis = (float)sd;
         best.sig_pl = sig_pl;
     }
 }
 
-// build_single_residual (voxel_map.cc:363-427): pre-order DFS, children in index order.  The depth is a
-// template parameter (<= LK_MAX_LAYER) so that no dynamically indexed private array (scratch) is needed.
-template <int L>
-__device__ __forceinline__ void match_node(const LkMap& m, int node, int max_layer, const PointGeom& g,
-                                           double sigma_num, bool& success, double& prob, Match& best) {
-    unsigned int flags = m.planes[node].flags;
-    if (flags & LK_PLANE_IS_PLANE) {
-        eval_plane(&m.planes[node], node, L, g, sigma_num, success, prob, best);
-        return;
-    }
-    if constexpr (L < LK_MAX_LAYER) {
-        if (L < max_layer) {
-            for (int ci = 0; ci < 8; ++ci) {
-                int child = m.nodes[node].child[ci];
-                if (child >= 0) match_node<L + 1>(m, child, max_layer, g, sigma_num, success, prob, best);
-            }
-        }
-    }
-}
+// build_single_residual (voxel_map.cc:363-427): pre-order DFS, children in index order, written as ONE flat loop
+// (a single copy of the plane evaluation in the instruction stream; the <=5-deep path lives in scalar registers
+// selected with compares, so no dynamically indexed private array / scratch is needed).
 __device__ __forceinline__ void match_root(const LkMap& m, int root, int max_layer, const PointGeom& g, double sigma_num,
                                            bool& success, double& prob, Match& best) {
-    match_node<0>(m, root, max_layer, g, sigma_num, success, prob, best);
+    int n0 = root, n1 = -1, n2 = -1, n3 = -1, n4 = -1;
+    unsigned int cis = 0;  // next child index of each level, 4 bits per level
+    int level = 0;
+    bool fresh = true;
+    while (level >= 0) {
+        const int node = (level == 0) ? n0 : (level == 1) ? n1 : (level == 2) ? n2 : (level == 3) ? n3 : n4;
+        if (fresh) {
+            const lk_match_rec* pl = &m.match[node];
+            const double2* q = reinterpret_cast<const double2*>(pl);
+            double2 q0 = q[0], q1 = q[1], q2 = q[2];
+            const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad
+            if (__float_as_uint(tail.z) & LK_PLANE_IS_PLANE) {
+                eval_plane(pl, q0, q1, q2, tail.x, tail.y, node, level, g, sigma_num, success, prob, best);
+                --level;
+                fresh = false;
+                continue;
+            }
+            if (level >= max_layer || level >= LK_MAX_LAYER) {
+                --level;
+                fresh = false;
+                continue;
+            }
+            cis &= ~(15u << (4 * level));
+        }
+        const int4* ch = reinterpret_cast<const int4*>(m.nodes[node].child);
+        const int4 ca = ch[0], cb = ch[1];
+        unsigned int ci = (cis >> (4 * level)) & 15u;
+        int child = -1;
+        while (ci < 8u && child < 0) {
+            child = (ci == 0) ? ca.x : (ci == 1) ? ca.y : (ci == 2) ? ca.z : (ci == 3) ? ca.w
+                  : (ci == 4) ? cb.x : (ci == 5) ? cb.y : (ci == 6) ? cb.z : cb.w;
+            ++ci;
+        }
+        cis = (cis & ~(15u << (4 * level))) | (ci << (4 * level));
+        if (child >= 0) {
+            ++level;
+            if (level == 1) n1 = child;
+            else if (level == 2) n2 = child;
+            else if (level == 3) n3 = child;
+            else n4 = child;
+            fresh = true;
+        } else {
+            --level;
+            fresh = false;
+        }
+    }
 }
 
-// KILO.cc:142-183: root lookup, match, one-neighbour retry (unit-mismatch comparison kept)
-__device__ __forceinline__ bool match_point(const LkMap& m, const LkParams& pr, const PointGeom& g, Match& best) {
-    float loc[3];
-    int key[3];
-    key_trunc(g.p_w, pr.voxel_size_d, loc, key);
-    int root = hash_find(m, key[0], key[1], key[2]);
-    if (root < 0) return false;
-    bool success = false;
-    double prob = 0;
-    match_root(m, root, pr.max_layer, g, pr.sigma_num, success, prob, best);
-    if (!success) {
-        const lk_node_rec* nr = &m.nodes[root];
-        double ql = (double)nr->quater_length;
-        int near[3] = {key[0], key[1], key[2]};
+// KILO.cc:156-178: the ONE neighbour voxel that is tried when the home voxel gave no match.  loc is in voxel
+// units, voxel_center +- quater_length in metres — the unit mismatch of the reference is kept as is.
+__device__ __forceinline__ void neighbour_retry(const LkMap& m, const LkParams& pr, int root, const float* loc, const int* key,
+                                                const PointGeom& g, bool& success, double& prob, Match& best) {
+    const lk_node_rec* nr = &m.nodes[root];
+    double ql = (double)nr->quater_length;
+    int near[3] = {key[0], key[1], key[2]};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double vc = nr->voxel_center[j];
-            if ((double)loc[j] > (vc + ql))
-                near[j] += 1;
-            else if ((double)loc[j] < (vc - ql))
-                near[j] -= 1;
-        }
-        int nroot = hash_find(m, near[0], near[1], near[2]);
-        if (nroot >= 0) match_root(m, nroot, pr.max_layer, g, pr.sigma_num, success, prob, best);
+    for (int j = 0; j < 3; ++j) {
+        double vc = nr->voxel_center[j];
+        if ((double)loc[j] > (vc + ql))
+            near[j] += 1;
+        else if ((double)loc[j] < (vc - ql))
+            near[j] -= 1;
     }
-    return success;
+    int nroot = hash_find(m, near[0], near[1], near[2]);
+    if (nroot >= 0) match_root(m, nroot, pr.max_layer, g, pr.sigma_num, success, prob, best);
 }
 
 // KILO.cc:195-209: h (1x6), z, R for a matched point
-__device__ __forceinline__ void obs_row(const Match& b, const PointGeom& g, const BucketConst& bc, double ratio,
-                                        double* h, double& z, double& R) {
-    V3 u = mat3T_mul_v(bc.R, b.n);  // R^T n
+__device__ __forceinline__ void obs_row(const LkMap& m, const Match& b, const PointGeom& g, const BucketConst& bc,
+                                        double ratio, double* h, double& z, double& R) {
+#if LK_OPT_SLIM
+    // the winner's normal is re-read (an L1/L2 hit) instead of being carried through the tree walk
+    const double2* q = reinterpret_cast<const double2*>(&m.match[b.node]);
+    const double2 q1 = q[1], q2 = q[2];
+    const V3 bn = V3{q1.y, q2.x, q2.y};
+#else
+    const V3 bn = b.n;
+#endif
+    V3 u = mat3T_mul_v(bc.R, bn);  // R^T n
     // crossmat(p_i) * u
     h[0] = -g.p_i.z * u.y + g.p_i.y * u.z;
     h[1] = g.p_i.z * u.x - g.p_i.x * u.z;
     h[2] = -g.p_i.y * u.x + g.p_i.x * u.y;
-    h[3] = b.n.x, h[4] = b.n.y, h[5] = b.n.z;
+    h[3] = bn.x, h[4] = bn.y, h[5] = bn.z;
     z = -(double)b.dis;
     S3 vb = congruence(bc.RE, g.body);  // (R ext_R) body_cov (R ext_R)^T, no state covariance (KILO.cc:205-206)
-    R = ratio * (b.sig_pl + quad3(vb, b.n));
+    R = ratio * (b.sig_pl + quad3(vb, bn));
 }
 
 struct ResidualOut {       // optional per-point outputs (config 2 / lk_residuals); any may be null
@@ -142,44 +182,82 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
     float* world;          // n x 4 (x y z intensity), cloud_down_world
 };
 
+// LDS row record of one point: h(6), z, 1/R, R   (9 doubles; stride 9 keeps 64-bit LDS reads conflict-free
+// for the access pattern of the reduction: lanes of one half-wave read the SAME row, i.e. broadcasts)
+#define LK_ROW2 10  // doubles per row: h(6) z 1/R R valid
+
+#if LK_OPT_WAVES
+#define LK_RES_BOUNDS __launch_bounds__(LK_PB, LK_OPT_WAVES)
+#else
+#define LK_RES_BOUNDS __launch_bounds__(LK_PB)
+#endif
 template <bool EMIT_ROWS>
-__global__ void __launch_bounds__(LK_PB)
+__global__ void LK_RES_BOUNDS
     lk_residual_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                        size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
                        ResidualOut out, size_t out_slot_stride) {
-    __shared__ double red[LK_PB / LK_WAVE][LK_NPART];
+    // per-wave LDS region holding the wave's 64 observation rows (h6, z, 1/R, R)
+    __shared__ float4 stage[LK_PB / LK_WAVE][64 * LK_ROW2 / 2];
+#ifdef LK_TIMING
+    unsigned long long ts[8];
+#define LK_STAMP(k) ts[k] = __builtin_readcyclecounter()
+#else
+#define LK_STAMP(k)
+#endif
+    LK_STAMP(0);
     const int slot = blockIdx.y;
-    const int i = blockIdx.x * LK_PB + threadIdx.x;
-    BucketConst bc;
-    load_bucket_const(&filters[slot], pr, bc);
-    double acc[29];
-#pragma unroll
-    for (int q = 0; q < 29; ++q) acc[q] = 0.0;
-    if (i < n) {
-        const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
-        PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
-        if (out.world) {
-            float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
-            reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
-        }
-        Match best;
-        bool ok = match_point(map, pr, g, best);
-        double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
-        if (ok) {
-            obs_row(best, g, bc, pr.lidar_ratio, h, z, R);
-            double ri = 1.0 / R;
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double ha = h[a] * ri;
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[q++] = ha * h[b];
-                acc[21 + a] = ha * z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * LK_PB + tid;
+    bool ok = false;
+    double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
+    {
+        BucketConst bc;
+        load_bucket_const(&filters[slot], pr, bc);
+        PointGeom g;
+        float loc[3] = {0.f, 0.f, 0.f};
+        int key[3] = {0, 0, 0};
+        int root = -1;
+        if (i < n) {
+            const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
+            g = point_geom(p.x, p.y, p.z, bc, pr);
+            if (out.world) {
+                float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
+                reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
             }
-            acc[27] = R;
-            acc[28] = 1.0;
+            LK_STAMP(1);
+            key_trunc(g.p_w, pr, loc, key);
+#if defined(LK_ABL) && LK_ABL == 2
+            root = (int)(lk_hash3(key[0], key[1], key[2]) % 16384u);  // ablation: no hash probe
+#else
+            root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
+#endif
         }
-        if (EMIT_ROWS) {
+        // K2: home voxel first (the root's 256-B record is fetched in one round trip inside match_root)
+        bool success = false;
+        double prob = 0;
+        Match best;
+        best.node = -1;
+        LK_STAMP(2);
+#if defined(LK_ABL) && LK_ABL == 1
+        if (root >= 0) { success = (root & 7) != 0; best.node = root; best.layer = 0; best.dis = 0.01f; best.sig_pl = 1e-4; }  // ablation: no plane fetch
+#else
+        if (root >= 0) match_root(map, root, pr.max_layer, g, pr.sigma_num, success, prob, best);
+#endif
+        LK_STAMP(3);
+        // the one-neighbour retry (KILO.cc:156-178)
+#if !(defined(LK_ABL) && (LK_ABL == 3 || LK_ABL == 1))
+        if (root >= 0 && !success) neighbour_retry(map, pr, root, loc, key, g, success, prob, best);
+#endif
+        LK_STAMP(4);
+        ok = success;
+#if defined(LK_ABL) && LK_ABL == 1
+        if (ok) { h[0] = g.p_i.x; h[1] = g.p_i.y; h[2] = g.p_i.z; h[3] = g.var.xx; h[4] = g.body.yy; h[5] = 1; z = 0.01; R = 1e-3 + g.var.zz; }
+#else
+        if (ok) obs_row(map, best, g, bc, pr.lidar_ratio, h, z, R);
+#endif
+        LK_STAMP(5);
+        if (EMIT_ROWS && i < n) {
             size_t o = (size_t)slot * out_slot_stride + i;
             out.valid[o] = ok ? 1 : 0;
             out.z[o] = z;
@@ -188,20 +266,72 @@ __global__ void __launch_bounds__(LK_PB)
             for (int a = 0; a < 6; ++a) out.h6[o * 6 + a] = h[a];
         }
     }
-    // K3: wave shuffle reduction, then 4 waves through LDS, one partial record per workgroup
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // K3, per wave and without any block barrier.  Every lane stores its row [h(6) z 1/R R valid] (zeros when it
+    // did not match) in the wave's LDS region; lane (q = lane & 31, half = lane >> 5) then accumulates component q of
+    // [A(21) b(6) sumR count] over the 32 rows of its half, in row order, branch-free (ds_read_b64 broadcasts, all
+    // loads independent of the arithmetic); the two halves are combined with one DPP-free cross-lane read.
+    // One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
+    double* rows = reinterpret_cast<double*>(&stage[wv][0]);
+    {
+        double* r = rows + lane * LK_ROW2;
+        const double ri = ok ? 1.0 / R : 0.0;
 #pragma unroll
-    for (int q = 0; q < 29; ++q) {
-        double v = wave_sum(acc[q]);
-        if (lane == 0) red[wv][q] = v;
+        for (int a = 0; a < 6; ++a) r[a] = h[a];   // h, z are zero for unmatched lanes
+        r[6] = z;
+        r[7] = ri;
+        r[8] = ok ? R : 0.0;
+        r[9] = ok ? 1.0 : 0.0;
     }
-    __syncthreads();
-    if (threadIdx.x < LK_NPART) {
-        double s = 0.0;
-        if (threadIdx.x < 29)
-            for (int w = 0; w < LK_PB / LK_WAVE; ++w) s += red[w][threadIdx.x];
-        partials[(size_t)slot * part_slot_stride + (size_t)blockIdx.x * LK_NPART + threadIdx.x] = s;
+    LK_STAMP(6);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    LK_STAMP(7);
+    {
+        const int q = lane & 31, half = lane >> 5;
+        int a = 0, b = 0;   // component -> operands: A(a,b) = sum h[a] ri h[b];  b-vector: h[a] ri z
+        if (q < 21) {
+            int rem = q;
+            while (rem >= 6 - a) {
+                rem -= 6 - a;
+                ++a;
+            }
+            b = a + rem;
+        } else if (q < 27) {
+            a = q - 21;
+            b = 6;
+        } else if (q == 27) {
+            a = 8;   // R * 1  (sumR):  r[8] * r[9] * r[9]... handled through the generic product below
+            b = 9;
+        } else {
+            a = 9;   // count: valid * valid
+            b = 9;
+        }
+        // generic product v = (r[a] * w) * r[b] with w = r[7] for A/b and w = 1 (i.e. r[9], the valid flag) otherwise
+        const int wsel = (q < 27) ? 7 : 9;
+        const double* base = rows + (half * 32) * LK_ROW2;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const double* r = base + j * LK_ROW2;
+            acc += (r[a] * r[wsel]) * r[b];
+        }
+        acc += __shfl_xor(acc, 32, LK_WAVE);
+        if (lane < LK_NPART) {
+            const size_t wave_id = (size_t)blockIdx.x * (LK_PB / LK_WAVE) + wv;
+            partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
+        }
     }
+#ifdef LK_TIMING
+    if (lane == 0 && out.h6 == nullptr && out.z != nullptr) {  // timing build: out.z doubles as the stamp buffer
+        unsigned long long tend = __builtin_readcyclecounter();
+        size_t w = ((size_t)slot * gridDim.x + blockIdx.x) * (LK_PB / LK_WAVE) + wv;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.z) + w * 10;
+        for (int k = 0; k < 8; ++k) dst[k] = ts[k];
+        dst[8] = tend;
+        dst[9] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID etc. (debug)
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- find-or-create a root voxel
@@ -249,6 +379,7 @@ __device__ __forceinline__ int root_find_or_create(const LkMap& m, const LkParam
                 nd->list_head = -1;
                 nd->pad_[0] = 0;  // list count
                 m.planes[id].flags = 0;
+                m.match[id].flags = 0;
                 slotw[4 * s + 0] = key[0];
                 slotw[4 * s + 1] = key[1];
                 slotw[4 * s + 2] = key[2];

@@ -146,17 +146,21 @@ def _expand21(v):
 
 
 def compare_planes(pa, pb, rtol, where, ptol=1e-9):
+    """ptol = tolerance on stored world points (the accumulated state delta of the run).  A plane fit divides by
+    eigenvalue gaps, so normal / plane_var deltas are ptol times a conditioning factor (bounded here at 1e3/1e4)."""
+    ntol = min(max(1e-7, 1e3 * ptol), 1e-3)
+    vtol = min(max(rtol, 1e4 * ptol), 1e-2)
     assert np.allclose(pa["center"], pb["center"], rtol=0, atol=ptol), (where, pa["center"], pb["center"])
     s = 1.0 if np.dot(pa["normal"], pb["normal"]) > 0 else -1.0
-    assert np.allclose(pa["normal"], s * pb["normal"], rtol=0, atol=1e-7), (where, pa["normal"], pb["normal"])
-    assert abs(pa["d"] - s * pb["d"]) <= 1e-5 * max(1.0, abs(pa["d"])), (where, pa["d"], pb["d"])
+    assert np.allclose(pa["normal"], s * pb["normal"], rtol=0, atol=ntol), (where, pa["normal"], pb["normal"])
+    assert abs(pa["d"] - s * pb["d"]) <= max(1e-5, 40 * ntol) * max(1.0, abs(pa["d"])), (where, pa["d"], pb["d"])
     assert abs(pa["radius"] - pb["radius"]) <= 1e-5 * max(1.0, abs(pa["radius"])), where
     assert pa["points_size"] == pb["points_size"], where
     A, B = _expand21(pa["plane_var"]), _expand21(pb["plane_var"])
     B[:3, 3:] *= s
     B[3:, :3] *= s
     scale = np.abs(A).max() + 1e-300
-    assert np.abs(A - B).max() <= rtol * scale, (where, np.abs(A - B).max() / scale)
+    assert np.abs(A - B).max() <= vtol * scale, (where, np.abs(A - B).max() / scale)
 
 
 def compare_nodes(a, b, where, rtol=1e-6, stats=None, ptol=1e-9):

