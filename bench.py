@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--map-warm", type=int, default=6)
     ap.add_argument("--stream-scans", type=int, default=6)
     ap.add_argument("--cpu-sample", type=int, default=4, help="scans the oracle replays for cpu_baseline (0 = skip)")
+    ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 2x, 16 B/slot)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +126,10 @@ def main():
     P = config.LEG_FUSION
     S = args.scans_per_gpu
     world, traj = synth.World(), synth.Trajectory()
-    cfg = config.make_config(P, device_id=local_rank, n_slots=S, max_roots=1 << 17, max_nodes=1 << 18,
+    # capacities sized to the scene (a 40 x 30 x 8 m room has ~20 k root voxels): a right-sized hash table keeps
+    # table + match records inside one XCD's 4 MB L2
+    mr = args.max_roots_log2
+    cfg = config.make_config(P, device_id=local_rank, n_slots=S, max_roots=1 << mr, max_nodes=1 << (mr + 1),
                              max_point_blocks=1 << 17, max_scan_points=1 << 17)
     g = binding.LegKiloHip(cfg)  # raises without the HIP library / a gfx950 device
 

@@ -133,23 +133,22 @@ __device__ __forceinline__ void match_root(const LkMap& m, int root, int max_lay
     }
 }
 
-// KILO.cc:156-178: the ONE neighbour voxel that is tried when the home voxel gave no match.  loc is in voxel
-// units, voxel_center +- quater_length in metres — the unit mismatch of the reference is kept as is.
-__device__ __forceinline__ void neighbour_retry(const LkMap& m, const LkParams& pr, int root, const float* loc, const int* key,
-                                                const PointGeom& g, bool& success, double& prob, Match& best) {
-    const lk_node_rec* nr = &m.nodes[root];
-    double ql = (double)nr->quater_length;
-    int near[3] = {key[0], key[1], key[2]};
+// KILO.cc:156-172: key of the ONE neighbour voxel that is tried when the home voxel gave no match.  loc is in
+// voxel units, voxel_center +- quater_length in metres — the unit mismatch of the reference is kept as is.  For a
+// root voxel, voxel_center = (0.5 + key) * voxel_size and quater_length = voxel_size / 4 (voxel_map.cc:354-357, both
+// with the float voxel_size) are functions of the key alone, so the root's node record need not be fetched.
+__device__ __forceinline__ void neighbour_key(const LkParams& pr, const float* loc, const int* key, int* near) {
+    const double vs = (double)pr.voxel_size_f;
+    const double ql = (double)(pr.voxel_size_f / 4);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        double vc = nr->voxel_center[j];
+        const double vc = (0.5 + key[j]) * vs;
+        near[j] = key[j];
         if ((double)loc[j] > (vc + ql))
             near[j] += 1;
         else if ((double)loc[j] < (vc - ql))
             near[j] -= 1;
     }
-    int nroot = hash_find(m, near[0], near[1], near[2]);
-    if (nroot >= 0) match_root(m, nroot, pr.max_layer, g, pr.sigma_num, success, prob, best);
 }
 
 // KILO.cc:195-209: h (1x6), z, R for a matched point
@@ -216,8 +215,8 @@ __global__ void LK_RES_BOUNDS
         load_bucket_const(&filters[slot], pr, bc);
         PointGeom g;
         float loc[3] = {0.f, 0.f, 0.f};
-        int key[3] = {0, 0, 0};
-        int root = -1;
+        int key[3] = {0, 0, 0}, near[3] = {0, 0, 0};
+        int root = -1, nroot = -1;
         if (i < n) {
             const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
             g = point_geom(p.x, p.y, p.z, bc, pr);
@@ -227,11 +226,7 @@ __global__ void LK_RES_BOUNDS
             }
             LK_STAMP(1);
             key_trunc(g.p_w, pr, loc, key);
-#if defined(LK_ABL) && LK_ABL == 2
-            root = (int)(lk_hash3(key[0], key[1], key[2]) % 16384u);  // ablation: no hash probe
-#else
             root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
-#endif
         }
         // K2: home voxel first (the root's 256-B record is fetched in one round trip inside match_root)
         bool success = false;
@@ -239,23 +234,18 @@ __global__ void LK_RES_BOUNDS
         Match best;
         best.node = -1;
         LK_STAMP(2);
-#if defined(LK_ABL) && LK_ABL == 1
-        if (root >= 0) { success = (root & 7) != 0; best.node = root; best.layer = 0; best.dis = 0.01f; best.sig_pl = 1e-4; }  // ablation: no plane fetch
-#else
         if (root >= 0) match_root(map, root, pr.max_layer, g, pr.sigma_num, success, prob, best);
-#endif
         LK_STAMP(3);
         // the one-neighbour retry (KILO.cc:156-178)
-#if !(defined(LK_ABL) && (LK_ABL == 3 || LK_ABL == 1))
-        if (root >= 0 && !success) neighbour_retry(map, pr, root, loc, key, g, success, prob, best);
-#endif
+        if (root >= 0 && !success) {  // KILO.cc:156-178
+            neighbour_key(pr, loc, key, near);
+            // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
+            if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = hash_find(map, near[0], near[1], near[2]);
+            if (nroot >= 0) match_root(map, nroot, pr.max_layer, g, pr.sigma_num, success, prob, best);
+        }
         LK_STAMP(4);
         ok = success;
-#if defined(LK_ABL) && LK_ABL == 1
-        if (ok) { h[0] = g.p_i.x; h[1] = g.p_i.y; h[2] = g.p_i.z; h[3] = g.var.xx; h[4] = g.body.yy; h[5] = 1; z = 0.01; R = 1e-3 + g.var.zz; }
-#else
         if (ok) obs_row(map, best, g, bc, pr.lidar_ratio, h, z, R);
-#endif
         LK_STAMP(5);
         if (EMIT_ROWS && i < n) {
             size_t o = (size_t)slot * out_slot_stride + i;
