@@ -181,6 +181,7 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMalloc(&m.blocks, sizeof(lk_block_rec) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&m.counters, sizeof(unsigned int) * LK_CTR_COUNT));
     HIPCHK(h, hipMalloc(&m.touched, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.heavy, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
@@ -208,7 +209,7 @@ void lk_destroy(lk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched,
+    void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
@@ -367,7 +368,7 @@ int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const 
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
     const int nblk = (n + LK_PB - 1) / LK_PB;
-    HIPCHK(h, hipMemsetAsync(&m.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipMemsetAsync(&m.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
     LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
@@ -380,10 +381,34 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
+#ifdef LK_TIMING
+    if (do_insert && !h->map.dbg) hipMalloc(&h->map.dbg, sizeof(unsigned long long) * 4 * (size_t)h->map.max_scan);
+#endif
     if (do_insert) {
+        LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
+                                                     h->d_filters, d_pts, n));
         int grid = std::min(std::max((n + 3) / 4, 1), 4096);
-        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, m, h->pr,
+        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+#ifdef LK_TIMING
+        {
+            hipStreamSynchronize(h->stream);
+            unsigned int ctr[LK_CTR_COUNT];
+            hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost);
+            unsigned int nh = ctr[LK_CTR_HEAVY];
+            std::vector<unsigned long long> d(4 * (size_t)nh);
+            if (nh) hipMemcpy(d.data(), h->map.dbg, d.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<size_t> order(nh);
+            for (size_t i = 0; i < nh; ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return d[4 * a + 1] > d[4 * b + 1]; });
+            unsigned long long tot = 0, totm = 0;
+            for (size_t i = 0; i < nh; ++i) tot += d[4 * i + 1], totm += d[4 * i];
+            fprintf(stderr, "[LK_TIMING insert] n=%d touched=%u heavy=%u sum_m=%llu mean_cycles=%.0f; longest:", n, ctr[LK_CTR_TOUCHED], nh, totm, nh ? (double)tot / nh : 0.0);
+            for (size_t i = 0; i < std::min<size_t>(6, nh); ++i)
+                fprintf(stderr, " [m=%llu cyc=%llu kind=0x%llx]", d[4 * order[i]], d[4 * order[i] + 1], d[4 * order[i] + 2]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     return LK_OK;
 }
@@ -437,7 +462,7 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     HIPCHK(h, hipMalloc(&d_i1, sizeof(int) * n));
     HIPCHK(h, hipMemcpyAsync(d_w, xyz_world, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_b, xyz_body, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "build_points", hipLaunchKernelGGL(lk_build_points_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr,
                                                  h->d_filters, d_w, d_b, (int)n, d_bpts, d_k0, d_i0));
@@ -468,7 +493,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     lk_pt_rec* d_pv = nullptr;
     HIPCHK(h, hipMalloc(&d_pv, sizeof(lk_pt_rec) * n));
     HIPCHK(h, hipMemcpyAsync(d_pv, st.data(), sizeof(lk_pt_rec) * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 2 * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 4096);

@@ -40,7 +40,7 @@
 #define LK_E_SCRATCH_FULL 8u
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,
-       LK_CTR_COUNT = 8 };
+       LK_CTR_HEAVY = 6, LK_CTR_COUNT = 8 };
 
 struct LkFilter {
     double x[LK_STATE_DOUBLES];  // rot(9) pos vel ba bw grav imu_a imu_w bv contact
@@ -109,6 +109,8 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     lk_block_rec* blocks;
     unsigned int* counters;      // LK_CTR_*
     int* touched;                // roots touched by the current bucket
+    int* heavy;                  // subset of touched that needs the wave-per-root state machine
+    unsigned long long* dbg;     // LK_TIMING builds only: per heavy root {m, cycles, kind, root}
     int* next;                   // per-point list links (bucket-local index)
     int* scratch;                // per-root gathered indices
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;

@@ -411,13 +411,23 @@ __global__ void __launch_bounds__(LK_MB)
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * LK_MB) >> 6;
-    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    // scan points: only the roots the light pre-pass could not finish; pointWithVar input: every touched root
+    const int n_touched = (int)map.counters[FROM_PV ? LK_CTR_TOUCHED : LK_CTR_HEAVY];
+    const int* worklist = FROM_PV ? map.touched : map.heavy;
     BucketConst bc;
     if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
     for (int t = wave; t < n_touched; t += nwaves) {
-        const int root = bcast0(map.touched[t]);
+        const int root = bcast0(worklist[t]);
         lk_node_rec* nd = &map.nodes[root];
         const int m = bcast0((int)nd->pad_[0]);
+#ifdef LK_TIMING
+        const unsigned long long t_begin = __builtin_readcyclecounter();
+        const unsigned int st0 = nd->state, pf0 = map.planes[root].flags;
+        struct DbgAtExit {
+            unsigned long long* p; unsigned long long t0; int m; unsigned int kind; int root; int lane;
+            __device__ ~DbgAtExit() { if (lane == 0 && p) { p[0] = (unsigned long long)m; p[1] = __builtin_readcyclecounter() - t0; p[2] = kind; p[3] = (unsigned long long)root; } }
+        } dbg_exit{map.dbg ? map.dbg + 4 * (size_t)t : nullptr, t_begin, m, (st0 & 7u) | ((pf0 & 1u) << 4), root, lane};
+#endif
         int cur = bcast0(nd->list_head);
         int base = 0;
         if (lane == 0) {
@@ -435,32 +445,173 @@ __global__ void __launch_bounds__(LK_MB)
             cur = bcast0(map.next[cur]);
         }
         wave_fence();
-        int last = -1;
-        for (int step = 0; step < m; ++step) {
-            int best = 0x7fffffff;
-            for (int j = lane; j < m; j += LK_WAVE) {
-                int v = map.scratch[base + j];
-                if (v > last && v < best) best = v;
-            }
-            best = wave_min_i(best);
-            last = best;
-            PtU pt;
+        auto point_of = [&](int idx, PtU& pt) {
             if (FROM_PV) {
-                load_pt(pv, nullptr, best, pt.pw, pt.var);
+                load_pt(pv, nullptr, idx, pt.pw, pt.var);
             } else {
-                const float4 p = reinterpret_cast<const float4*>(pts)[best];
+                const float4 p = reinterpret_cast<const float4*>(pts)[idx];
                 PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
                 pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
                 pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
                 pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
             }
-            dev_update_octo(map, pr, root, pt);
-            // a root that froze as a plane ignores all remaining points
-            unsigned int st = (unsigned int)bcast0((int)nd->state);
-            unsigned int pf = (unsigned int)bcast0((int)map.planes[root].flags);
-            if ((st & LK_NODE_INIT_OCTO) && (pf & LK_PLANE_IS_PLANE) && !(st & LK_NODE_UPDATE_ENABLE)) break;
+        };
+        if (m <= LK_WAVE) {
+            // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
+            const int myidx = (lane < m) ? map.scratch[base + lane] : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
+            const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
+            int pos = 0;
+            while (pos < m) {
+                NodeRegs r = node_load(nd);
+                const bool is_plane = (bcast0((int)map.planes[root].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+                const bool leaf_uninit = !(r.state & LK_NODE_INIT_OCTO);
+                if (leaf_uninit || is_plane) {
+                    // leaf root: append up to the next event in one go (all lanes derive their own point)
+                    if (!leaf_uninit && !(r.state & LK_NODE_UPDATE_ENABLE)) break;  // frozen plane ignores the rest
+                    int k = m - pos;
+                    if (leaf_uninit) {
+                        k = min(k, pr.layer_init_num[0] + 1 - r.npts);               // until size > threshold
+                    } else {
+                        k = min(k, min(6 - r.new_points, pr.max_points_num - r.npts)); // until refit / freeze
+                    }
+                    k = max(k, 1);  // e.g. a first-frame plane with exactly max_points_num points: push one, then freeze
+                    if (r.block < 0) r.block = alloc_block(map);
+                    if (lane >= pos && lane < pos + k) {
+                        PtU pt;
+                        point_of(sidx, pt);
+                        lk_pt_rec* dst = &map.blocks[r.block].pts[r.npts + (lane - pos)];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) dst->pw[c] = pt.pw[c];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) dst->var[c] = pt.var[c];
+                    }
+                    r.npts += k;
+                    r.new_points += k;
+                    pos += k;
+                    wave_fence();
+                    if (leaf_uninit) {
+                        node_store(nd, r);
+                        if (r.npts > pr.layer_init_num[0]) dev_init_octo<0>(map, pr, root);  // voxel_map.cc:189
+                    } else {
+                        if (r.new_points > 5) {  // voxel_map.cc:195-198
+                            const bool still = dev_init_plane(&map.planes[root], &map.match[root], pr.planer_threshold,
+                                                              map.blocks[r.block].pts, nullptr, r.npts);
+                            r.new_points = 0;
+                            if (!still && r.layer < pr.max_layer) r.block = -1;
+                        }
+                        if (r.npts >= pr.max_points_num) node_freeze(r);  // voxel_map.cc:199-203
+                        node_store(nd, r);
+                    }
+                } else {
+                    // root with children (or a non-planar max-layer root): per-point state machine
+                    for (; pos < m; ++pos) {
+                        PtU pt;
+                        point_of(__builtin_amdgcn_readlane(sidx, pos), pt);
+                        dev_update_octo(map, pr, root, pt);
+                    }
+                }
+            }
+        } else {
+            // very long list: successive-minimum selection, one point at a time
+            int last = -1;
+            for (int step = 0; step < m; ++step) {
+                int best = 0x7fffffff;
+                for (int j = lane; j < m; j += LK_WAVE) {
+                    int v = map.scratch[base + j];
+                    if (v > last && v < best) best = v;
+                }
+                best = wave_min_i(best);
+                last = best;
+                PtU pt;
+                point_of(best, pt);
+                dev_update_octo(map, pr, root, pt);
+                unsigned int st = (unsigned int)bcast0((int)nd->state);
+                unsigned int pf = (unsigned int)bcast0((int)map.planes[root].flags);
+                if ((st & LK_NODE_INIT_OCTO) && (pf & LK_PLANE_IS_PLANE) && !(st & LK_NODE_UPDATE_ENABLE)) break;
+            }
         }
     }
+}
+
+// Light pre-pass of the insert: ONE THREAD per touched root.  Most touched roots only need their few new points
+// appended — an un-initialised root that stays at <= layer_init_num points, or a plane root that reaches neither
+// its 6th new point (refit, voxel_map.cc:195) nor max_points_num (freeze, :199).  Those are finished here, in input
+// order (8-input sorting network on the list indices); every other root is queued for lk_insert_kernel.
+__device__ __forceinline__ void cswap(int& a, int& b) {
+    int lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo, b = hi;
+}
+__global__ void __launch_bounds__(256)
+    lk_insert_light_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int)map.counters[LK_CTR_TOUCHED]) return;
+    const int root = map.touched[t];
+    lk_node_rec* nd = &map.nodes[root];
+    const int m = (int)nd->pad_[0];
+    const unsigned int st = nd->state, pf = map.planes[root].flags;
+    int npts = nd->npts;
+    const int newp = nd->new_points;
+    bool light = false;
+    if (m <= 8) {
+        if (!(st & LK_NODE_INIT_OCTO))
+            light = (npts + m <= pr.layer_init_num[0]) && (npts + m <= LK_BLOCK_PTS);
+        else if ((pf & LK_PLANE_IS_PLANE) && (st & LK_NODE_UPDATE_ENABLE))
+            light = (newp + m <= 5) && (npts + m < pr.max_points_num);
+    }
+    if (!light) {
+        unsigned int hpos = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
+        map.heavy[hpos] = root;
+        return;
+    }
+    int i0, i1, i2, i3, i4, i5, i6, i7;
+    {
+        const int BIG = 0x7fffffff;
+        int cur = nd->list_head;
+        i0 = (m > 0) ? cur : BIG; cur = (m > 1) ? map.next[cur] : cur;
+        i1 = (m > 1) ? cur : BIG; cur = (m > 2) ? map.next[cur] : cur;
+        i2 = (m > 2) ? cur : BIG; cur = (m > 3) ? map.next[cur] : cur;
+        i3 = (m > 3) ? cur : BIG; cur = (m > 4) ? map.next[cur] : cur;
+        i4 = (m > 4) ? cur : BIG; cur = (m > 5) ? map.next[cur] : cur;
+        i5 = (m > 5) ? cur : BIG; cur = (m > 6) ? map.next[cur] : cur;
+        i6 = (m > 6) ? cur : BIG; cur = (m > 7) ? map.next[cur] : cur;
+        i7 = (m > 7) ? cur : BIG;
+    }
+    // Batcher odd-even merge sort, 8 inputs (19 compare-exchanges): input order = ascending bucket index
+    cswap(i0, i1); cswap(i2, i3); cswap(i4, i5); cswap(i6, i7);
+    cswap(i0, i2); cswap(i1, i3); cswap(i4, i6); cswap(i5, i7);
+    cswap(i1, i2); cswap(i5, i6);
+    cswap(i0, i4); cswap(i1, i5); cswap(i2, i6); cswap(i3, i7);
+    cswap(i2, i4); cswap(i3, i5);
+    cswap(i1, i2); cswap(i3, i4); cswap(i5, i6);
+    nd->list_head = -1;
+    nd->pad_[0] = 0;
+    int block = nd->block;
+    if (block < 0) {
+        unsigned int b = atomicAdd(&map.counters[LK_CTR_BLOCKS], 1u);
+        if (b >= map.max_blocks) {
+            atomicOr(&map.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
+            b = map.max_blocks - 1;
+        }
+        block = (int)b;
+    }
+    BucketConst bc;
+    load_bucket_const(&filters[0], pr, bc);
+#pragma unroll 1
+    for (int k = 0; k < m; ++k) {
+        const int idx = (k == 0) ? i0 : (k == 1) ? i1 : (k == 2) ? i2 : (k == 3) ? i3 : (k == 4) ? i4 : (k == 5) ? i5 : (k == 6) ? i6 : i7;
+        const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+        const PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
+        lk_pt_rec* dst = &map.blocks[block].pts[npts];
+        dst->pw[0] = g.p_w.x, dst->pw[1] = g.p_w.y, dst->pw[2] = g.p_w.z;
+        dst->var[0] = g.var.xx, dst->var[1] = g.var.xy, dst->var[2] = g.var.xz;
+        dst->var[3] = g.var.yy, dst->var[4] = g.var.yz, dst->var[5] = g.var.zz;
+        ++npts;
+    }
+    nd->npts = npts;
+    nd->new_points = newp + m;
+    nd->block = block;
 }
 
 // hashing half of UpdateVoxelMap for caller-supplied pointWithVar records

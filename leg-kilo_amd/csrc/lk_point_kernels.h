@@ -411,10 +411,33 @@ __global__ void __launch_bounds__(LK_PB)
     key_floor(g.p_w, pr.voxel_size_f, key);
     int root = root_find_or_create(map, pr, key);
     if (root < 0) return;
-    // a frozen plane root ignores every further point (voxel_map.cc:191-204): skip the list entirely
-    unsigned int st = map.nodes[root].state;
-    unsigned int pf = map.planes[root].flags;
-    if ((st & LK_NODE_INIT_OCTO) && (pf & LK_PLANE_IS_PLANE) && !(st & LK_NODE_UPDATE_ENABLE)) return;
+    // Drop points that UpdateOctoTree would ignore (voxel_map.cc:185-241), per point and in parallel: walk down from
+    // the root while the node is an initialised NON-plane below max_layer (such nodes are never refitted, so they
+    // stay what they are), and skip the point if the node it ends in is frozen — a plane, or a max-layer leaf, whose
+    // update_enable_ is already false (frozen is permanent).  Anything else (un-initialised node, live leaf, a child
+    // that does not exist yet) is queued for the ordered per-root replay.
+    {
+        int node = root;
+        bool ignore = false;
+        for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
+            const lk_node_rec* nr = &map.nodes[node];
+            const unsigned int st = nr->state;
+            const unsigned int pf = map.planes[node].flags;
+            if (!(st & LK_NODE_INIT_OCTO)) break;
+            const bool is_plane = (pf & LK_PLANE_IS_PLANE) != 0;
+            const int layer = nr->layer;
+            if (is_plane || layer >= pr.max_layer) {
+                ignore = !(st & LK_NODE_UPDATE_ENABLE);
+                break;
+            }
+            const int oct = ((g.p_w.x > nr->voxel_center[0]) ? 4 : 0) + ((g.p_w.y > nr->voxel_center[1]) ? 2 : 0) +
+                            ((g.p_w.z > nr->voxel_center[2]) ? 1 : 0);
+            const int child = nr->child[oct];
+            if (child < 0) break;
+            node = child;
+        }
+        if (ignore) return;
+    }
     int old = atomicExch(&map.nodes[root].list_head, i);
     map.next[i] = old;
     atomicAdd(&map.nodes[root].pad_[0], 1u);
