@@ -18,9 +18,7 @@
 
 #include "../../include/legkilo_hip.h"
 
-#ifndef LK_OPT_RECIP
-#define LK_OPT_RECIP 0
-#endif
+// build-time knobs kept for A/B runs (tools/ab.sh); both measured neutral on MI355X
 #ifndef LK_OPT_SLIM
 #define LK_OPT_SLIM 0
 #endif
