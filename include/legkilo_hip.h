@@ -247,6 +247,18 @@ int lk_process_scan(lk_handle* h, const lk_point* sorted_pts, size_t n, double t
 int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_begin, const uint32_t* bucket_off,
                         const double* bucket_dt, size_t n_buckets, lk_pose* out);
 
+/* ---- the two steps in front of the path, device-resident ----
+ * pcl::VoxelGrid centroid filter as used at KILO.cc:356-360 (leaf = yaml voxel_grid_resolution; centroid of x, y, z
+ * AND curvature) followed by the time sort of KILO.cc:369-370 (stable).  Cells are emitted in ascending cell index,
+ * points of a cell are summed in input order in float32 (PCL leaves both undefined; oracle/preprocess_oracle.py).
+ * out_sorted must hold n_raw points; *n_out receives the number of cells. */
+int lk_preprocess_scan(lk_handle* h, const lk_point* raw, size_t n_raw, float leaf, lk_point* out_sorted, size_t* n_out);
+int lk_preprocess_scan_dev(lk_handle* h, const lk_point* d_raw, size_t n_raw, float leaf, lk_point* d_out_sorted, size_t* n_out);
+/* raw scan -> pose without the cloud leaving HBM: lk_preprocess_scan_dev + the bucket loop of lk_process_scan
+ * (only the n_out x 16 B sorted cloud is read back, for the bucket bounds and the IMU interleave). */
+int lk_process_raw_scan(lk_handle* h, const lk_point* raw, size_t n_raw, float leaf, double t_begin, const lk_imu* imus,
+                        size_t n_imu, const lk_kin_imu* kins, size_t n_kin, size_t* n_down, lk_pose* out);
+
 /* ---- batch replay (config 5): scans are independent units against the handle's FROZEN map ----
  * scan s uses filter slot s (n_scans <= n_slots); all scans have n_pts points laid out
  * d_pts[s * n_pts + i]; bucket bounds are shared by all scans.  Inserts are disabled. */

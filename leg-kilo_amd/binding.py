@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_batch_set_priors", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -232,6 +232,32 @@ class LegKiloHip:
         self._chk(self.L.lk_process_scan_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n), C.c_double(t_begin), _p(off), _p(dt),
                                              C.c_size_t(len(dt)), C.byref(pose)))
         return pose
+
+    # ---- preprocessing in front of the path ----
+    def preprocess_scan(self, raw_pts, leaf):
+        raw = np.ascontiguousarray(raw_pts)
+        out = np.zeros(len(raw), dtype=raw.dtype)
+        n_out = C.c_size_t(0)
+        self._chk(self.L.lk_preprocess_scan(self.h, _p(raw), C.c_size_t(len(raw)), C.c_float(leaf), _p(out), C.byref(n_out)))
+        return out[: n_out.value]
+
+    def preprocess_scan_dev(self, d_raw, n_raw, leaf, d_out):
+        n_out = C.c_size_t(0)
+        self._chk(self.L.lk_preprocess_scan_dev(self.h, C.c_void_p(d_raw), C.c_size_t(n_raw), C.c_float(leaf), C.c_void_p(d_out),
+                                                C.byref(n_out)))
+        return n_out.value
+
+    def process_raw_scan(self, raw_pts, leaf, t_begin, imus=None, kins=None):
+        raw = np.ascontiguousarray(raw_pts)
+        ni = 0 if imus is None else len(imus)
+        nk = 0 if kins is None else len(kins)
+        imus = None if imus is None else np.ascontiguousarray(imus)
+        kins = None if kins is None else np.ascontiguousarray(kins)
+        pose = abi.lk_pose()
+        nd = C.c_size_t(0)
+        self._chk(self.L.lk_process_raw_scan(self.h, _p(raw), C.c_size_t(len(raw)), C.c_float(leaf), C.c_double(t_begin), _p(imus),
+                                             C.c_size_t(ni), _p(kins), C.c_size_t(nk), C.byref(nd), C.byref(pose)))
+        return pose, nd.value
 
     # ---- batch replay ----
     def batch_set_priors(self, x36, P900):

@@ -18,6 +18,7 @@
 #include "lk_filter_kernels.h"
 #include "lk_point_kernels.h"
 #include "lk_map_kernels.h"
+#include "lk_pre_kernels.h"
 
 static_assert(sizeof(lk_plane_rec) == 256, "plane record must be 256 B");
 static_assert(sizeof(lk_node_rec) == 128, "node record must be 128 B");
@@ -46,6 +47,12 @@ struct lk_handle {
     double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
     lk_pose* d_poses = nullptr;
     double acc_norm = 1.0;
+    // grow-only scratch of lk_preprocess_scan
+    size_t pre_cap = 0, pre_tmp_bytes = 0;
+    lk_point *pre_raw = nullptr, *pre_cells = nullptr, *pre_out = nullptr;
+    unsigned int *pre_k0 = nullptr, *pre_k1 = nullptr, *pre_flags = nullptr, *pre_pos = nullptr, *pre_misc = nullptr;
+    int *pre_v0 = nullptr, *pre_v1 = nullptr, *pre_starts = nullptr;
+    void* pre_tmp = nullptr;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfEntry> prof;
@@ -213,6 +220,10 @@ void lk_destroy(lk_handle* h) {
                     h->map.next, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
+        if (p) hipFree(p);
+    void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
+                   h->pre_v0, h->pre_v1, h->pre_starts, h->pre_tmp};
+    for (void* p : pre)
         if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -773,6 +784,11 @@ int lk_update_kin_imu(lk_handle* h, const lk_kin_imu* kin) {
     return LK_OK;
 }
 
+// bucket loop of KILO::process (KILO.cc:375-395); pts = host copy of the sorted cloud (bucket bounds, IMU interleave),
+// d_pts = the same cloud in HBM
+static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n, double t_begin, const lk_imu* imus,
+                    size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out);
+
 int lk_process_scan(lk_handle* h, const lk_point* pts, size_t n, double t_begin, const lk_imu* imus, size_t n_imu,
                     const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out) {
     CHECK_H(h);
@@ -780,6 +796,11 @@ int lk_process_scan(lk_handle* h, const lk_point* pts, size_t n, double t_begin,
     if (n_imu && n_kin) return fail(h, LK_ERR_INVALID, "pass either IMU or kin+IMU messages, not both");
     if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
     HIPCHK(h, hipMemcpyAsync(h->d_scan, pts, sizeof(lk_point) * n, hipMemcpyHostToDevice, h->stream));
+    return run_scan(h, pts, h->d_scan, n, t_begin, imus, n_imu, kins, n_kin, xyz_world_out, out);
+}
+
+static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n, double t_begin, const lk_imu* imus,
+                    size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out) {
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
     size_t qi = 0, qk = 0;
@@ -796,7 +817,7 @@ int lk_process_scan(lk_handle* h, const lk_point* pts, size_t n, double t_begin,
             if ((rc = enqueue_kin(h, &kins[qk]))) return rc;
             ++qk;
         }
-        rc = enqueue_bucket(h, h->d_scan + idx_i, (int)(idx_j - idx_i), cur_point_time,
+        rc = enqueue_bucket(h, d_pts + idx_i, (int)(idx_j - idx_i), cur_point_time,
                             xyz_world_out ? h->d_world + 4 * idx_i : nullptr, true);
         if (rc) return rc;
         idx_i = idx_j;
@@ -838,6 +859,107 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     if (rc) return rc;
     if (out) *out = pose;
     return LK_OK;
+}
+
+// ------------------------------------------------------------------ voxel-grid centroid filter + time sort
+static int pre_reserve(lk_handle* h, size_t n) {
+    if (n <= h->pre_cap) return LK_OK;
+    void** ptrs[] = {(void**)&h->pre_raw, (void**)&h->pre_cells, (void**)&h->pre_out, (void**)&h->pre_k0, (void**)&h->pre_k1,
+                     (void**)&h->pre_flags, (void**)&h->pre_pos, (void**)&h->pre_misc, (void**)&h->pre_v0, (void**)&h->pre_v1,
+                     (void**)&h->pre_starts, (void**)&h->pre_tmp};
+    for (void** p : ptrs)
+        if (*p) hipFree(*p), *p = nullptr;
+    size_t cap = n + n / 4 + 1024;
+    HIPCHK(h, hipMalloc(&h->pre_raw, sizeof(lk_point) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_cells, sizeof(lk_point) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_out, sizeof(lk_point) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_k0, sizeof(unsigned int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_k1, sizeof(unsigned int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_flags, sizeof(unsigned int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_pos, sizeof(unsigned int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_misc, sizeof(unsigned int) * 16));
+    HIPCHK(h, hipMalloc(&h->pre_v0, sizeof(int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_v1, sizeof(int) * cap));
+    HIPCHK(h, hipMalloc(&h->pre_starts, sizeof(int) * cap));
+    size_t t1 = 0, t2 = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, t1, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, cap, 0, 32, h->stream));
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, t2, h->pre_flags, h->pre_pos, 0u, cap, rocprim::plus<unsigned int>(), h->stream));
+    h->pre_tmp_bytes = std::max(t1, t2);
+    HIPCHK(h, hipMalloc(&h->pre_tmp, h->pre_tmp_bytes));
+    h->pre_cap = cap;
+    return LK_OK;
+}
+
+int lk_preprocess_scan_dev(lk_handle* h, const lk_point* d_raw, size_t n_raw, float leaf, lk_point* d_out, size_t* n_out) {
+    CHECK_H(h);
+    if (!d_raw || !d_out || !n_out || n_raw == 0 || !(leaf > 0.f)) return fail(h, LK_ERR_INVALID, "lk_preprocess_scan: bad argument");
+    if (n_raw > 0x7fffffffu) return fail(h, LK_ERR_INVALID, "too many points");
+    int rc = pre_reserve(h, n_raw);
+    if (rc) return rc;
+    const int n = (int)n_raw;
+    const int nb = (n + 255) / 256;
+    const float inv = 1.0f / leaf;  // inverse_leaf_size_, float as in PCL
+    int* mm = reinterpret_cast<int*>(h->pre_misc);
+    const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    unsigned int* err = h->pre_misc + 6;
+    unsigned int* ncells_d = h->pre_misc + 7;
+    LAUNCH(h, "pre_minmax", hipLaunchKernelGGL(lk_pre_minmax_kernel, dim3(std::min(nb, 1024)), dim3(256), 0, h->stream, d_raw, n, mm));
+    LAUNCH(h, "pre_cellidx", hipLaunchKernelGGL(lk_pre_cellidx_kernel, dim3(nb), dim3(256), 0, h->stream, d_raw, n, inv, mm, h->pre_k0,
+                                                h->pre_v0, err));
+    size_t tb = h->pre_tmp_bytes;
+    HIPCHK(h, rocprim::radix_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, n_raw, 0, 32, h->stream));
+    LAUNCH(h, "pre_heads", hipLaunchKernelGGL(lk_pre_heads_kernel, dim3(nb), dim3(256), 0, h->stream, h->pre_k1, n, h->pre_flags));
+    tb = h->pre_tmp_bytes;
+    HIPCHK(h, rocprim::exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, 0u, n_raw, rocprim::plus<unsigned int>(), h->stream));
+    LAUNCH(h, "pre_starts", hipLaunchKernelGGL(lk_pre_starts_kernel, dim3(nb), dim3(256), 0, h->stream, h->pre_flags, h->pre_pos, n,
+                                               h->pre_starts, ncells_d));
+    LAUNCH(h, "pre_centroid", hipLaunchKernelGGL(lk_pre_centroid_kernel, dim3(nb), dim3(256), 0, h->stream, d_raw, h->pre_v1,
+                                                 h->pre_starts, ncells_d, n, h->pre_cells, h->pre_k0, h->pre_v0));
+    unsigned int host_misc[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(host_misc, err, sizeof(host_misc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (host_misc[0]) return fail(h, LK_ERR_INVALID, "voxel grid leaf too small for the cloud extent (index overflow)");
+    const size_t nc = host_misc[1];
+    tb = h->pre_tmp_bytes;
+    HIPCHK(h, rocprim::radix_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, nc, 0, 32, h->stream));
+    LAUNCH(h, "pre_gather", hipLaunchKernelGGL(lk_pre_gather_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream,
+                                               h->pre_cells, h->pre_v1, (int)nc, d_out));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_out = nc;
+    return LK_OK;
+}
+
+int lk_preprocess_scan(lk_handle* h, const lk_point* raw, size_t n_raw, float leaf, lk_point* out_sorted, size_t* n_out) {
+    CHECK_H(h);
+    if (!raw || !out_sorted || n_raw == 0) return fail(h, LK_ERR_INVALID, "lk_preprocess_scan: bad argument");
+    int rc = pre_reserve(h, n_raw);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->pre_raw, raw, sizeof(lk_point) * n_raw, hipMemcpyHostToDevice, h->stream));
+    rc = lk_preprocess_scan_dev(h, h->pre_raw, n_raw, leaf, h->pre_out, n_out);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out_sorted, h->pre_out, sizeof(lk_point) * (*n_out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+int lk_process_raw_scan(lk_handle* h, const lk_point* raw, size_t n_raw, float leaf, double t_begin, const lk_imu* imus,
+                        size_t n_imu, const lk_kin_imu* kins, size_t n_kin, size_t* n_down, lk_pose* out) {
+    CHECK_H(h);
+    if (!raw || n_raw == 0) return fail(h, LK_ERR_INVALID, "empty scan");
+    if (n_imu && n_kin) return fail(h, LK_ERR_INVALID, "pass either IMU or kin+IMU messages, not both");
+    int rc = pre_reserve(h, n_raw);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->pre_raw, raw, sizeof(lk_point) * n_raw, hipMemcpyHostToDevice, h->stream));
+    size_t nd = 0;
+    rc = lk_preprocess_scan_dev(h, h->pre_raw, n_raw, leaf, h->pre_out, &nd);
+    if (rc) return rc;
+    if (nd > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "downsampled scan exceeds max_scan_points");
+    std::vector<lk_point> sorted(nd);
+    HIPCHK(h, hipMemcpyAsync(sorted.data(), h->pre_out, sizeof(lk_point) * nd, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_down) *n_down = nd;
+    return run_scan(h, sorted.data(), h->pre_out, nd, t_begin, imus, n_imu, kins, n_kin, nullptr, out);
 }
 
 // ------------------------------------------------------------------ batch replay against the frozen map

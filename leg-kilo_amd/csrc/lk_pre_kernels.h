@@ -1,0 +1,103 @@
+// lk_pre_kernels.h — the two steps that feed the path, kept on the device so that a raw scan
+// never returns to the host between decode and the ESKF update:
+//   pcl::VoxelGrid centroid filter as used at KILO.cc:356-360  -> cell index, stable radix sort by cell, one thread
+//       per cell sums its points sequentially in input order in float32 (all four fields incl. curvature)
+//   std::sort by curvature at KILO.cc:369-370                   -> stable radix sort on the order-preserving bit image
+// Definition (PCL leaves the order inside a cell and the output order undefined): oracle/preprocess_oracle.py.
+// HBM-bound streaming kernels: one lk_point (16 B, float4) per lane, coalesced.
+#pragma once
+#include "lk_device.h"
+
+__device__ __forceinline__ int lk_f2ord(float f) {
+    int i = __float_as_int(f);
+    return i >= 0 ? i : (i ^ 0x7fffffff);
+}
+__device__ __forceinline__ float lk_ord2f(int i) { return __int_as_float(i >= 0 ? i : (i ^ 0x7fffffff)); }
+
+// mm[0..2] = min x,y,z ; mm[3..5] = max x,y,z   (order-preserving int image; init: INT_MAX / INT_MIN)
+__global__ void __launch_bounds__(256) lk_pre_minmax_kernel(const lk_point* __restrict__ pts, int n, int* mm) {
+    __shared__ int smin[3][4], smax[3][4];
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = reinterpret_cast<const float4*>(pts)[i];
+        const int v[3] = {lk_f2ord(p.x), lk_f2ord(p.y), lk_f2ord(p.z)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lo[c] = min(lo[c], v[c]), hi[c] = max(hi[c], v[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = min(lo[c], __shfl_xor(lo[c], o, LK_WAVE));
+            hi[c] = max(hi[c], __shfl_xor(hi[c], o, LK_WAVE));
+        }
+        if ((threadIdx.x & 63) == 0) smin[c][threadIdx.x >> 6] = lo[c], smax[c][threadIdx.x >> 6] = hi[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        atomicMin(&mm[c], min(min(smin[c][0], smin[c][1]), min(smin[c][2], smin[c][3])));
+        atomicMax(&mm[3 + c], max(max(smax[c][0], smax[c][1]), max(smax[c][2], smax[c][3])));
+    }
+}
+
+// cell index idx = ijk0 + ijk1*div0 + ijk2*div0*div1 with ijk = floor(p * inv) - min_b (float arithmetic)
+__global__ void __launch_bounds__(256)
+    lk_pre_cellidx_kernel(const lk_point* __restrict__ pts, int n, float inv, const int* __restrict__ mm,
+                          unsigned int* __restrict__ keys, int* __restrict__ vals, unsigned int* err) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int mn[3], dv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = (int)floorf(lk_ord2f(mm[c]) * inv);
+        dv[c] = (int)floorf(lk_ord2f(mm[3 + c]) * inv) - mn[c] + 1;
+    }
+    if (i == 0 && (double)dv[0] * (double)dv[1] * (double)dv[2] > 2147483647.0) atomicOr(err, 1u);  // PCL refuses this too
+    const float4 p = reinterpret_cast<const float4*>(pts)[i];
+    const int i0 = (int)floorf(p.x * inv) - mn[0], i1 = (int)floorf(p.y * inv) - mn[1], i2 = (int)floorf(p.z * inv) - mn[2];
+    keys[i] = (unsigned int)(i0 + i1 * dv[0] + i2 * dv[0] * dv[1]);
+    vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256) lk_pre_heads_kernel(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+    lk_pre_starts_kernel(const unsigned int* __restrict__ flags, const unsigned int* __restrict__ pos, int n, int* __restrict__ starts,
+                         unsigned int* __restrict__ ncells) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) starts[pos[i]] = i;
+    if (i == n - 1) *ncells = pos[i] + flags[i];
+}
+
+// one thread per cell: sequential float32 sums in input order (vals are stably sorted by cell), centroid, time key
+__global__ void __launch_bounds__(256)
+    lk_pre_centroid_kernel(const lk_point* __restrict__ pts, const int* __restrict__ vals, const int* __restrict__ starts,
+                           const unsigned int* __restrict__ ncells_p, int n, lk_point* __restrict__ cells,
+                           unsigned int* __restrict__ tkeys, int* __restrict__ tvals) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ncells = (int)*ncells_p;
+    if (c >= ncells) return;
+    const int b = starts[c], e = (c + 1 < ncells) ? starts[c + 1] : n;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+    for (int k = b; k < e; ++k) {
+        const float4 p = reinterpret_cast<const float4*>(pts)[vals[k]];
+        sx = sx + p.x, sy = sy + p.y, sz = sz + p.z, sc = sc + p.w;
+    }
+    const float cnt = (float)(e - b);
+    const float4 o = make_float4(sx / cnt, sy / cnt, sz / cnt, sc / cnt);
+    reinterpret_cast<float4*>(cells)[c] = o;
+    unsigned int u = __float_as_uint(o.w);
+    tkeys[c] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving image of the float time stamp
+    tvals[c] = c;
+}
+
+__global__ void __launch_bounds__(256)
+    lk_pre_gather_kernel(const lk_point* __restrict__ cells, const int* __restrict__ order, int n, lk_point* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(cells)[order[i]];
+}

@@ -215,25 +215,30 @@ def preprocess_velodyne(raw, filter_num=3, blind=1.5):
 
 
 def voxel_grid_centroid(pts, leaf):
-    """Centroid of all fields (x, y, z, curvature) per leaf cell — the behaviour of pcl::VoxelGrid
-    that the reference relies on at KILO.cc:356-360 (it de-quantises the time stamps).  Output
-    order (unpinned in PCL): ascending cell index, x fastest."""
-    xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float64)
-    inv = 1.0 / leaf
-    mn = np.floor(xyz.min(0) * inv).astype(np.int64)
-    mx = np.floor(xyz.max(0) * inv).astype(np.int64)
+    """Centroid of all fields (x, y, z, curvature) per leaf cell — the behaviour of pcl::VoxelGrid that the
+    reference relies on at KILO.cc:356-360 (it de-quantises the time stamps).  Host definition of what
+    lk_preprocess_scan computes on the device: float32 cell index floor(p * (1/leaf)) - min, cells in ascending
+    index (x fastest), points of a cell summed sequentially in input order in float32."""
+    x = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
+    inv = np.float32(1.0) / np.float32(leaf)
+    mn = np.floor(x.min(0) * inv).astype(np.int64)
+    mx = np.floor(x.max(0) * inv).astype(np.int64)
     div = mx - mn + 1
-    ijk = np.floor(xyz * inv).astype(np.int64) - mn
+    ijk = np.floor(x * inv).astype(np.int64) - mn
     idx = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
     order = np.argsort(idx, kind="stable")
     idx_s = idx[order]
     starts = np.flatnonzero(np.r_[True, idx_s[1:] != idx_s[:-1]])
     cnt = np.diff(np.r_[starts, len(idx_s)])
     out = np.zeros(len(starts), dtype=POINT_DTYPE)
+    kmax = int(cnt.max())
     for name in ("x", "y", "z", "curvature"):
         v = pts[name][order].astype(np.float32)
-        s = np.add.reduceat(v.astype(np.float32), starts).astype(np.float32)
-        out[name] = s / cnt.astype(np.float32)
+        acc = np.zeros(len(starts), dtype=np.float32)
+        for k in range(kmax):
+            m = cnt > k
+            acc[m] = acc[m] + v[starts[m] + k]
+        out[name] = acc / cnt.astype(np.float32)
     return out
 
 
