@@ -190,6 +190,7 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMalloc(&m.touched, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.heavy, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.slots, sizeof(int) * (size_t)LK_SLOTS * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
     HIPCHK(h, hipMemsetAsync(h->d_filters, 0, sizeof(LkFilter) * (size_t)cfg->n_slots, h->stream));
@@ -217,7 +218,7 @@ void lk_destroy(lk_handle* h) {
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
-                    h->map.next, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
+                    h->map.next, h->map.slots, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
         if (p) hipFree(p);

@@ -29,6 +29,7 @@
 #define LK_EMPTY (-1)
 #define LK_LOCKED (-2)
 #define LK_MAX_LAYER 4
+#define LK_SLOTS 32  // inline index slots per root voxel (one 128-B line); more points overflow to a linked list
 #define LK_NPART 32  // doubles per block partial: A(21) b(6) sumR(1) count(1) pad
 
 // error bits in LkMap.counters[LK_CTR_ERR]
@@ -109,7 +110,8 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int* touched;                // roots touched by the current bucket
     int* heavy;                  // subset of touched that needs the wave-per-root state machine
     unsigned long long* dbg;     // LK_TIMING builds only: per heavy root {m, cycles, kind, root}
-    int* next;                   // per-point list links (bucket-local index)
+    int* next;                   // per-point list links (bucket-local index): overflow beyond LK_SLOTS
+    int* slots;                  // [max_nodes][LK_SLOTS] bucket-local point indices queued on a root
     int* scratch;                // per-root gathered indices
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;
 };

@@ -440,9 +440,13 @@ __global__ void __launch_bounds__(LK_MB)
             if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
             continue;
         }
-        for (int k = 0; k < m && cur >= 0; ++k) {  // unordered list -> scratch
-            if (lane == 0) map.scratch[base + k] = cur;
-            cur = bcast0(map.next[cur]);
+        {   // unordered indices -> scratch: inline slots with one coalesced read, overflow by walking the list
+            const int ms = min(m, LK_SLOTS);
+            if (lane < ms) map.scratch[base + lane] = map.slots[(size_t)root * LK_SLOTS + lane];
+            for (int k = ms; k < m && cur >= 0; ++k) {
+                if (lane == 0) map.scratch[base + k] = cur;
+                cur = bcast0(map.next[cur]);
+            }
         }
         wave_fence();
         auto point_of = [&](int idx, PtU& pt) {
@@ -568,15 +572,15 @@ __global__ void __launch_bounds__(256)
     int i0, i1, i2, i3, i4, i5, i6, i7;
     {
         const int BIG = 0x7fffffff;
-        int cur = nd->list_head;
-        i0 = (m > 0) ? cur : BIG; cur = (m > 1) ? map.next[cur] : cur;
-        i1 = (m > 1) ? cur : BIG; cur = (m > 2) ? map.next[cur] : cur;
-        i2 = (m > 2) ? cur : BIG; cur = (m > 3) ? map.next[cur] : cur;
-        i3 = (m > 3) ? cur : BIG; cur = (m > 4) ? map.next[cur] : cur;
-        i4 = (m > 4) ? cur : BIG; cur = (m > 5) ? map.next[cur] : cur;
-        i5 = (m > 5) ? cur : BIG; cur = (m > 6) ? map.next[cur] : cur;
-        i6 = (m > 6) ? cur : BIG; cur = (m > 7) ? map.next[cur] : cur;
-        i7 = (m > 7) ? cur : BIG;
+        const int* sl = &map.slots[(size_t)root * LK_SLOTS];  // m <= 8 < LK_SLOTS: everything is in the slot line
+        i0 = (m > 0) ? sl[0] : BIG;
+        i1 = (m > 1) ? sl[1] : BIG;
+        i2 = (m > 2) ? sl[2] : BIG;
+        i3 = (m > 3) ? sl[3] : BIG;
+        i4 = (m > 4) ? sl[4] : BIG;
+        i5 = (m > 5) ? sl[5] : BIG;
+        i6 = (m > 6) ? sl[6] : BIG;
+        i7 = (m > 7) ? sl[7] : BIG;
     }
     // Batcher odd-even merge sort, 8 inputs (19 compare-exchanges): input order = ascending bucket index
     cswap(i0, i1); cswap(i2, i3); cswap(i4, i5); cswap(i6, i7);
@@ -622,13 +626,7 @@ __global__ void __launch_bounds__(256) lk_queue_pv_kernel(LkMap map, LkParams pr
     key_floor(V3{pv[i].pw[0], pv[i].pw[1], pv[i].pw[2]}, pr.voxel_size_f, key);
     int root = root_find_or_create(map, pr, key);
     if (root < 0) return;
-    int old = atomicExch(&map.nodes[root].list_head, i);
-    map.next[i] = old;
-    atomicAdd(&map.nodes[root].pad_[0], 1u);
-    if (old == -1) {
-        unsigned int t = atomicAdd(&map.counters[LK_CTR_TOUCHED], 1u);
-        map.touched[t] = root;
-    }
+    queue_point_on_root(map, root, i);
 }
 
 // ------------------------------------------------------------------ first-frame build (voxel_map.cc:287-334)

@@ -392,6 +392,22 @@ __device__ __forceinline__ int root_find_or_create(const LkMap& m, const LkParam
     return -1;
 }
 
+// Queue bucket-local point i on its root voxel: the first LK_SLOTS points of a root go to its inline slot line (so
+// the per-root kernels read all indices with one coalesced load), later ones to a linked list; the first arrival
+// registers the root in the touched list.  Arrival order is arbitrary: the consumers sort by index.
+__device__ __forceinline__ void queue_point_on_root(const LkMap& map, int root, int i) {
+    const unsigned int k = atomicAdd(&map.nodes[root].pad_[0], 1u);
+    if (k < (unsigned int)LK_SLOTS) {
+        map.slots[(size_t)root * LK_SLOTS + k] = i;
+    } else {
+        map.next[i] = atomicExch(&map.nodes[root].list_head, i);
+    }
+    if (k == 0) {
+        unsigned int t = atomicAdd(&map.counters[LK_CTR_TOUCHED], 1u);
+        map.touched[t] = root;
+    }
+}
+
 // KILO.cc:216-230 + voxel_map.cc:343-358 (hash half).  pts are the bucket's points (bucket-local i).
 __global__ void __launch_bounds__(LK_PB)
     lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
@@ -438,11 +454,5 @@ __global__ void __launch_bounds__(LK_PB)
         }
         if (ignore) return;
     }
-    int old = atomicExch(&map.nodes[root].list_head, i);
-    map.next[i] = old;
-    atomicAdd(&map.nodes[root].pad_[0], 1u);
-    if (old == -1) {
-        unsigned int t = atomicAdd(&map.counters[LK_CTR_TOUCHED], 1u);
-        map.touched[t] = root;
-    }
+    queue_point_on_root(map, root, i);
 }
