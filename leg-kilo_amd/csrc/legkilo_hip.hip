@@ -399,7 +399,9 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     if (do_insert) {
         LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
                                                      h->d_filters, d_pts, n));
-        int grid = std::min(std::max((n + 3) / 4, 1), 4096);
+        // 1 wave per root, 1 resident wave per SIMD (255 VGPRs): 256 blocks x 4 waves is exactly one resident round on
+        // 256 CUs; more blocks would only be empty waves queueing for dispatch (the loop inside is grid-stride)
+        int grid = std::min(std::max((n + 3) / 4, 1), 256);
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
 #ifdef LK_TIMING
@@ -484,7 +486,7 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     HIPCHK(h, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
     LAUNCH(h, "build_segments",
            hipLaunchKernelGGL(lk_build_segments_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, d_k1, (int)n));
-    int grid = std::min(std::max((int)((n + 3) / 4), 1), 4096);
+    int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
     LAUNCH(h, "build_tree", hipLaunchKernelGGL(lk_build_tree_kernel, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                d_bpts, d_i1, d_i0));
     int rc = check_map_errors(h);
@@ -508,7 +510,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
-    int grid = std::min(std::max((int)((n + 3) / 4), 1), 4096);
+    int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
     LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                               h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     int rc = check_map_errors(h);

@@ -202,6 +202,139 @@ __device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, lk_match_rec* mr, 
     return is_plane;
 }
 
+// ---- register-resident plane fit (one point per lane, count <= 64): the same formulas, in the same order, as
+// dev_init_plane, split into the cheap test (centroid, scatter, eigen-decomposition -> is_plane) and the expensive
+// plane_var accumulation, so that a chain of refit events inside one bucket costs one full fit, not one per event.
+struct PlaneFit {
+    bool is_plane;
+    double c[3];
+    double emin, emid, emax;
+    double vmin[3], vmid[3], vmax[3];
+};
+// decide_only: just is_plane = (lambda_min < threshold), decided WITHOUT an eigen-decomposition: lambda_min >= t  <=>
+// cov - t I is positive semi-definite, and it is positive definite iff its three leading principal minors are > 0
+// (Sylvester).  Used for the refit events in the middle of a bucket, whose eigenvectors nobody ever reads; differs
+// from the Jacobi decision only when lambda_min equals the threshold to rounding.
+template <bool decide_only = false>
+__device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool active, int count, float planer_threshold) {
+    double s[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = 0.0;
+    if (active) {
+        s[0] += pw[0], s[1] += pw[1], s[2] += pw[2];
+        s[3] += pw[0] * pw[0], s[4] += pw[0] * pw[1], s[5] += pw[0] * pw[2];
+        s[6] += pw[1] * pw[1], s[7] += pw[1] * pw[2], s[8] += pw[2] * pw[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = wave_sum(s[q]);
+    const double n = (double)count;
+    PlaneFit f;
+    f.c[0] = s[0] / n, f.c[1] = s[1] / n, f.c[2] = s[2] / n;
+    double cov[6] = {s[3] / n - f.c[0] * f.c[0], s[4] / n - f.c[0] * f.c[1], s[5] / n - f.c[0] * f.c[2],
+                     s[6] / n - f.c[1] * f.c[1], s[7] / n - f.c[1] * f.c[2], s[8] / n - f.c[2] * f.c[2]};
+    if (decide_only) {
+        const double t = (double)planer_threshold;
+        const double b11 = cov[0] - t, b22 = cov[3] - t, b33 = cov[5] - t, bxy = cov[1], bxz = cov[2], byz = cov[4];
+        const double m2 = b11 * b22 - bxy * bxy;
+        const double m3 = b11 * (b22 * b33 - byz * byz) - bxy * (bxy * b33 - byz * bxz) + bxz * (bxy * byz - b22 * bxz);
+        f.is_plane = !(b11 > 0.0 && m2 > 0.0 && m3 > 0.0);
+        f.emin = f.emid = f.emax = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f.vmin[k] = f.vmid[k] = f.vmax[k] = 0.0;
+        return f;
+    }
+    double ev[3], V[9];
+    eig_sym3_dev(cov, ev, V);
+    int imin = 0, imax = 0;
+    for (int k = 1; k < 3; ++k) {
+        if (ev[k] < ev[imin]) imin = k;
+        if (ev[k] > ev[imax]) imax = k;
+    }
+    int imid = 3 - imin - imax;
+    if (imid > 2) imid = imin;
+    auto col = [&](int k, double* o) {
+        o[0] = (k == 0) ? V[0] : (k == 1) ? V[1] : V[2];
+        o[1] = (k == 0) ? V[3] : (k == 1) ? V[4] : V[5];
+        o[2] = (k == 0) ? V[6] : (k == 1) ? V[7] : V[8];
+    };
+    auto evk = [&](int k) { return (k == 0) ? ev[0] : (k == 1) ? ev[1] : ev[2]; };
+    col(imin, f.vmin), col(imid, f.vmid), col(imax, f.vmax);
+    f.emin = evk(imin), f.emid = evk(imid), f.emax = evk(imax);
+    f.is_plane = f.emin < (double)planer_threshold;
+    return f;
+}
+// plane_var = sum_i J_i var_i J_i^T over the active lanes (voxel_map.cc:76-95), 21 unique terms, wave-reduced
+__device__ __forceinline__ void plane_var_regs(const PlaneFit& f, const double* pw, const double* var, bool active, int count,
+                                               double* acc) {
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[q] = 0.0;
+    double rhsA[9], rhsB[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            rhsA[3 * r + cc] = f.vmid[r] * f.vmin[cc] + f.vmin[r] * f.vmid[cc];
+            rhsB[3 * r + cc] = f.vmax[r] * f.vmin[cc] + f.vmin[r] * f.vmax[cc];
+        }
+    const double denA = count * (f.emin - f.emid), denB = count * (f.emin - f.emax);
+    const double invn = 1.0 / count;
+    if (active) {
+        double q[3] = {pw[0] - f.c[0], pw[1] - f.c[1], pw[2] - f.c[2]};
+        double la[3] = {q[0] / denA, q[1] / denA, q[2] / denA};
+        double lb[3] = {q[0] / denB, q[1] / denB, q[2] / denB};
+        double FA[3], FB[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            FA[cc] = la[0] * rhsA[cc] + la[1] * rhsA[3 + cc] + la[2] * rhsA[6 + cc];
+            FB[cc] = lb[0] * rhsB[cc] + lb[1] * rhsB[3 + cc] + lb[2] * rhsB[6 + cc];
+        }
+        double J[6][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                J[r][cc] = f.vmid[r] * FA[cc] + f.vmax[r] * FB[cc];
+                J[3 + r][cc] = (r == cc) ? invn : 0.0;
+            }
+        double Sv[3][3] = {{var[0], var[1], var[2]}, {var[1], var[3], var[4]}, {var[2], var[4], var[5]}};
+        double JV[6][3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) JV[r][cc] = J[r][0] * Sv[0][cc] + J[r][1] * Sv[1][cc] + J[r][2] * Sv[2][cc];
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = r; cc < 6; ++cc) acc[k++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
+    }
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[q] = wave_sum(acc[q]);
+}
+// lane 0 writes the plane (and its compact match copy) exactly like the tail of dev_init_plane
+__device__ __forceinline__ void plane_commit(lk_plane_rec* pl, lk_match_rec* mr, const PlaneFit& f, const double* acc, int count) {
+    if ((threadIdx.x & 63) == 0) {
+        pl->points_size = count;
+        if (f.is_plane) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pl->center[k] = f.c[k], pl->normal[k] = f.vmin[k];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) pl->plane_var[q] = acc[q];
+            pl->min_eigen_value = (float)f.emin;
+            pl->mid_eigen_value = (float)f.emid;
+            pl->max_eigen_value = (float)f.emax;
+            pl->radius = (float)sqrt(f.emax);
+            pl->d = (float)(-(f.vmin[0] * f.c[0] + f.vmin[1] * f.c[1] + f.vmin[2] * f.c[2]));
+            pl->flags = LK_PLANE_IS_PLANE | LK_PLANE_IS_INIT;
+            lk_derive_match(pl, mr);
+        } else {
+            pl->flags = pl->flags & ~LK_PLANE_IS_PLANE;
+            mr->flags = pl->flags;
+        }
+    }
+    wave_fence();
+}
+
 // ---- node helpers (wave-uniform; lane 0 writes)
 __device__ __forceinline__ int alloc_block(const LkMap& m) {
     int id = -1;
@@ -428,27 +561,30 @@ __global__ void __launch_bounds__(LK_MB)
             __device__ ~DbgAtExit() { if (lane == 0 && p) { p[0] = (unsigned long long)m; p[1] = __builtin_readcyclecounter() - t0; p[2] = kind; p[3] = (unsigned long long)root; } }
         } dbg_exit{map.dbg ? map.dbg + 4 * (size_t)t : nullptr, t_begin, m, (st0 & 7u) | ((pf0 & 1u) << 4), root, lane};
 #endif
-        int cur = bcast0(nd->list_head);
         int base = 0;
-        if (lane == 0) {
-            nd->list_head = -1;
-            nd->pad_[0] = 0;
-            base = (int)atomicAdd(&map.counters[LK_CTR_SCRATCH], (unsigned int)m);
-        }
-        base = bcast0(base);
-        if (base + m > (int)map.max_scan) {
-            if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
-            continue;
-        }
-        {   // unordered indices -> scratch: inline slots with one coalesced read, overflow by walking the list
-            const int ms = min(m, LK_SLOTS);
-            if (lane < ms) map.scratch[base + lane] = map.slots[(size_t)root * LK_SLOTS + lane];
-            for (int k = ms; k < m && cur >= 0; ++k) {
+        const bool in_slots = m <= LK_SLOTS;  // the common case: every queued index sits in the root's slot line
+        if (in_slots) {
+            if (lane == 0) nd->pad_[0] = 0;
+        } else {
+            int cur = bcast0(nd->list_head);
+            if (lane == 0) {
+                nd->list_head = -1;
+                nd->pad_[0] = 0;
+                base = (int)atomicAdd(&map.counters[LK_CTR_SCRATCH], (unsigned int)m);
+            }
+            base = bcast0(base);
+            if (base + m > (int)map.max_scan) {
+                if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+                continue;
+            }
+            // unordered indices -> scratch: the slot line with one coalesced read, the overflow by walking the list
+            if (lane < LK_SLOTS) map.scratch[base + lane] = map.slots[(size_t)root * LK_SLOTS + lane];
+            for (int k = LK_SLOTS; k < m && cur >= 0; ++k) {
                 if (lane == 0) map.scratch[base + k] = cur;
                 cur = bcast0(map.next[cur]);
             }
+            wave_fence();
         }
-        wave_fence();
         auto point_of = [&](int idx, PtU& pt) {
             if (FROM_PV) {
                 load_pt(pv, nullptr, idx, pt.pw, pt.var);
@@ -462,59 +598,185 @@ __global__ void __launch_bounds__(LK_MB)
         };
         if (m <= LK_WAVE) {
             // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
-            const int myidx = (lane < m) ? map.scratch[base + lane] : 0x7fffffff;
+            const int myidx = (lane < m) ? (in_slots ? map.slots[(size_t)root * LK_SLOTS + lane] : map.scratch[base + lane]) : 0x7fffffff;
             int rank = 0;
             for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
             const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
-            int pos = 0;
-            while (pos < m) {
-                NodeRegs r = node_load(nd);
-                const bool is_plane = (bcast0((int)map.planes[root].flags) & (int)LK_PLANE_IS_PLANE) != 0;
-                const bool leaf_uninit = !(r.state & LK_NODE_INIT_OCTO);
-                if (leaf_uninit || is_plane) {
-                    // leaf root: append up to the next event in one go (all lanes derive their own point)
-                    if (!leaf_uninit && !(r.state & LK_NODE_UPDATE_ENABLE)) break;  // frozen plane ignores the rest
-                    int k = m - pos;
-                    if (leaf_uninit) {
-                        k = min(k, pr.layer_init_num[0] + 1 - r.npts);               // until size > threshold
-                    } else {
-                        k = min(k, min(6 - r.new_points, pr.max_points_num - r.npts)); // until refit / freeze
+            const bool mine = lane < m;
+            // every lane derives its point once and walks (read-only) to the node the point would be pushed into:
+            // down through initialised non-planar nodes below max_layer (voxel_map.cc:205-223); these never change
+            // again, so the walk is exact for the whole bucket.  tnode < 0: child `toct` of `tparent` does not exist.
+            PtU mypt;
+            int tnode = -1, tparent = -1, toct = 0;
+            if (mine) {
+                point_of(sidx, mypt);
+                int node = root;
+                for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
+                    const lk_node_rec* nr = &map.nodes[node];
+                    const unsigned int st = nr->state;
+                    const bool pl = (map.planes[node].flags & LK_PLANE_IS_PLANE) != 0;
+                    if (!(st & LK_NODE_INIT_OCTO) || pl || nr->layer >= pr.max_layer) {
+                        tnode = node;
+                        break;
                     }
-                    k = max(k, 1);  // e.g. a first-frame plane with exactly max_points_num points: push one, then freeze
-                    if (r.block < 0) r.block = alloc_block(map);
-                    if (lane >= pos && lane < pos + k) {
-                        PtU pt;
-                        point_of(sidx, pt);
-                        lk_pt_rec* dst = &map.blocks[r.block].pts[r.npts + (lane - pos)];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) dst->pw[c] = pt.pw[c];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) dst->var[c] = pt.var[c];
+                    const int oct = octant_of(mypt.pw, nr->voxel_center);
+                    const int child = nr->child[oct];
+                    if (child < 0) {
+                        tnode = -1, tparent = node, toct = oct;
+                        break;
                     }
-                    r.npts += k;
-                    r.new_points += k;
-                    pos += k;
-                    wave_fence();
-                    if (leaf_uninit) {
-                        node_store(nd, r);
-                        if (r.npts > pr.layer_init_num[0]) dev_init_octo<0>(map, pr, root);  // voxel_map.cc:189
-                    } else {
-                        if (r.new_points > 5) {  // voxel_map.cc:195-198
-                            const bool still = dev_init_plane(&map.planes[root], &map.match[root], pr.planer_threshold,
-                                                              map.blocks[r.block].pts, nullptr, r.npts);
-                            r.new_points = 0;
-                            if (!still && r.layer < pr.max_layer) r.block = -1;
+                    node = child;
+                    tnode = node;
+                }
+            }
+            unsigned long long todo = __ballot(mine);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int Tn = __builtin_amdgcn_readlane(tnode, leader), Tp = __builtin_amdgcn_readlane(tparent, leader),
+                          To = __builtin_amdgcn_readlane(toct, leader);
+                const unsigned long long grp = __ballot(mine && tnode == Tn && tparent == Tp && toct == To) & todo;
+                todo &= ~grp;
+                int leaf = Tn;
+                if (leaf < 0) {  // voxel_map.cc:214-222: first point of a new octant creates the child
+                    const lk_node_rec* pn = &map.nodes[Tp];
+                    double pc[3] = {pn->voxel_center[0], pn->voxel_center[1], pn->voxel_center[2]};
+                    leaf = create_child(map, Tp, To, pc, pn->quater_length, bcast0(pn->layer));
+                }
+                // ---------------- one leaf, its points = lanes of grp in lane (= input) order
+                lk_node_rec* ln = &map.nodes[leaf];
+                NodeRegs r = node_load(ln);
+                const bool lplane = (bcast0((int)map.planes[leaf].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+                const int g = __popcll(grp);
+                const int L = r.layer;
+                const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
+                const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
+                const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
+                if (!uninit && !live && (lplane || maxnp)) continue;  // frozen leaf ignores its points
+                int consumed = 0;
+                if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts + g <= LK_WAVE) {
+                    // lane Ln holds node point Ln: existing points from the block, then the group's points in order
+                    const int n0 = r.npts;
+                    double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
+                    if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
+                    {
+                        int rr = lane - n0, src = 0;  // src = position of the rr-th set bit of grp
+                        if (rr >= 0 && rr < g) {
+                            int rem = rr;
+#pragma unroll
+                            for (int w = 32; w > 0; w >>= 1) {
+                                const unsigned long long low = ((w == 64) ? ~0ull : ((1ull << w) - 1ull)) << src;
+                                const int cbits = __popcll(grp & low);
+                                if (rem >= cbits) rem -= cbits, src += w;
+                            }
+                        } else {
+                            src = lane;
                         }
-                        if (r.npts >= pr.max_points_num) node_freeze(r);  // voxel_map.cc:199-203
-                        node_store(nd, r);
+                        const int qidx = __builtin_amdgcn_ds_bpermute(src << 2, sidx);
+                        if (rr >= 0 && rr < g) {
+                            PtU pt;
+                            point_of(qidx, pt);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) ppw[c] = pt.pw[c];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
+                        }
                     }
-                } else {
-                    // root with children (or a non-planar max-layer root): per-point state machine
-                    for (; pos < m; ++pos) {
-                        PtU pt;
-                        point_of(__builtin_amdgcn_readlane(sidx, pos), pt);
-                        dev_update_octo(map, pr, root, pt);
+                    const int thr = pr.layer_init_num[L];
+                    int cur = n0, newp = r.new_points;
+                    int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
+                    bool frozen = false, general_init = false, stop = false, fitted = false, flipped_to_tree = false;
+                    PlaneFit fit;
+                    fit.is_plane = lplane;
+                    int fit_count = 0;
+                    while (consumed < g && !stop) {
+                        const int rem = g - consumed;
+                        if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
+                            const int k = max(min(rem, thr + 1 - cur), 1);
+                            cur += k, newp += k, consumed += k;
+                            if (cur > thr) {
+                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                                fit_count = cur, fitted = true, newp = 0;
+                                if (fit.is_plane) {
+                                    mode = 1;
+                                    if (cur > pr.max_points_num) frozen = true, stop = true;
+                                } else if (L >= pr.max_layer) {
+                                    mode = 2;  // cut_octo_tree returns at once at max_layer (:140-143)
+                                } else {
+                                    general_init = true, stop = true;  // the generic code cuts the voxel
+                                }
+                            }
+                        } else if (mode == 1) {  // voxel_map.cc:191-204
+                            const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
+                            cur += k, newp += k, consumed += k;
+                            if (newp > 5) {
+                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                                fit_count = cur, fitted = true, newp = 0;
+                                if (!fit.is_plane) {
+                                    if (L < pr.max_layer) flipped_to_tree = true, stop = true;
+                                    else mode = 2;
+                                }
+                            }
+                            if (cur >= pr.max_points_num) frozen = true, stop = true;
+                        } else {  // voxel_map.cc:224-237
+                            const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
+                            cur += k, newp += k, consumed += k;
+                            if (newp > 5) {
+                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                                fit_count = cur, fitted = true, newp = 0;
+                                if (fit.is_plane) mode = 1;
+                            }
+                            if (cur > pr.max_points_num) frozen = true, stop = true;
+                        }
                     }
+                    // ---- commit points, counters, one full fit
+                    if (cur > n0 && r.block < 0) r.block = alloc_block(map);
+                    if (lane >= n0 && lane < cur) {
+                        lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) dst->var[c] = pvar[c];
+                    }
+                    r.npts = cur;
+                    if (general_init) {
+                        r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
+                        node_store(ln, r);
+                        switch (L) {
+                            case 0: dev_init_octo<0>(map, pr, leaf); break;
+                            case 1: dev_init_octo<1>(map, pr, leaf); break;
+                            case 2: dev_init_octo<2>(map, pr, leaf); break;
+                            default: dev_init_octo<3>(map, pr, leaf); break;
+                        }
+                    } else {
+                        r.new_points = newp;
+                        if (fitted) {
+                            // the one full fit of this leaf in this bucket: the state of its LAST refit event
+                            const bool decided = fit.is_plane;
+                            fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold);
+                            fit.is_plane = decided;  // control flow above already followed the event's decision
+                            double acc21[21];
+                            if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
+                            plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
+                            r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
+                            if (flipped_to_tree) r.block = -1;  // its own points are never read again
+                        }
+                        if (frozen) node_freeze(r);
+                        node_store(ln, r);
+                        if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
+                    }
+                }
+                // ---------------- whatever is left of the group: the per-point state machine from this node down
+                for (int tpos = consumed; tpos < g; ++tpos) {
+                    int src = 0, rem = tpos;
+#pragma unroll
+                    for (int w = 32; w > 0; w >>= 1) {
+                        const unsigned long long low = ((1ull << w) - 1ull) << src;
+                        const int cbits = __popcll(grp & low);
+                        if (rem >= cbits) rem -= cbits, src += w;
+                    }
+                    PtU pt;
+                    point_of(__builtin_amdgcn_readlane(sidx, src), pt);
+                    dev_update_octo(map, pr, leaf, pt);
                 }
             }
         } else {
