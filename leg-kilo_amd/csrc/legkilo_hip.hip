@@ -389,7 +389,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
            hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, m, h->pr, h->d_filters,
                               d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
     LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                           h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t));
+                                           h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
@@ -1000,18 +1000,27 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     if (!d_ts) hipMalloc(&d_ts, ts_waves * 10 * sizeof(unsigned long long));
     ro.z = reinterpret_cast<double*>(d_ts);
 #endif
+    // non-empty buckets; update(k) and predict(k+1) share one launch (the map is frozen: nothing reads the state in between)
+    std::vector<size_t> live;
     for (size_t b = 0; b < n_buckets; ++b) {
-        int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
-        if (nb <= 0) continue;
-        if ((size_t)nb > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+        if (bucket_off[b + 1] <= bucket_off[b]) continue;
+        if ((size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+        live.push_back(b);
+    }
+    for (size_t k = 0; k < live.size(); ++k) {
+        const size_t b = live[k];
+        const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
         const double t = t_begin + bucket_dt[b];
+        const bool has_next = k + 1 < live.size();
+        const double t_next = has_next ? t_begin + bucket_dt[live[k + 1]] : 0.0;
         const int nblk = (nb + LK_PB - 1) / LK_PB;
-        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
+        if (k == 0)
+            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
         LAUNCH(h, "residual",
                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_PB), 0, h->stream, h->map, h->pr,
                                   h->d_filters, d_pts + bucket_off[b], n_pts, nb, h->d_partials, h->part_stride, ro, (size_t)0));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                               h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_partials,
+                                               nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
     }
 #ifdef LK_TIMING
     {

@@ -260,9 +260,12 @@ __device__ void dev_point_update(LkFilter* f, FilterSmem& sm, const double* A21,
     dev_kalman_apply(f, sm, 6);
 }
 
-// reduce per-block partials (deterministic order) and update; partials: [nblk][LK_NPART] per slot
+// reduce the per-wave partial records (fixed order -> deterministic) and update; partials: [nblk][LK_NPART] per slot.
+// do_predict != 0 (batch replay on a frozen map, where nothing reads the state between update(k) and predict(k+1)):
+// the predict of the NEXT bucket (time t_next) runs in the same launch.
 __global__ void __launch_bounds__(LK_FB)
-    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t) {
+    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
+                     const double* __restrict__ Q, double t_next, int do_predict) {
     __shared__ FilterSmem sm;
     __shared__ double red[8][LK_NPART];
     __shared__ double tot[LK_NPART];
@@ -270,10 +273,18 @@ __global__ void __launch_bounds__(LK_FB)
     const double* part = partials + (size_t)blockIdx.x * slot_stride;
     const int tid = threadIdx.x;
     {
-        int j = tid % LK_NPART, g = tid / LK_NPART;  // 8 groups x 32 components
-        double s = 0.0;
-        for (int b = g; b < nblk; b += 8) s += part[(size_t)b * LK_NPART + j];
-        red[g][j] = s;
+        const int j = tid % LK_NPART, g = tid / LK_NPART;  // 8 groups x 32 components
+        // four independent accumulators keep four loads in flight; combined in a fixed order
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = g;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += part[(size_t)b * LK_NPART + j];
+            s1 += part[(size_t)(b + 8) * LK_NPART + j];
+            s2 += part[(size_t)(b + 16) * LK_NPART + j];
+            s3 += part[(size_t)(b + 24) * LK_NPART + j];
+        }
+        for (; b < nblk; b += 8) s0 += part[(size_t)b * LK_NPART + j];
+        red[g][j] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     if (tid < LK_NPART) {
@@ -293,15 +304,20 @@ __global__ void __launch_bounds__(LK_FB)
             f->last_update_t = t;  // KILO.cc:212
         }
     }
-    if (N == 0) return;
-    if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
-        double r = tot[27];
-        double sc = r / (r + 0.0001);
+    if (N > 0) {
+        if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
+            double r = tot[27];
+            double sc = r / (r + 0.0001);
+            __syncthreads();
+            if (tid < 27) tot[tid] *= sc;
+        }
         __syncthreads();
-        if (tid < 27) tot[tid] *= sc;
+        dev_point_update(f, sm, &tot[0], &tot[21]);
     }
-    __syncthreads();
-    dev_point_update(f, sm, &tot[0], &tot[21]);
+    if (do_predict) {
+        __syncthreads();  // f->x, f->P, f->last_update_t written above are re-read by dev_predict
+        dev_predict(f, Q, t_next, sm);
+    }
 }
 
 // updateByPoints(ObsShared&) on caller rows (class-surface call): one block accumulates A, b
