@@ -192,6 +192,8 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.slots, sizeof(int) * (size_t)LK_SLOTS * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.free_list, sizeof(int) * (size_t)m.max_blocks));
+    HIPCHK(h, hipMalloc(&m.freed_next, sizeof(int) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
     HIPCHK(h, hipMemsetAsync(h->d_filters, 0, sizeof(LkFilter) * (size_t)cfg->n_slots, h->stream));
     HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * 900));
@@ -218,7 +220,7 @@ void lk_destroy(lk_handle* h) {
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
-                    h->map.next, h->map.slots, h->map.scratch, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
+                    h->map.next, h->map.slots, h->map.scratch, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -380,7 +382,7 @@ int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const 
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
     const int nblk = (n + LK_PB - 1) / LK_PB;
-    HIPCHK(h, hipMemsetAsync(&m.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, m);
     LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
@@ -476,7 +478,7 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     HIPCHK(h, hipMalloc(&d_i1, sizeof(int) * n));
     HIPCHK(h, hipMemcpyAsync(d_w, xyz_world, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_b, xyz_body, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->map);
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "build_points", hipLaunchKernelGGL(lk_build_points_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr,
                                                  h->d_filters, d_w, d_b, (int)n, d_bpts, d_k0, d_i0));
@@ -507,7 +509,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     lk_pt_rec* d_pv = nullptr;
     HIPCHK(h, hipMalloc(&d_pv, sizeof(lk_pt_rec) * n));
     HIPCHK(h, hipMemcpyAsync(d_pv, st.data(), sizeof(lk_pt_rec) * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->map.counters[LK_CTR_TOUCHED], 0, 3 * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->map);
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);

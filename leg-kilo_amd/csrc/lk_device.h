@@ -39,7 +39,8 @@
 #define LK_E_SCRATCH_FULL 8u
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,
-       LK_CTR_HEAVY = 6, LK_CTR_COUNT = 8 };
+       LK_CTR_HEAVY = 6, LK_CTR_FREE = 7 /* signed: blocks poppable this bucket */, LK_CTR_FREED = 8 /* blocks retired
+       during this bucket */, LK_CTR_COUNT = 16 };
 
 struct LkFilter {
     double x[LK_STATE_DOUBLES];  // rot(9) pos vel ba bw grav imu_a imu_w bv contact
@@ -113,6 +114,8 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int* next;                   // per-point list links (bucket-local index): overflow beyond LK_SLOTS
     int* slots;                  // [max_nodes][LK_SLOTS] bucket-local point indices queued on a root
     int* scratch;                // per-root gathered indices
+    int* free_list;              // point blocks that may be re-allocated during this bucket
+    int* freed_next;             // point blocks retired during this bucket (allocatable from the next bucket on)
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;
 };
 

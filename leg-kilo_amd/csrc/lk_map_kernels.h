@@ -336,16 +336,29 @@ __device__ __forceinline__ void plane_commit(lk_plane_rec* pl, lk_match_rec* mr,
 }
 
 // ---- node helpers (wave-uniform; lane 0 writes)
+// Point-block pool.  Blocks retired by a freeze / cut during bucket k go to `freed_next`; lk_bucket_begin_kernel
+// moves them to `free_list` before bucket k+1, so within one launch the free list is only ever popped (a signed
+// counter; a failed pop restores it) and the retired list only ever pushed: no ABA, no lock.
+__device__ __forceinline__ int pop_or_bump_block(const LkMap& m) {
+    int* fc = reinterpret_cast<int*>(&m.counters[LK_CTR_FREE]);
+    const int k = atomicSub(fc, 1) - 1;
+    if (k >= 0) return m.free_list[k];
+    atomicAdd(fc, 1);
+    unsigned int b = atomicAdd(&m.counters[LK_CTR_BLOCKS], 1u);
+    if (b >= m.max_blocks) {
+        atomicOr(&m.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
+        b = m.max_blocks - 1;  // keep memory safe; the error flag fails the call
+    }
+    return (int)b;
+}
+__device__ __forceinline__ void retire_block(const LkMap& m, int block) {  // one lane
+    if (block < 0) return;
+    const unsigned int p = atomicAdd(&m.counters[LK_CTR_FREED], 1u);
+    if (p < m.max_blocks) m.freed_next[p] = block;
+}
 __device__ __forceinline__ int alloc_block(const LkMap& m) {
     int id = -1;
-    if ((threadIdx.x & 63) == 0) {
-        unsigned int b = atomicAdd(&m.counters[LK_CTR_BLOCKS], 1u);
-        if (b >= m.max_blocks) {
-            atomicOr(&m.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
-            b = m.max_blocks - 1;  // keep memory safe; the error flag fails the call
-        }
-        id = (int)b;
-    }
+    if ((threadIdx.x & 63) == 0) id = pop_or_bump_block(m);
     return bcast0(id);
 }
 __device__ __forceinline__ int create_child(const LkMap& m, int parent, int oct, const double* pcenter, float pquater,
@@ -414,11 +427,15 @@ __device__ __forceinline__ void node_push(const LkMap& m, NodeRegs& r, const PtU
     r.npts += 1;
     wave_fence();
 }
-__device__ __forceinline__ void node_freeze(NodeRegs& r) {  // update_enable_=false; swap(temp_points_); new_points_=0
+__device__ __forceinline__ void node_drop_block(const LkMap& m, NodeRegs& r) {  // temp_points_ will never be read again
+    if ((threadIdx.x & 63) == 0) retire_block(m, r.block);
+    r.block = -1;
+}
+__device__ __forceinline__ void node_freeze(const LkMap& m, NodeRegs& r) {  // update_enable_=false; swap(temp_points_); new_points_=0
     r.state &= ~LK_NODE_UPDATE_ENABLE;
     r.npts = 0;
     r.new_points = 0;
-    r.block = -1;  // the block is retired (not recycled in this version)
+    node_drop_block(m, r);
 }
 
 // init_octo_tree + cut_octo_tree for a node whose points live in its block (voxel_map.cc:119-183).
@@ -431,7 +448,7 @@ __device__ __noinline__ void dev_init_octo(const LkMap m, const LkParams pr, int
     const bool is_plane = dev_init_plane(&m.planes[node], &m.match[node], pr.planer_threshold, m.blocks[r.block].pts, nullptr, r.npts);
     if (is_plane) {
         r.state &= ~LK_NODE_OCTO_STATE;
-        if (r.npts > pr.max_points_num) node_freeze(r);
+        if (r.npts > pr.max_points_num) node_freeze(m, r);
     } else {
         r.state |= LK_NODE_OCTO_STATE;
         if (L >= pr.max_layer) {
@@ -458,7 +475,7 @@ __device__ __noinline__ void dev_init_octo(const LkMap m, const LkParams pr, int
                 int cn = bcast0(m.nodes[child].npts);
                 if (cn > pr.layer_init_num[L + 1]) dev_init_octo<L + 1>(m, pr, child);
             }
-            r.block = -1;  // the parent's own points are never read again (dead)
+            node_drop_block(m, r);  // the parent's own points are never read again (dead)
         }
     }
     r.state |= LK_NODE_INIT_OCTO;
@@ -497,9 +514,9 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
                     r.new_points = 0;
                     // a refit that turns the node into a non-plane below max_layer makes later points descend
                     // to children (voxel_map.cc:205-223): its own temp_points_ are never read again
-                    if (!still && r.layer < pr.max_layer) r.block = -1;
+                    if (!still && r.layer < pr.max_layer) node_drop_block(m, r);
                 }
-                if (r.npts >= pr.max_points_num) node_freeze(r);
+                if (r.npts >= pr.max_points_num) node_freeze(m, r);
                 node_store(nd, r);
             }
             return;
@@ -524,7 +541,7 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
                 r.new_points = 0;
             }
             if (r.npts > pr.max_points_num) {
-                node_freeze(r);
+                node_freeze(m, r);
                 r.state &= ~LK_NODE_PTS_DROPPED;
             }
             node_store(nd, r);
@@ -758,9 +775,9 @@ __global__ void __launch_bounds__(LK_MB)
                             if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
                             plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
                             r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
-                            if (flipped_to_tree) r.block = -1;  // its own points are never read again
+                            if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
                         }
-                        if (frozen) node_freeze(r);
+                        if (frozen) node_freeze(map, r);
                         node_store(ln, r);
                         if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
                     }
@@ -854,14 +871,7 @@ __global__ void __launch_bounds__(256)
     nd->list_head = -1;
     nd->pad_[0] = 0;
     int block = nd->block;
-    if (block < 0) {
-        unsigned int b = atomicAdd(&map.counters[LK_CTR_BLOCKS], 1u);
-        if (b >= map.max_blocks) {
-            atomicOr(&map.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
-            b = map.max_blocks - 1;
-        }
-        block = (int)b;
-    }
+    if (block < 0) block = pop_or_bump_block(map);
     BucketConst bc;
     load_bucket_const(&filters[0], pr, bc);
 #pragma unroll 1
@@ -953,7 +963,7 @@ __device__ __noinline__ void dev_build_node(const LkMap m, const LkParams pr, in
         if (is_plane) {
             r.state &= ~LK_NODE_OCTO_STATE;
             if (count > pr.max_points_num) {
-                node_freeze(r);
+                node_freeze(m, r);
                 keep = false;
             }
         } else {
@@ -1035,6 +1045,29 @@ __global__ void __launch_bounds__(LK_MB)
         const int root = bcast0(map.touched[t]);
         const int b = bcast0((int)map.nodes[root].pad_[1]), e = bcast0((int)map.nodes[root].pad_[2]);
         dev_build_node<0>(map, pr, root, bpts, idxA, idxB, b, e - b);
+    }
+}
+
+// Start of a bucket's insert phase: clear the per-bucket counters and make the blocks retired during the previous
+// bucket allocatable (see pop_or_bump_block).  One workgroup.
+__global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) {
+    __shared__ int base, nfreed;
+    if (threadIdx.x == 0) {
+        int fc = (int)map.counters[LK_CTR_FREE];
+        base = fc > 0 ? fc : 0;
+        unsigned int nf = map.counters[LK_CTR_FREED];
+        nfreed = (int)(nf < map.max_blocks ? nf : map.max_blocks);
+        if (base + nfreed > (int)map.max_blocks) nfreed = (int)map.max_blocks - base;
+        map.counters[LK_CTR_TOUCHED] = 0;
+        map.counters[LK_CTR_SCRATCH] = 0;
+        map.counters[LK_CTR_HEAVY] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfreed; i += 256) map.free_list[base + i] = map.freed_next[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        map.counters[LK_CTR_FREE] = (unsigned int)(base + nfreed);
+        map.counters[LK_CTR_FREED] = 0;
     }
 }
 

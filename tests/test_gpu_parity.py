@@ -396,6 +396,41 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib):
     o.close()
 
 
+def test_block_recycling_and_capacity_errors(scene, oracle_lib, hip_lib):
+    """Point blocks retired by freezes / cuts are re-used from the next bucket on: the pool's high-water mark stays
+    near the number of LIVE blocks instead of growing with every leaf that ever existed; exhausting a pool is a loud
+    LK_ERR_CAPACITY, never silent corruption."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 1.0
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0)
+    scenes.replay_vlp(o, scene, t0, 10)
+    scenes.replay_vlp(g, scene, t0, 10)
+    bo = abi.parse_blob(o.map_export())
+    live = int((bo["nodes"]["block"] >= 0).sum())
+    ever = int(((bo["nodes"]["state"] & abi.LK_NODE_INIT_OCTO) > 0).sum())  # leaves that held a block at some time
+    high_water = g.map_stats()[2]
+    print(f"live blocks {live}, initialised nodes {ever}, GPU pool high-water {high_water}")
+    assert high_water <= live + 0.35 * ever + 64, (high_water, live, ever)
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-6)
+    g.close()
+    # a pool that is too small for the first frame fails loudly
+    small = hip_lib.LegKiloHip(scene.cfg(max_point_blocks=64))
+    x0 = scenes.init_filter(small, scene, t0)
+    with pytest.raises(hip_lib.LegKiloError, match="overflow"):
+        scenes.first_frame(small, scene, t0, x0)
+    small.close()
+    tiny = hip_lib.LegKiloHip(scene.cfg(max_scan_points=256))
+    with pytest.raises(hip_lib.LegKiloError):
+        tiny.residuals(np.zeros((1000, 3), dtype=np.float32))
+    with pytest.raises(hip_lib.LegKiloError):
+        tiny.set_state(np.zeros(36), None, slot=5)
+    tiny.close()
+    o.close()
+
+
 def test_no_device_fallback_is_loud(hip_lib, scene):
     bad = scene.cfg(device_id=99)
     with pytest.raises(hip_lib.LegKiloError):
