@@ -10,7 +10,9 @@ Workload (BASELINE.json metric "LiDAR scans/sec (per-point ESKF update), 100k-pt
             run through the full per-bucket ESKF update (5 time buckets x 20 000 points: predict ->
             voxel-hash plane matching + residual rows + A/b reduction -> 6x6 information-form update)
             against ONE shared voxel map, frozen (inserts disabled on both GPU and oracle), each scan from
-            its own perturbed prior.  Scans are resident in HBM before the timed region.
+            its own perturbed prior.  Scans are resident in HBM before the timed region.  Inside a time bucket the
+            points come in the order the reference's pipeline hands them over: pcl::VoxelGrid's output order
+            (ascending cell index, KILO.cc:356-370), which is spatially coherent.
             N>1: rank 0 builds the map and broadcasts the device blob over RCCL; scans are sharded
             (weak scaling: per-GPU work fixed); per-step results are all-gathered.
   extra     config 3 as one sequential stream with map insert (the reference's own semantics):

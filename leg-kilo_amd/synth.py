@@ -166,7 +166,7 @@ def vlp16_scan(world, traj, t_begin, cfg, seed_noise=3003, n_az=1800, period=0.1
 
 
 def dense_scan(world, traj, t_begin, cfg, n=100_000, n_buckets=5, seed_scan=2002, seed_noise=3003, period=0.1,
-               blind=1.5):
+               blind=1.5, layout="cell"):
     """Configs 2/3/5: n points ENTERING the path (post-downsample), random ray directions
     (azimuth uniform, elevation in [-25, 40] deg), time bins by azimuth rank: n_buckets runs of
     equal curvature k * period / n_buckets... quantised like lidar_processing.cc:48 when n_buckets=51.
@@ -197,6 +197,18 @@ def dense_scan(world, traj, t_begin, cfg, n=100_000, n_buckets=5, seed_scan=2002
     else:
         b = (np.arange(n) * n_buckets) // n
         pts["curvature"] = (b * (period / n_buckets)).astype(np.float32)
+    if layout == "cell":
+        # Inside a run of equal time stamps the reference's order is whatever pcl::VoxelGrid emitted (ascending cell
+        # index, x fastest; the std::sort by time is over equal keys there).  Reproduce that spatially coherent order:
+        # sort each bucket by the body-frame cell index of the yaml voxel_grid_resolution.
+        leaf = float(cfg.get("voxel_grid_resolution", 0.3))
+        xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
+        inv = np.float32(1.0) / np.float32(leaf)
+        ijk = np.floor(xyz * inv).astype(np.int64)
+        ijk -= ijk.min(0)
+        div = ijk.max(0) + 1
+        cell = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+        pts = pts[np.lexsort((cell, pts["curvature"]))]
     # stable sort again (rounding keeps monotonic order, but make the contract explicit)
     pts = pts[np.argsort(pts["curvature"], kind="stable")]
     return pts
