@@ -247,6 +247,23 @@ int lk_process_scan(lk_handle* h, const lk_point* sorted_pts, size_t n, double t
 int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_begin, const uint32_t* bucket_off,
                         const double* bucket_dt, size_t n_buckets, lk_pose* out);
 
+/* ---- sensor decode: LidarProcessing::{velodyne,ouster,hesai}Handler, lidar_processing.cc:25-108 ----
+ * msg_data = sensor_msgs::PointCloud2::data (n_points x point_step bytes).  Keeps every filter_num-th point that is
+ * outside the blind radius (lidar_processing.h:96-98), curvature = round((t - t_first) * 500) / 500 in the arithmetic
+ * type of the respective handler, input order preserved.  begin/end = LidarScan::lidar_begin_time_/lidar_end_time_. */
+typedef struct lk_cloud_layout {
+    uint32_t point_step;
+    uint32_t off_x, off_y, off_z;   /* float32 fields */
+    uint32_t off_time;              /* Velodyne `time` f32 | Ouster `t` u32 | Hesai `timestamp` f64 */
+    int32_t lidar_type;             /* 1 Velodyne, 2 Ouster, 3 Hesai (sensor_types.hpp:34) */
+} lk_cloud_layout;
+int lk_decode_scan(lk_handle* h, const void* msg_data, size_t n_points, const lk_cloud_layout* layout, double time_scale,
+                   int filter_num, float blind, double header_stamp, lk_point* out, size_t* n_out, double* begin_time,
+                   double* end_time);
+int lk_decode_scan_dev(lk_handle* h, const void* d_msg_data, size_t n_points, const lk_cloud_layout* layout, double time_scale,
+                       int filter_num, float blind, double header_stamp, lk_point* d_out, size_t* n_out, double* begin_time,
+                       double* end_time);
+
 /* ---- the two steps in front of the path, device-resident ----
  * pcl::VoxelGrid centroid filter as used at KILO.cc:356-360 (leaf = yaml voxel_grid_resolution; centroid of x, y, z
  * AND curvature) followed by the time sort of KILO.cc:369-370 (stable).  Cells are emitted in ascending cell index,

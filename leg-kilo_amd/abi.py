@@ -81,6 +81,11 @@ class lk_pose(C.Structure):
     ]
 
 
+class lk_cloud_layout(C.Structure):
+    _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32), ("off_z", C.c_uint32),
+                ("off_time", C.c_uint32), ("lidar_type", C.c_int32)]
+
+
 class lk_blob_header(C.Structure):
     _fields_ = [
         ("magic", C.c_uint32),

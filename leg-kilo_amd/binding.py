@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -233,7 +233,17 @@ class LegKiloHip:
                                              C.c_size_t(len(dt)), C.byref(pose)))
         return pose
 
-    # ---- preprocessing in front of the path ----
+    # ---- sensor decode + preprocessing in front of the path ----
+    def decode_scan(self, msg_bytes, n_points, layout, time_scale, filter_num, blind, header_stamp=0.0):
+        """layout = dict(point_step, off_x, off_y, off_z, off_time, lidar_type)."""
+        data = np.ascontiguousarray(np.frombuffer(msg_bytes, dtype=np.uint8))
+        lay = abi.lk_cloud_layout(**layout)
+        out = np.zeros(n_points, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("curvature", "<f4")]))
+        n_out, tb, te = C.c_size_t(0), C.c_double(0), C.c_double(0)
+        self._chk(self.L.lk_decode_scan(self.h, _p(data), C.c_size_t(n_points), C.byref(lay), C.c_double(time_scale), int(filter_num),
+                                        C.c_float(blind), C.c_double(header_stamp), _p(out), C.byref(n_out), C.byref(tb), C.byref(te)))
+        return out[: n_out.value], tb.value, te.value
+
     def preprocess_scan(self, raw_pts, leaf):
         raw = np.ascontiguousarray(raw_pts)
         out = np.zeros(len(raw), dtype=raw.dtype)

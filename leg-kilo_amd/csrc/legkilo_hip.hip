@@ -882,7 +882,7 @@ static int pre_reserve(lk_handle* h, size_t n) {
     HIPCHK(h, hipMalloc(&h->pre_k1, sizeof(unsigned int) * cap));
     HIPCHK(h, hipMalloc(&h->pre_flags, sizeof(unsigned int) * cap));
     HIPCHK(h, hipMalloc(&h->pre_pos, sizeof(unsigned int) * cap));
-    HIPCHK(h, hipMalloc(&h->pre_misc, sizeof(unsigned int) * 16));
+    HIPCHK(h, hipMalloc(&h->pre_misc, sizeof(unsigned int) * 32));
     HIPCHK(h, hipMalloc(&h->pre_v0, sizeof(int) * cap));
     HIPCHK(h, hipMalloc(&h->pre_v1, sizeof(int) * cap));
     HIPCHK(h, hipMalloc(&h->pre_starts, sizeof(int) * cap));
@@ -893,6 +893,62 @@ static int pre_reserve(lk_handle* h, size_t n) {
     HIPCHK(h, hipMalloc(&h->pre_tmp, h->pre_tmp_bytes));
     h->pre_cap = cap;
     return LK_OK;
+}
+
+int lk_decode_scan_dev(lk_handle* h, const void* d_msg, size_t n_points, const lk_cloud_layout* layout, double time_scale,
+                       int filter_num, float blind, double header_stamp, lk_point* d_out, size_t* n_out, double* begin_time,
+                       double* end_time) {
+    CHECK_H(h);
+    if (!d_msg || !layout || !d_out || !n_out || n_points == 0 || filter_num < 1 || n_points > 0x7fffffffu)
+        return fail(h, LK_ERR_INVALID, "lk_decode_scan: bad argument");
+    if (layout->lidar_type < 1 || layout->lidar_type > 3) return fail(h, LK_ERR_INVALID, "lidar_type must be 1, 2 or 3");
+    const uint32_t tsz = layout->lidar_type == 3 ? 8u : 4u;
+    if (layout->off_x + 4 > layout->point_step || layout->off_y + 4 > layout->point_step || layout->off_z + 4 > layout->point_step ||
+        layout->off_time + tsz > layout->point_step)
+        return fail(h, LK_ERR_INVALID, "field offsets exceed point_step");
+    int rc = pre_reserve(h, n_points);
+    if (rc) return rc;
+    LkDecodeArgs a;
+    a.lay = *layout, a.time_scale = time_scale, a.filter_num = filter_num, a.blind = blind;
+    const int n = (int)n_points, nb = (n + 255) / 256;
+    unsigned int* n_out_d = h->pre_misc + 7;
+    double* fl = reinterpret_cast<double*>(h->pre_misc + 8);
+    LAUNCH(h, "decode_flags", hipLaunchKernelGGL(lk_decode_flags_kernel, dim3(nb), dim3(256), 0, h->stream,
+                                                 (const unsigned char*)d_msg, n, a, h->pre_flags));
+    size_t tb = h->pre_tmp_bytes;
+    HIPCHK(h, rocprim::exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, 0u, n_points, rocprim::plus<unsigned int>(), h->stream));
+    LAUNCH(h, "decode_scatter", hipLaunchKernelGGL(lk_decode_scatter_kernel, dim3(nb), dim3(256), 0, h->stream,
+                                                   (const unsigned char*)d_msg, n, a, h->pre_flags, h->pre_pos, d_out, n_out_d, fl));
+    unsigned int cnt = 0;
+    double tfl[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(&cnt, n_out_d, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(tfl, fl, sizeof(tfl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_out = cnt;
+    const double base = layout->lidar_type == 3 ? 0.0 : header_stamp;  // lidar_processing.cc:34-35,63-64 vs :91-92
+    if (begin_time) *begin_time = base + tfl[0];
+    if (end_time) *end_time = base + tfl[1];
+    return LK_OK;
+}
+
+int lk_decode_scan(lk_handle* h, const void* msg, size_t n_points, const lk_cloud_layout* layout, double time_scale, int filter_num,
+                   float blind, double header_stamp, lk_point* out, size_t* n_out, double* begin_time, double* end_time) {
+    CHECK_H(h);
+    if (!msg || !layout || !out || n_points == 0) return fail(h, LK_ERR_INVALID, "lk_decode_scan: bad argument");
+    void* d_msg = nullptr;
+    const size_t bytes = n_points * (size_t)layout->point_step;
+    HIPCHK(h, hipMalloc(&d_msg, bytes));
+    int rc = pre_reserve(h, n_points);
+    if (rc == LK_OK) {
+        hipMemcpyAsync(d_msg, msg, bytes, hipMemcpyHostToDevice, h->stream);
+        rc = lk_decode_scan_dev(h, d_msg, n_points, layout, time_scale, filter_num, blind, header_stamp, h->pre_out, n_out, begin_time, end_time);
+        if (rc == LK_OK) {
+            hipMemcpyAsync(out, h->pre_out, sizeof(lk_point) * (*n_out), hipMemcpyDeviceToHost, h->stream);
+            hipStreamSynchronize(h->stream);
+        }
+    }
+    hipFree(d_msg);
+    return rc;
 }
 
 int lk_preprocess_scan_dev(lk_handle* h, const lk_point* d_raw, size_t n_raw, float leaf, lk_point* d_out, size_t* n_out) {

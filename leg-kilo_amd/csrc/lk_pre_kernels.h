@@ -101,3 +101,72 @@ __global__ void __launch_bounds__(256)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(cells)[order[i]];
 }
+
+// ------------------------------------------------------------------ sensor decode (lidar_processing.cc:25-108)
+struct LkDecodeArgs {
+    lk_cloud_layout lay;
+    double time_scale;
+    int filter_num;
+    float blind;
+};
+__device__ __forceinline__ float lk_ld_f32(const unsigned char* p) {  // PointCloud2 fields are not 4-B aligned in general
+    unsigned int u = (unsigned int)p[0] | ((unsigned int)p[1] << 8) | ((unsigned int)p[2] << 16) | ((unsigned int)p[3] << 24);
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned int lk_ld_u32(const unsigned char* p) {
+    return (unsigned int)p[0] | ((unsigned int)p[1] << 8) | ((unsigned int)p[2] << 16) | ((unsigned int)p[3] << 24);
+}
+__device__ __forceinline__ double lk_ld_f64(const unsigned char* p) {
+    unsigned long long u = (unsigned long long)lk_ld_u32(p) | ((unsigned long long)lk_ld_u32(p + 4) << 32);
+    return __longlong_as_double((long long)u);
+}
+// per point: keep flag (every filter_num-th point outside the blind radius)
+__global__ void __launch_bounds__(256)
+    lk_decode_flags_kernel(const unsigned char* __restrict__ data, int n, LkDecodeArgs a, unsigned int* __restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* p = data + (size_t)i * a.lay.point_step;
+    const float x = lk_ld_f32(p + a.lay.off_x), y = lk_ld_f32(p + a.lay.off_y), z = lk_ld_f32(p + a.lay.off_z);
+    const bool blind = a.blind * a.blind > x * x + y * y + z * z;  // blindCheck, lidar_processing.h:96-98
+    flags[i] = ((i % a.filter_num) || blind) ? 0u : 1u;
+}
+// scatter the kept points in input order; time arithmetic per handler
+__global__ void __launch_bounds__(256)
+    lk_decode_scatter_kernel(const unsigned char* __restrict__ data, int n, LkDecodeArgs a, const unsigned int* __restrict__ flags,
+                             const unsigned int* __restrict__ pos, lk_point* __restrict__ out, unsigned int* __restrict__ n_out,
+                             double* __restrict__ first_last) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* p0 = data + a.lay.off_time;
+    const unsigned char* pl = data + (size_t)(n - 1) * a.lay.point_step + a.lay.off_time;
+    const unsigned char* p = data + (size_t)i * a.lay.point_step;
+    float curv;
+    double first_d, last_d;
+    if (a.lay.lidar_type == 3) {  // hesaiHandler: doubles
+        first_d = a.time_scale * lk_ld_f64(p0);
+        last_d = a.time_scale * lk_ld_f64(pl);
+        const double cur = a.time_scale * lk_ld_f64(p + a.lay.off_time);
+        curv = (float)(round((cur - first_d) * (double)500.0f) / (double)500.0f);
+    } else {
+        float first_f, last_f, cur_f;
+        if (a.lay.lidar_type == 2) {  // ousterHander: uint32 t
+            first_f = (float)(a.time_scale * (double)lk_ld_u32(p0));
+            last_f = (float)(a.time_scale * (double)lk_ld_u32(pl));
+            cur_f = (float)(a.time_scale * (double)lk_ld_u32(p + a.lay.off_time));
+        } else {  // velodyneHandler: float time
+            first_f = (float)(a.time_scale * (double)lk_ld_f32(p0));
+            last_f = (float)(a.time_scale * (double)lk_ld_f32(pl));
+            cur_f = (float)(a.time_scale * (double)lk_ld_f32(p + a.lay.off_time));
+        }
+        first_d = (double)first_f, last_d = (double)last_f;
+        curv = roundf((cur_f - first_f) * 500.0f) / 500.0f;
+    }
+    if (i == 0) first_last[0] = first_d, first_last[1] = last_d;
+    if (i == n - 1) *n_out = pos[i] + flags[i];
+    if (flags[i]) {
+        lk_point o;
+        o.x = lk_ld_f32(p + a.lay.off_x), o.y = lk_ld_f32(p + a.lay.off_y), o.z = lk_ld_f32(p + a.lay.off_z);
+        o.curvature = curv;
+        out[pos[i]] = o;
+    }
+}

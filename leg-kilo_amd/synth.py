@@ -222,7 +222,9 @@ def preprocess_velodyne(raw, filter_num=3, blind=1.5):
     keep = (idx % filter_num == 0) & ~(np.float32(blind * blind) > r2)
     out = raw[keep].copy()
     first = raw["curvature"][0]
-    out["curvature"] = np.round((out["curvature"] - first) * np.float32(500.0)) / np.float32(500.0)
+    v = ((out["curvature"] - first) * np.float32(500.0)).astype(np.float32)
+    r = (np.floor(np.abs(v.astype(np.float64)) + 0.5) * np.sign(v)).astype(np.float32)  # std::round, half away from zero
+    out["curvature"] = r / np.float32(500.0)
     return out
 
 

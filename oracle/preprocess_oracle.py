@@ -63,3 +63,46 @@ def voxel_grid_centroid_loops(pts, leaf):
                 acc = np.float32(acc + np.float32(p[name]))
             out[name][o] = acc / np.float32(len(cells[key]))
     return out
+
+
+# ------------------------------------------------------------------ sensor decode (lidar_processing.cc:25-108)
+VELODYNE_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "time", "ring"], "formats": ["<f4", "<f4", "<f4", "<f4", "<f4", "<u2"],
+                           "offsets": [0, 4, 8, 12, 16, 20], "itemsize": 22})
+OUSTER_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "ambient", "range"],
+                         "formats": ["<f4", "<f4", "<f4", "<f4", "<u4", "<u2", "u1", "<u2", "<u4"],
+                         "offsets": [0, 4, 8, 16, 20, 24, 26, 28, 32], "itemsize": 48})
+HESAI_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "timestamp", "ring"], "formats": ["<f4", "<f4", "<f4", "<f4", "<f8", "<u2"],
+                        "offsets": [0, 4, 8, 16, 24, 32], "itemsize": 40})
+OUT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("curvature", "<f4")])
+
+
+def decode(raw, lidar_type, time_scale, filter_num, blind, header_stamp=0.0):
+    """velodyneHandler (:25-52) / ousterHander (:54-80) / hesaiHandler (:82-108): plain-loop restatement."""
+    tname = {1: "time", 2: "t", 3: "timestamp"}[lidar_type]
+    n = len(raw)
+    blind = np.float32(blind)
+    out = []
+    if lidar_type == 3:
+        first = np.float64(time_scale) * np.float64(raw[tname][0])
+        last = np.float64(time_scale) * np.float64(raw[tname][-1])
+        begin, end = float(first), float(last)
+    else:
+        first = np.float32(np.float64(time_scale) * np.float64(raw[tname][0]))
+        last = np.float32(np.float64(time_scale) * np.float64(raw[tname][-1]))
+        begin, end = header_stamp + float(first), header_stamp + float(last)
+    for i in range(n):
+        x, y, z = np.float32(raw["x"][i]), np.float32(raw["y"][i]), np.float32(raw["z"][i])
+        if (i % filter_num) or (blind * blind > x * x + y * y + z * z):
+            continue
+        if lidar_type == 3:
+            cur = np.float64(time_scale) * np.float64(raw[tname][i])
+            v = (cur - first) * np.float64(np.float32(500.0))
+            curv = np.float32(np.floor(np.abs(v) + 0.5) * np.sign(v) / np.float64(np.float32(500.0)))  # std::round: half away from zero
+        else:
+            cur = np.float32(np.float64(time_scale) * np.float64(raw[tname][i]))
+            v = np.float32(np.float32(cur - first) * np.float32(500.0))
+            # std::round: half away from zero (np.round is half-to-even); |v| + 0.5 is exact in float64
+            r = np.float32(np.floor(np.abs(np.float64(v)) + 0.5) * np.sign(np.float64(v)))
+            curv = np.float32(r / np.float32(500.0))
+        out.append((x, y, z, curv))
+    return np.array(out, dtype=OUT_DTYPE), begin, end

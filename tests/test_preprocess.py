@@ -98,3 +98,61 @@ def test_gpu_raw_scan_to_pose(scene, hip_lib, oracle_lib):
         assert np.abs(xo - xg).max() < 1e-7, (k, np.abs(xo - xg).max())
     g.close()
     o.close()
+
+
+# ----------------------------------------------------------------------------- sensor decode
+def raw_message(scene, t, lidar_type):
+    """A synthetic sensor_msgs::PointCloud2 payload in the Velodyne / Ouster / Hesai point layout."""
+    pts = synth.vlp16_scan(scene.world, scene.traj, t, scene.P)
+    dt = {1: po.VELODYNE_DTYPE, 2: po.OUSTER_DTYPE, 3: po.HESAI_DTYPE}[lidar_type]
+    raw = np.zeros(len(pts), dtype=dt)
+    raw["x"], raw["y"], raw["z"] = pts["x"], pts["y"], pts["z"]
+    raw["intensity"] = 10.0
+    if lidar_type == 1:
+        raw["time"] = pts["curvature"]
+        scale = 1.0
+    elif lidar_type == 2:
+        raw["t"] = np.round(pts["curvature"].astype(np.float64) * 1e9).astype(np.uint32)
+        scale = 1e-9
+    else:
+        raw["timestamp"] = 1.7e9 + pts["curvature"].astype(np.float64)
+        scale = 1.0
+    tname = {1: "time", 2: "t", 3: "timestamp"}[lidar_type]
+    layout = dict(point_step=dt.itemsize, off_x=dt.fields["x"][1], off_y=dt.fields["y"][1], off_z=dt.fields["z"][1],
+                  off_time=dt.fields[tname][1], lidar_type=lidar_type)
+    return raw, layout, scale
+
+
+def test_decode_oracle_matches_vectorised_host_version(scene):
+    raw, layout, scale = raw_message(scene, 1.0, 1)
+    got, tb, te = po.decode(raw[:3000], 1, scale, 3, 1.5, header_stamp=100.0)
+    host = synth.preprocess_velodyne(synth.vlp16_scan(scene.world, scene.traj, 1.0, scene.P)[:3000], 3, 1.5)
+    assert len(got) == len(host) > 500
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], host[f]), f
+    assert abs(tb - (100.0 + float(raw["time"][0]))) < 1e-9 and te > tb
+    # 2 ms bins (lidar_processing.cc:48)
+    assert np.allclose(got["curvature"] * 500.0, np.round(got["curvature"] * 500.0), atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lidar_type", [1, 2, 3])
+def test_gpu_decode_bit_exact(scene, hip_lib, lidar_type):
+    g = hip_lib.LegKiloHip(scene.cfg())
+    raw, layout, scale = raw_message(scene, 2.0, lidar_type)
+    raw = raw[:6000]  # the oracle is a plain Python loop
+    want, tb, te = po.decode(raw, lidar_type, scale, 3, 1.5, header_stamp=50.0)
+    got, gb, ge = g.decode_scan(raw.tobytes(), len(raw), layout, scale, 3, 1.5, header_stamp=50.0)
+    assert len(got) == len(want) > 1000
+    for f in want.dtype.names:
+        assert np.array_equal(got[f], want[f]), (f, int((got[f] != want[f]).sum()))
+    assert gb == tb and ge == te
+    # decode -> voxel grid -> time sort, all on the device, equals the oracle chain
+    full, layout, scale = raw_message(scene, 2.0, lidar_type)
+    dec, _, _ = g.decode_scan(full.tobytes(), len(full), layout, scale, 3, 1.5)
+    ds = g.preprocess_scan(dec, 0.3)
+    assert np.all(np.diff(ds["curvature"]) >= 0) and 1000 < len(ds) < len(dec)
+    want_ds = po.preprocess(dec, 0.3)
+    for f in want_ds.dtype.names:
+        assert np.array_equal(ds[f], want_ds[f]), f
+    g.close()
