@@ -248,7 +248,7 @@ def test_update_points_bucket_and_insert(pair, scene):
 
 # ----------------------------------------------------------------------------- full sequences
 @pytest.mark.parametrize("literal", [True, False])
-def test_sequence_imu_mode(pair, scene, literal):
+def test_sequence_imu_mode(pair, scene, literal, tmp_path):
     """Config 1 shape: first-frame build + 12 real-like scans (hundreds of small buckets each), IMU-only mode.
     literal=True : the oracle runs the reference's literal N x N inverse (eskf.cc:105-112) for every bucket;
     literal=False: the oracle uses the algebraically identical 6 x 6 form -> only summation order differs,
@@ -270,6 +270,13 @@ def test_sequence_imu_mode(pair, scene, literal):
     ate = scenes.ate([x[9:12] for _, x in ro], [x[9:12] for _, x in rg])
     assert ate < tol, ate  # north star: ATE delta < 1 mm
     print(f"literal={literal}: worst position delta {worst:.3e} m, ATE delta {ate:.3e} m")
+    # the same statement through the on-disk format the reference writes (trajectory_saver.hpp:43-50)
+    from legkilo_amd import tum
+    stamps = [t0 + 0.1 * (k + 1) for k in range(len(ro))]
+    tum.write_tum(tmp_path / "cpu.txt", stamps, [x[:9] for _, x in ro], [x[9:12] for _, x in ro])
+    tum.write_tum(tmp_path / "gpu.txt", stamps, [x[:9] for _, x in rg], [x[9:12] for _, x in rg])
+    e, n = tum.ate_files(tmp_path / "cpu.txt", tmp_path / "gpu.txt")
+    assert n == len(ro) and e < 1e-3, e  # north star: trajectory ATE delta < 1 mm (files carry 9 decimals)
     # the stored points / plane centres carry the accumulated state delta
     scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=10 * tol)
 
