@@ -11,4 +11,4 @@ Layout
 
 The product path never imports anything from oracle/.
 """
-__all__ = ["abi", "binding", "config", "synth", "replay", "tum"]
+__all__ = ["abi", "binding", "config", "synth", "replay", "tum", "checkpoint"]

@@ -438,6 +438,32 @@ def test_block_recycling_and_capacity_errors(scene, oracle_lib, hip_lib):
     o.close()
 
 
+def test_checkpoint_resume_is_bit_identical(scene, hip_lib, tmp_path):
+    """Save (state + map blob) mid-run, restore into a FRESH handle, continue: every later state is bit-identical to
+    the uninterrupted run (also a run-to-run determinism check: node / block ids differ, results must not)."""
+    from legkilo_amd import checkpoint
+
+    a = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 1.0
+    x0 = scenes.init_filter(a, scene, t0)
+    scenes.first_frame(a, scene, t0, x0)
+    scenes.replay_vlp(a, scene, t0, 4)
+    checkpoint.save(tmp_path / "ck.npz", a)
+    b = hip_lib.LegKiloHip(scene.cfg())
+    checkpoint.restore(tmp_path / "ck.npz", b)
+    ra = scenes.replay_vlp(a, scene, t0, 4, start=4)
+    rb = scenes.replay_vlp(b, scene, t0, 4, start=4)
+    for k, ((pa, xa), (pb, xb)) in enumerate(zip(ra, rb)):
+        assert (pa.n_buckets, pa.n_updates, pa.n_effect) == (pb.n_buckets, pb.n_updates, pb.n_effect), k
+        assert np.array_equal(xa, xb), (k, np.abs(xa - xb).max())
+    _, Pa = a.get_state()
+    _, Pb = b.get_state()
+    assert np.array_equal(Pa, Pb)
+    scenes.compare_maps(a.map_export(), b.map_export(), rtol=0.0, ptol=0.0)
+    a.close()
+    b.close()
+
+
 def test_no_device_fallback_is_loud(hip_lib, scene):
     bad = scene.cfg(device_id=99)
     with pytest.raises(hip_lib.LegKiloError):
