@@ -119,8 +119,16 @@ def main():
     if world_size > 1:
         import torch.distributed as dist
 
+        # test hooks (tools/gpu_multirank_selftest.sh): several ranks on ONE GPU over gloo exercise the whole N>1 code
+        # path on a single-GPU box; the driver's real runs use neither variable (RCCL, one GPU per rank)
+        backend = os.environ.get("LEGKILO_BENCH_BACKEND", "nccl")
+        if os.environ.get("LEGKILO_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_size}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
