@@ -35,6 +35,10 @@ struct lk_handle {
     LkParams pr;
     LkMap map;
     hipStream_t stream = nullptr;
+    static constexpr int kMaxGroups = 4;
+    hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
+    int replay_groups = 3;
     unsigned int hash_cap = 0;
     LkFilter* d_filters = nullptr;
     double* d_Q = nullptr;
@@ -147,6 +151,12 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     h->cfg = *cfg;
     HIPCHK(h, hipSetDevice(cfg->device_id));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    if (const char* e = getenv("LEGKILO_REPLAY_GROUPS")) h->replay_groups = std::min(std::max(atoi(e), 1), (int)lk_handle::kMaxGroups);
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
     // parameters
@@ -230,6 +240,11 @@ void lk_destroy(lk_handle* h) {
         if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i) {
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+        if (h->side[i]) hipStreamDestroy(h->side[i]);
+    }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1065,6 +1080,17 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
         if ((size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
         live.push_back(b);
     }
+    // Slot groups on separate HIP streams (default 3 — measured best of 1..8 on MI355X; LEGKILO_REPLAY_GROUPS=1..4 overrides): the single-workgroup update/predict kernels of one group (half of the CUs
+    // idle, latency-bound) overlap the residual kernel of the other group.  Groups touch disjoint filters / partials and
+    // only read the map.  Profiling mode (per-launch events + sync) and small batches stay on one stream.
+    const int ngroups = (!h->profiling && S >= 2 * h->replay_groups) ? h->replay_groups : 1;
+    hipStream_t streams[lk_handle::kMaxGroups];
+    streams[0] = h->stream;
+    for (int g = 1; g < lk_handle::kMaxGroups; ++g) streams[g] = h->side[g - 1];
+    if (ngroups > 1) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        for (int g = 1; g < ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(streams[g], h->ev_fork, 0));
+    }
     for (size_t k = 0; k < live.size(); ++k) {
         const size_t b = live[k];
         const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
@@ -1072,13 +1098,32 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
         const bool has_next = k + 1 < live.size();
         const double t_next = has_next ? t_begin + bucket_dt[live[k + 1]] : 0.0;
         const int nblk = (nb + LK_PB - 1) / LK_PB;
-        if (k == 0)
-            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
-        LAUNCH(h, "residual",
-               hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_PB), 0, h->stream, h->map, h->pr,
-                                  h->d_filters, d_pts + bucket_off[b], n_pts, nb, h->d_partials, h->part_stride, ro, (size_t)0));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_partials,
-                                               nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
+        for (int grp = 0; grp < ngroups; ++grp) {
+            const int s0 = (int)((long)S * grp / ngroups), sn = (int)((long)S * (grp + 1) / ngroups) - s0;
+            hipStream_t st = streams[grp];
+            LkFilter* fl = h->d_filters + s0;
+            double* parts = h->d_partials + (size_t)s0 * h->part_stride;
+            const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
+            if (ngroups == 1) {
+                if (k == 0)
+                    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
+                LAUNCH(h, "residual", hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_PB), 0, st, h->map, h->pr, fl,
+                                                         pts, n_pts, nb, parts, h->part_stride, ro, (size_t)0));
+                LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts,
+                                                       nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
+            } else {
+                if (k == 0) hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_PB), 0, st, h->map, h->pr, fl, pts, n_pts, nb, parts,
+                                   h->part_stride, ro, (size_t)0);
+                hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_PB / LK_WAVE), h->part_stride, t,
+                                   h->d_Q, t_next, has_next ? 1 : 0);
+            }
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    for (int g = 1; g < ngroups; ++g) {  // join: everything after this point on h->stream sees every group's results
+        HIPCHK(h, hipEventRecord(h->ev_join[g - 1], streams[g]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[g - 1], 0));
     }
 #ifdef LK_TIMING
     {

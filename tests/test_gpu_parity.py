@@ -360,8 +360,9 @@ def test_config2_full_size_residuals(big, hip_lib):
 
 
 # ----------------------------------------------------------------------------- batch replay (config 5, reduced)
-def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib):
-    S, n_pts, nb = 6, 8000, 5
+@pytest.mark.parametrize("S", [6, 7, 3])   # 6/7: three slot groups on three HIP streams (even / ragged split); 3: single stream
+def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
+    n_pts, nb = 8000, 5
     o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
     g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
     t0 = 1.0
