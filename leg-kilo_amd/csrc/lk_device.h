@@ -244,12 +244,13 @@ struct BucketConst {
     double R[9], p[3], RE[9];
     S3 Prr, Ppp;
 };
+template <bool WITH_RE = true>
 __device__ __forceinline__ void load_bucket_const(const LkFilter* __restrict__ f, const LkParams& pr, BucketConst& bc) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) bc.R[i] = f->x[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) bc.p[i] = f->x[9 + i];
-    mat3_mul(bc.R, pr.ext_R, bc.RE);
+    if (WITH_RE) mat3_mul(bc.R, pr.ext_R, bc.RE);
     const double* P = f->P;
     bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
     bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
@@ -272,6 +273,50 @@ __device__ __forceinline__ PointGeom point_geom(float bx, float by, float bz, co
     g.var = S3{a.xx + b.xx + bc.Ppp.xx, a.xy + b.xy + bc.Ppp.xy, a.xz + b.xz + bc.Ppp.xz,
                a.yy + b.yy + bc.Ppp.yy, a.yz + b.yz + bc.Ppp.yz, a.zz + b.zz + bc.Ppp.zz};
     return g;
+}
+
+// Residual-side point geometry: what lk_residual_kernel needs of KILO.cc:126-140 WITHOUT materialising the 3x3
+// covariances.  The matcher and the observation row only ever consume  n^T var n  for a candidate normal n
+// (voxel_map.cc:384-388, KILO.cc:205-206), and with body_cov = alpha d d^T + beta I (calc_body_cov above),
+// K = [p_i]x, u = R^T n, m = (R ext_R)^T n = ext_R^T u:
+//   n^T (R ext_R) body_cov (R ext_R)^T n = alpha (d.m)^2 + beta (m.m),      d.m = (pb.m) / |pb|
+//   n^T (R K) P_rr (R K)^T n            = w^T P_rr w,  w = p_i x u  (= the rotation part of the H row, KILO.cc:197-199)
+//   n^T P_pp n
+// These are identities in exact arithmetic for ANY R / ext_R (no orthonormality is assumed); in fp64 they differ
+// from the reference's matrix route by rounding only (~1e-16 relative), ~60 flops per candidate instead of ~230 per
+// point + 12 per candidate, and ~40 fewer live VGPRs.
+struct PointLite {
+    V3 p_i, p_w, pb;       // pb: body point with the z == 0 guard of calcBodyCov applied
+    double alpha_n, beta;  // alpha / |pb|^2, beta
+};
+__device__ __forceinline__ PointLite point_lite(float bx, float by, float bz, const BucketConst& bc, const LkParams& pr) {
+    PointLite g;
+    V3 pb = V3{(double)bx, (double)by, (double)bz};
+    V3 e = mat3_mul_v(pr.ext_R, pb);
+    g.p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
+    V3 w = mat3_mul_v(bc.R, g.p_i);
+    g.p_w = V3{w.x + bc.p[0], w.y + bc.p[1], w.z + bc.p[2]};
+    if (pb.z == 0) pb.z = 0.0001;
+    g.pb = pb;
+    const double n2 = dot3(pb.x, pb.x, pb.y, pb.y, pb.z, pb.z);
+    const double r = (double)(float)sqrt(n2);            // float range, voxel_map.cc:24
+    g.beta = (r * r) * pr.dir_var;
+    g.alpha_n = ((double)pr.range_var - g.beta) / n2;
+    return g;
+}
+struct PlaneTerms {  // per (point, candidate normal)
+    V3 w;            // p_i x (R^T n)
+    double ta;       // n^T (R ext_R) body_cov (R ext_R)^T n
+};
+__device__ __forceinline__ PlaneTerms plane_terms(const PointLite& g, const BucketConst& bc, const LkParams& pr, V3 n) {
+    PlaneTerms t;
+    const V3 u = mat3T_mul_v(bc.R, n);
+    const V3 m = mat3T_mul_v(pr.ext_R, u);
+    const double dm = dot3(g.pb.x, m.x, g.pb.y, m.y, g.pb.z, m.z);
+    const double mm = dot3(m.x, m.x, m.y, m.y, m.z, m.z);
+    t.ta = __builtin_fma(g.alpha_n * dm, dm, g.beta * mm);
+    t.w = V3{-g.p_i.z * u.y + g.p_i.y * u.z, g.p_i.z * u.x - g.p_i.x * u.z, -g.p_i.y * u.x + g.p_i.x * u.y};
+    return t;
 }
 
 // ---------------------------------------------------------------- voxel keys and hash

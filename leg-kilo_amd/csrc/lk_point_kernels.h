@@ -20,12 +20,10 @@
 struct Match {
     int node;
     int layer;
-#if !LK_OPT_SLIM
     V3 n;          // plane normal
-    V3 c;          // plane center
-#endif
+    V3 w;          // p_i x (R^T n): rotation part of the H row
     float dis;     // signed distance stored as float (voxel_map.h:92, .cc:401-402)
-    double sig_pl; // J_nq * plane_var * J_nq^T
+    double sig_r;  // J_nq plane_var J_nq^T + n^T (R ext_R) body_cov (R ext_R)^T n  (KILO.cc:205-206, before lidar_ratio)
     double lazy_d, lazy_sig;  // |d| and sigma_l of the first passing candidate (deferred probability)
 };
 
@@ -33,8 +31,9 @@ struct Match {
 // normal, d, radius, flags), already in registers; the remaining 80 B (S11, w, s22) are requested BEFORE the float
 // range gate is evaluated so that the whole record costs one memory round trip.
 __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, double2 q0, double2 q1, double2 q2,
-                                           float pd, float pradius, int node, int layer, const PointGeom& g,
-                                           double sigma_num, bool& success, double& prob, Match& best) {
+                                           float pd, float pradius, int node, int layer, const PointLite& g,
+                                           const BucketConst& bc, const LkParams& pr, bool& success, double& prob,
+                                           Match& best) {
     const double2* sv = reinterpret_cast<const double2*>(mr->s11);  // byte offset 64, 16-B aligned
     const double2 v0 = sv[0], v1 = sv[1], v2 = sv[2], v3 = sv[3], v4 = sv[4];
     V3 c = V3{q0.x, q0.y, q1.x}, n = V3{q1.y, q2.x, q2.y};
@@ -47,13 +46,17 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
     const V3 q = V3{g.p_w.x - c.x, g.p_w.y - c.y, g.p_w.z - c.z};
     const S3 s11 = S3{v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
     // J plane_var J^T = q^T S11 q - 2 q.w + s22   (w = S12 n, s22 = n^T S22 n precomputed per plane)
-    double sig_pl = quad3(s11, q) - 2.0 * dot3(q.x, v3.x, q.y, v3.y, q.z, v4.x) + v4.y;
-    double sigma_l = sig_pl + quad3(g.var, n);
-    if (!((double)dis_to_plane < sigma_num * sqrt(sigma_l))) return;
+    const double sig_pl = quad3(s11, q) - 2.0 * dot3(q.x, v3.x, q.y, v3.y, q.z, v4.x) + v4.y;
+    const PlaneTerms t = plane_terms(g, bc, pr, n);
+    const double sig_r = sig_pl + t.ta;
+    const double sigma_l = sig_r + (quad3(bc.Prr, t.w) + quad3(bc.Ppp, n));
+    // 3-sigma gate  |d| < sigma_num sqrt(sigma_l)  (voxel_map.cc:388) in squared form: both sides are >= 0, and a
+    // negative / NaN sigma_l fails either way
+    const double d2 = (double)dis_to_plane * (double)dis_to_plane;
+    if (!(d2 < (pr.sigma_num * pr.sigma_num) * sigma_l)) return;
     // prob = exp(-d^2 / 2 sigma) / sqrt(sigma) only ranks candidates (voxel_map.cc:389-391).  The first passing
     // candidate always wins against prob = 0 (the 3-sigma gate bounds the exponent by -4.5), so its value is
     // only computed if a second candidate passes; `prob` < 0 encodes "first candidate, value not yet computed".
-    const double ssig = sqrt(sigma_l);
     bool take;
     if (!success) {
         take = true;
@@ -63,7 +66,7 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
     } else {
         if (prob < 0.0)
             prob = 1.0 / (sqrt(best.lazy_sig)) * exp(-0.5 * best.lazy_d * best.lazy_d / best.lazy_sig);
-        const double this_prob = 1.0 / ssig * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
+        const double this_prob = 1.0 / sqrt(sigma_l) * exp(-0.5 * d2 / sigma_l);
         take = this_prob > prob;
         if (take) prob = this_prob;
     }
@@ -71,20 +74,19 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
     if (take) {
         best.node = node;
         best.layer = layer;
-#if !LK_OPT_SLIM
         best.n = n;
-        best.c = c;
-#endif
+        best.w = t.w;
         best.dis = (float)sd;
-        best.sig_pl = sig_pl;
+        best.sig_r = sig_r;
     }
 }
 
 // build_single_residual (voxel_map.cc:363-427): pre-order DFS, children in index order, written as ONE flat loop
 // (a single copy of the plane evaluation in the instruction stream; the <=5-deep path lives in scalar registers
 // selected with compares, so no dynamically indexed private array / scratch is needed).
-__device__ __forceinline__ void match_root(const LkMap& m, int root, int max_layer, const PointGeom& g, double sigma_num,
-                                           bool& success, double& prob, Match& best) {
+__device__ __forceinline__ void match_root(const LkMap& m, int root, const PointLite& g, const BucketConst& bc,
+                                           const LkParams& pr, bool& success, double& prob, Match& best) {
+    const int max_layer = pr.max_layer;
     int n0 = root, n1 = -1, n2 = -1, n3 = -1, n4 = -1;
     unsigned int cis = 0;  // next child index of each level, 4 bits per level
     int level = 0;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void match_root(const LkMap& m, int root, int max_lay
             double2 q0 = q[0], q1 = q[1], q2 = q[2];
             const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad
             if (__float_as_uint(tail.z) & LK_PLANE_IS_PLANE) {
-                eval_plane(pl, q0, q1, q2, tail.x, tail.y, node, level, g, sigma_num, success, prob, best);
+                eval_plane(pl, q0, q1, q2, tail.x, tail.y, node, level, g, bc, pr, success, prob, best);
                 --level;
                 fresh = false;
                 continue;
@@ -151,26 +153,12 @@ __device__ __forceinline__ void neighbour_key(const LkParams& pr, const float* l
     }
 }
 
-// KILO.cc:195-209: h (1x6), z, R for a matched point
-__device__ __forceinline__ void obs_row(const LkMap& m, const Match& b, const PointGeom& g, const BucketConst& bc,
-                                        double ratio, double* h, double& z, double& R) {
-#if LK_OPT_SLIM
-    // the winner's normal is re-read (an L1/L2 hit) instead of being carried through the tree walk
-    const double2* q = reinterpret_cast<const double2*>(&m.match[b.node]);
-    const double2 q1 = q[1], q2 = q[2];
-    const V3 bn = V3{q1.y, q2.x, q2.y};
-#else
-    const V3 bn = b.n;
-#endif
-    V3 u = mat3T_mul_v(bc.R, bn);  // R^T n
-    // crossmat(p_i) * u
-    h[0] = -g.p_i.z * u.y + g.p_i.y * u.z;
-    h[1] = g.p_i.z * u.x - g.p_i.x * u.z;
-    h[2] = -g.p_i.y * u.x + g.p_i.x * u.y;
-    h[3] = bn.x, h[4] = bn.y, h[5] = bn.z;
+// KILO.cc:195-209: h (1x6), z, R for a matched point — everything was already derived while gating the winner
+__device__ __forceinline__ void obs_row(const Match& b, double ratio, double* h, double& z, double& R) {
+    h[0] = b.w.x, h[1] = b.w.y, h[2] = b.w.z;
+    h[3] = b.n.x, h[4] = b.n.y, h[5] = b.n.z;
     z = -(double)b.dis;
-    S3 vb = congruence(bc.RE, g.body);  // (R ext_R) body_cov (R ext_R)^T, no state covariance (KILO.cc:205-206)
-    R = ratio * (b.sig_pl + quad3(vb, bn));
+    R = ratio * b.sig_r;  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
 }
 
 struct ResidualOut {       // optional per-point outputs (config 2 / lk_residuals); any may be null
@@ -183,7 +171,7 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 
 // LDS row record of one point: h(6), z, 1/R, R   (9 doubles; stride 9 keeps 64-bit LDS reads conflict-free
 // for the access pattern of the reduction: lanes of one half-wave read the SAME row, i.e. broadcasts)
-#define LK_ROW2 10  // doubles per row: h(6) z 1/R R valid
+#define LK_ROW2 15  // doubles per row: h(6) z | h(6)/R | R valid   (odd stride)
 
 #if LK_OPT_WAVES
 #define LK_RES_BOUNDS __launch_bounds__(LK_PB, LK_OPT_WAVES)
@@ -196,7 +184,7 @@ __global__ void LK_RES_BOUNDS
                        size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
                        ResidualOut out, size_t out_slot_stride) {
     // per-wave LDS region holding the wave's 64 observation rows (h6, z, 1/R, R)
-    __shared__ float4 stage[LK_PB / LK_WAVE][64 * LK_ROW2 / 2];
+    __shared__ double stage[LK_PB / LK_WAVE][64 * LK_ROW2];
 #ifdef LK_TIMING
     unsigned long long ts[8];
 #define LK_STAMP(k) ts[k] = __builtin_readcyclecounter()
@@ -212,14 +200,14 @@ __global__ void LK_RES_BOUNDS
     double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
     {
         BucketConst bc;
-        load_bucket_const(&filters[slot], pr, bc);
-        PointGeom g;
+        load_bucket_const<false>(&filters[slot], pr, bc);
+        PointLite g;
         float loc[3] = {0.f, 0.f, 0.f};
         int key[3] = {0, 0, 0}, near[3] = {0, 0, 0};
         int root = -1, nroot = -1;
         if (i < n) {
             const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
-            g = point_geom(p.x, p.y, p.z, bc, pr);
+            g = point_lite(p.x, p.y, p.z, bc, pr);
             if (out.world) {
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
                 reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
@@ -234,18 +222,18 @@ __global__ void LK_RES_BOUNDS
         Match best;
         best.node = -1;
         LK_STAMP(2);
-        if (root >= 0) match_root(map, root, pr.max_layer, g, pr.sigma_num, success, prob, best);
+        if (root >= 0) match_root(map, root, g, bc, pr, success, prob, best);
         LK_STAMP(3);
         // the one-neighbour retry (KILO.cc:156-178)
         if (root >= 0 && !success) {  // KILO.cc:156-178
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = hash_find(map, near[0], near[1], near[2]);
-            if (nroot >= 0) match_root(map, nroot, pr.max_layer, g, pr.sigma_num, success, prob, best);
+            if (nroot >= 0) match_root(map, nroot, g, bc, pr, success, prob, best);
         }
         LK_STAMP(4);
         ok = success;
-        if (ok) obs_row(map, best, g, bc, pr.lidar_ratio, h, z, R);
+        if (ok) obs_row(best, pr.lidar_ratio, h, z, R);
         LK_STAMP(5);
         if (EMIT_ROWS && i < n) {
             size_t o = (size_t)slot * out_slot_stride + i;
@@ -256,11 +244,11 @@ __global__ void LK_RES_BOUNDS
             for (int a = 0; a < 6; ++a) out.h6[o * 6 + a] = h[a];
         }
     }
-    // K3, per wave and without any block barrier.  Every lane stores its row [h(6) z 1/R R valid] (zeros when it
-    // did not match) in the wave's LDS region; lane (q = lane & 31, half = lane >> 5) then accumulates component q of
-    // [A(21) b(6) sumR count] over the 32 rows of its half, in row order, branch-free (ds_read_b64 broadcasts, all
-    // loads independent of the arithmetic); the two halves are combined with one DPP-free cross-lane read.
-    // One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
+    // K3, per wave and without any block barrier.  Every lane stores its row [h(6) z | h(6)/R | R valid] (zeros when
+    // it did not match) in the wave's LDS region; lane (q = lane & 31, half = lane >> 5) then accumulates component q
+    // of [A(21) b(6) sumR count] over the 32 rows of its half, in row order, branch-free and with ONE fma per row
+    // (ds_read_b64 broadcasts, all loads independent of the arithmetic); the two halves are combined with one
+    // cross-lane read.  One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
     double* rows = reinterpret_cast<double*>(&stage[wv][0]);
     {
         double* r = rows + lane * LK_ROW2;
@@ -268,9 +256,10 @@ __global__ void LK_RES_BOUNDS
 #pragma unroll
         for (int a = 0; a < 6; ++a) r[a] = h[a];   // h, z are zero for unmatched lanes
         r[6] = z;
-        r[7] = ri;
-        r[8] = ok ? R : 0.0;
-        r[9] = ok ? 1.0 : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) r[7 + a] = h[a] * ri;
+        r[13] = ok ? R : 0.0;
+        r[14] = ok ? 1.0 : 0.0;
     }
     LK_STAMP(6);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -279,32 +268,31 @@ __global__ void LK_RES_BOUNDS
     LK_STAMP(7);
     {
         const int q = lane & 31, half = lane >> 5;
-        int a = 0, b = 0;   // component -> operands: A(a,b) = sum h[a] ri h[b];  b-vector: h[a] ri z
-        if (q < 21) {
-            int rem = q;
-            while (rem >= 6 - a) {
-                rem -= 6 - a;
-                ++a;
+        int a = 0, b = 0;   // component q = sum over rows of r[a] * r[b]
+        if (q < 21) {       // A(i,j) = sum (h_i / R) h_j, upper triangle in row-major order
+            int i = 0, rem = q;
+            while (rem >= 6 - i) {
+                rem -= 6 - i;
+                ++i;
             }
-            b = a + rem;
-        } else if (q < 27) {
-            a = q - 21;
+            a = 7 + i;
+            b = i + rem;
+        } else if (q < 27) {  // b_i = sum (h_i / R) z
+            a = 7 + (q - 21);
             b = 6;
-        } else if (q == 27) {
-            a = 8;   // R * 1  (sumR):  r[8] * r[9] * r[9]... handled through the generic product below
-            b = 9;
-        } else {
-            a = 9;   // count: valid * valid
-            b = 9;
+        } else if (q == 27) {  // sum R
+            a = 13;
+            b = 14;
+        } else {               // count
+            a = 14;
+            b = 14;
         }
-        // generic product v = (r[a] * w) * r[b] with w = r[7] for A/b and w = 1 (i.e. r[9], the valid flag) otherwise
-        const int wsel = (q < 27) ? 7 : 9;
         const double* base = rows + (half * 32) * LK_ROW2;
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const double* r = base + j * LK_ROW2;
-            acc += (r[a] * r[wsel]) * r[b];
+            acc = __builtin_fma(r[a], r[b], acc);
         }
         acc += __shfl_xor(acc, 32, LK_WAVE);
         if (lane < LK_NPART) {
