@@ -18,7 +18,7 @@ Workload (BASELINE.json metric "LiDAR scans/sec (per-point ESKF update), 100k-pt
   extra     config 3 as one sequential stream with map insert (the reference's own semantics):
             latency-bound, reported as `stream_scans_per_s`.
 The JSON line carries `roofline` (dominant kernel = lk_residual_kernel, HBM bound, algorithmic
-288 B/point, duration from HIP events on the handle's stream) and `cpu_baseline` (the oracle — a
+176 B/point (SURVEY's 288 B figure is reported beside it), duration from HIP events on the handle's stream) and `cpu_baseline` (the oracle — a
 port, the reference cannot be built here — single thread, bounded sample of the same workload).
 """
 import argparse
@@ -39,7 +39,9 @@ import lk_pkg  # noqa: E402
 lk_pkg.load()
 from legkilo_amd import binding, config, replay, synth  # noqa: E402
 
-ALG_BYTES_RESIDUAL = 288   # scan pt 16 + hash slot 16 + plane record 240 + world pt 16
+ALG_BYTES_SURVEY = 288     # scan pt 16 + hash slot 16 + plane record 240 + world pt 16
+ALG_BYTES_RESIDUAL = 176   # what THIS layout must touch per point in batch replay: scan pt 16 + hash slot 16 + the 144-B match
+                           # record (the 240-B plane record is pre-reduced at map-update time; no world point is written)
 ALG_BYTES_FULL = 1016      # + update pass 728 (re-projection write, map append, amortised refit)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 N_PTS = 100_000
@@ -102,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scans-per-gpu", type=int, default=128)
+    ap.add_argument("--scans-per-gpu", type=int, default=1024, help="BASELINE config 5: a batch of 1024 scans (fits one GPU)")
     ap.add_argument("--unique-scans", type=int, default=16, help="distinct synthetic scans generated per GPU (tiled to the batch)")
     ap.add_argument("--map-warm", type=int, default=6)
     ap.add_argument("--stream-scans", type=int, default=6)
@@ -171,12 +173,17 @@ def main():
     xs = xs_u[tile].copy()
     xs[:, 9:12] += rngp.normal(0, 0.005, (S, 3))  # de-duplicate the tiled priors
     Ps = np.tile((1e-4 * np.eye(30)).reshape(1, 900), (S, 1))
-    allpts = np.concatenate([scans[u] for u in tile])
-    d_batch = torch.empty(allpts.nbytes, dtype=torch.uint8, device=dev)
-    g.h2d(d_batch.data_ptr(), allpts)
+    # the U unique scans go up once and are tiled ON the device; priors are resident too (re-armed per step by a D2D copy)
+    d_unique = torch.from_numpy(np.stack([np.ascontiguousarray(sc).view(np.uint8).reshape(-1) for sc in scans])).to(dev)
+    d_batch = d_unique[torch.from_numpy(tile).to(dev)].contiguous()
+    assert d_batch.numel() == S * N_PTS * 16
+    del d_unique
+    d_x = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
+    d_P = torch.from_numpy(np.ascontiguousarray(Ps)).to(dev)
+    torch.cuda.synchronize()
 
     def step():
-        g.batch_set_priors(xs, Ps)
+        g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S)
         poses = g.batch_replay_dev(d_batch.data_ptr(), S, N_PTS, 0.0, off, dt)
         if dist is not None:
             replay.gather_results(dist, replay.pose_rows(poses), world_size, dev)
@@ -215,17 +222,38 @@ def main():
     avg_res_ms = ms_res / max(n_res, 1)
     pts_per_launch = S * (N_PTS // N_BUCKETS)
     achieved = ALG_BYTES_RESIDUAL * pts_per_launch / (avg_res_ms * 1e-3) / 1e9 if n_res else 0.0
-    traffic = None
+    # HBM traffic per launch from the committed PMC pass (FETCH_SIZE / WRITE_SIZE, tools/gpu_profile.sh); when that
+    # pass used another batch size the measured bytes/point are scaled to this launch and the source says so
+    traffic, traffic_src, valu_frac = None, None, None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_residual.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc_file))
+            geo = next((v for v in pj.get("by_geometry", {}).values() if v.get("slots") == S), None)
+            if geo:
+                traffic, traffic_src = geo["hbm_bytes_per_launch"], f"rocprofv3 --pmc, {pj.get('tag')}, same launch geometry"
+            else:
+                big = max(pj.get("by_geometry", {}).values(), key=lambda v: v.get("slots", 0))
+                traffic = big["hbm_bytes_per_point"] * pts_per_launch
+                traffic_src = f"rocprofv3 --pmc, {pj.get('tag')}: {big['hbm_bytes_per_point']:.1f} B/point measured at {big['slots']} slots, scaled"
         except Exception:
             traffic = None
+    sq_file = os.path.join(ROOT, "profiles", "r01g_pmc_attrib.json")
+    if os.path.exists(sq_file) and n_res:
+        try:
+            sq = json.load(open(sq_file))
+            valu_per_wave = sq["SQ_INSTS_VALU"]["avg"] / sq["SQ_WAVES"]["avg"]
+            waves = pts_per_launch / 64
+            # one wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+            valu_frac = round(valu_per_wave * 4 * waves / (1024 * 2.4e9 * avg_res_ms * 1e-3), 3)
+        except Exception:
+            valu_frac = None
     roofline = {
         "kernel": "lk_residual_kernel<false>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "alg_bytes_per_point": ALG_BYTES_RESIDUAL, "points_per_launch": pts_per_launch,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "alg_bytes_per_point": ALG_BYTES_RESIDUAL, "survey_alg_bytes_per_point": ALG_BYTES_SURVEY,
+        "frac_at_survey_bytes": round(achieved * ALG_BYTES_SURVEY / ALG_BYTES_RESIDUAL / HBM_PEAK_GBS, 4),
+        "valu_issue_frac": valu_frac, "points_per_launch": pts_per_launch,
         "avg_launch_ms": round(avg_res_ms, 4), "launches": n_res,
         "whole_scan_alg_GBs": round(ALG_BYTES_RESIDUAL * N_PTS * value / 1e9, 1),
         "other_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items() if k != "residual"},
@@ -306,8 +334,8 @@ def main():
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config5 shard: batch replay of 100k-pt scans, 5 buckets x 20k, full ESKF update, "
-                                   "shared frozen voxel map (RCCL broadcast when N>1)",
+            "config": {"workload": f"config5: batch replay of {S} synthetic 100k-pt scans per GPU, 5 buckets x 20k, full "
+                                   "ESKF update, shared frozen voxel map (RCCL broadcast when N>1)",
                        "scans_per_gpu": S, "points_per_scan": N_PTS, "buckets": N_BUCKETS, "parallelism": f"replay-shard x{world_size}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }

@@ -280,6 +280,9 @@ int lk_process_raw_scan(lk_handle* h, const lk_point* raw, size_t n_raw, float l
  * scan s uses filter slot s (n_scans <= n_slots); all scans have n_pts points laid out
  * d_pts[s * n_pts + i]; bucket bounds are shared by all scans.  Inserts are disabled. */
 int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, size_t n_scans); /* per-scan priors */
+/* same, priors already resident in HBM (d_x36: n_scans x 36, d_P900: n_scans x 900); asynchronous on the handle's
+ * stream - a replay loop re-arms its batch without touching the host */
+int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P900, size_t n_scans);
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
 

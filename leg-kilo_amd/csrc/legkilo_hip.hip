@@ -1050,6 +1050,17 @@ int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, siz
     return LK_OK;
 }
 
+int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P900, size_t n_scans) {
+    CHECK_H(h);
+    if (n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans exceeds n_slots");
+    if (!d_x36 || !d_P900) return fail(h, LK_ERR_INVALID, "null prior buffer");
+    HIPCHK(h, hipMemcpy2DAsync(h->d_filters[0].x, sizeof(LkFilter), d_x36, sizeof(double) * 36, sizeof(double) * 36, n_scans,
+                               hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_filters[0].P, sizeof(LkFilter), d_P900, sizeof(double) * 900, sizeof(double) * 900, n_scans,
+                               hipMemcpyDeviceToDevice, h->stream));
+    return LK_OK;
+}
+
 __global__ void lk_set_times_kernel(LkFilter* filters, int n, double t) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n) filters[s].last_predict_t = t, filters[s].last_update_t = t;

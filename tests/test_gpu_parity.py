@@ -388,9 +388,19 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     allpts = np.concatenate(scans)
     d_pts = g.device_malloc(allpts.nbytes)
     g.h2d(d_pts, allpts)
-    g.batch_set_priors(np.array(xs), np.array(Ps))
+    if S == 7:   # priors already resident in HBM (lk_batch_set_priors_dev)
+        hx, hP = np.ascontiguousarray(np.array(xs)), np.ascontiguousarray(np.array(Ps).reshape(S, 900))
+        d_x, d_P = g.device_malloc(hx.nbytes), g.device_malloc(hP.nbytes)
+        g.h2d(d_x, hx)
+        g.h2d(d_P, hP)
+        g.batch_set_priors_dev(d_x, d_P, S)
+    else:
+        g.batch_set_priors(np.array(xs), np.array(Ps))
     poses = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
     g.device_free(d_pts)
+    if S == 7:
+        g.device_free(d_x)
+        g.device_free(d_P)
     for s in range(S):
         o.set_state(xs[s], Ps[s])
         o.set_times(0.0, 0.0)

@@ -4,13 +4,16 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 TAG=${1:-r01b}
+ONLY=${2:-}   # optional space-separated list of pass numbers to run, e.g. "1 2 7"
 ARGS="--steps 2 --warmup 0 --cpu-sample 0 --stream-scans 0 --map-warm 4 --unique-scans 8"
 cd /tmp && export TMPDIR=/tmp
+export LEGKILO_REPLAY_GROUPS=1   # whole-batch launches, comparable across rounds
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $line -d $OUT/pmc_${TAG}_$i -o bench -- python $REPO/bench.py $ARGS > $OUT/pmc_${TAG}_$i.log 2>&1
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $i "; then continue; fi
+  timeout 240 rocprofv3 --pmc $line -d $OUT/pmc_${TAG}_$i -o bench -- python $REPO/bench.py $ARGS > $OUT/pmc_${TAG}_$i.log 2>&1 < /dev/null
   echo "pass $i: $line -> $(ls $OUT/pmc_${TAG}_$i 2>/dev/null | head -1) $(grep -ciE 'error|invalid' $OUT/pmc_${TAG}_$i.log)"
 done <<'PASSES'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
