@@ -208,8 +208,8 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMemsetAsync(h->d_filters, 0, sizeof(LkFilter) * (size_t)cfg->n_slots, h->stream));
     HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * 900));
     HIPCHK(h, hipMemsetAsync(h->d_Q, 0, sizeof(double) * 900, h->stream));
-    size_t nblk_max = ((size_t)m.max_scan + LK_PB - 1) / LK_PB;
-    h->part_stride = nblk_max * (LK_PB / LK_WAVE) * LK_NPART;  // one partial record per wave
+    size_t nblk_max = ((size_t)m.max_scan + LK_RB - 1) / LK_RB;
+    h->part_stride = nblk_max * (LK_RB / LK_WAVE) * LK_NPART;  // one partial record per wave
     HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->part_stride * cfg->n_slots));
     HIPCHK(h, hipMalloc(&h->d_scan, sizeof(lk_point) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&h->d_world, sizeof(float) * 4 * (size_t)m.max_scan));
@@ -397,16 +397,17 @@ int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const 
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
     const int nblk = (n + LK_PB - 1) / LK_PB;
+    const int nblk_r = (n + LK_RB - 1) / LK_RB;
     hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, m);
     LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
     ro.world = d_world;
     LAUNCH(h, "residual",
-           hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, m, h->pr, h->d_filters,
+           hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
                               d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
     LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                           h->d_partials, nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
+                                           h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
@@ -555,9 +556,9 @@ int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, doub
     ro.R = h->d_rows + 7 * n;
     ro.valid = h->d_valid;
     ro.world = nullptr;
-    const int nblk = (int)((n + LK_PB - 1) / LK_PB);
+    const int nblk = (int)((n + LK_RB - 1) / LK_RB);
     LAUNCH(h, "residual_rows",
-           hipLaunchKernelGGL(lk_residual_kernel<true>, dim3(nblk, 1), dim3(LK_PB), 0, h->stream, h->map, h->pr, h->d_filters,
+           hipLaunchKernelGGL(lk_residual_kernel<true>, dim3(nblk, 1), dim3(LK_RB), 0, h->stream, h->map, h->pr, h->d_filters,
                               h->d_scan, (size_t)0, (int)n, h->d_partials, h->part_stride, ro, (size_t)0));
     HIPCHK(h, hipMemcpyAsync(h6, ro.h6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(z, ro.z, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -1078,12 +1079,6 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     HIPCHK(h, hipGetLastError());
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
-#ifdef LK_TIMING
-    static unsigned long long* d_ts = nullptr;
-    const size_t ts_waves = (size_t)S * ((h->map.max_scan + LK_PB - 1) / LK_PB) * (LK_PB / LK_WAVE);
-    if (!d_ts) hipMalloc(&d_ts, ts_waves * 10 * sizeof(unsigned long long));
-    ro.z = reinterpret_cast<double*>(d_ts);
-#endif
     // non-empty buckets; update(k) and predict(k+1) share one launch (the map is frozen: nothing reads the state in between)
     std::vector<size_t> live;
     for (size_t b = 0; b < n_buckets; ++b) {
@@ -1108,7 +1103,7 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
         const double t = t_begin + bucket_dt[b];
         const bool has_next = k + 1 < live.size();
         const double t_next = has_next ? t_begin + bucket_dt[live[k + 1]] : 0.0;
-        const int nblk = (nb + LK_PB - 1) / LK_PB;
+        const int nblk = (nb + LK_RB - 1) / LK_RB;
         for (int grp = 0; grp < ngroups; ++grp) {
             const int s0 = (int)((long)S * grp / ngroups), sn = (int)((long)S * (grp + 1) / ngroups) - s0;
             hipStream_t st = streams[grp];
@@ -1118,15 +1113,15 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
             if (ngroups == 1) {
                 if (k == 0)
                     LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
-                LAUNCH(h, "residual", hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_PB), 0, st, h->map, h->pr, fl,
+                LAUNCH(h, "residual", hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl,
                                                          pts, n_pts, nb, parts, h->part_stride, ro, (size_t)0));
                 LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts,
-                                                       nblk * (LK_PB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
+                                                       nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
             } else {
                 if (k == 0) hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
-                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_PB), 0, st, h->map, h->pr, fl, pts, n_pts, nb, parts,
+                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl, pts, n_pts, nb, parts,
                                    h->part_stride, ro, (size_t)0);
-                hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_PB / LK_WAVE), h->part_stride, t,
+                hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,
                                    h->d_Q, t_next, has_next ? 1 : 0);
             }
         }
@@ -1136,30 +1131,6 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
         HIPCHK(h, hipEventRecord(h->ev_join[g - 1], streams[g]));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[g - 1], 0));
     }
-#ifdef LK_TIMING
-    {
-        hipStreamSynchronize(h->stream);
-        int nb = (int)(bucket_off[n_buckets] - bucket_off[n_buckets - 1]);
-        size_t nw = (size_t)S * ((nb + LK_PB - 1) / LK_PB) * (LK_PB / LK_WAVE);
-        std::vector<unsigned long long> ts(nw * 10);
-        hipMemcpy(ts.data(), d_ts, ts.size() * 8, hipMemcpyDeviceToHost);
-        double acc[9] = {0};
-        unsigned long long tmin = ~0ull, tmax = 0;
-        for (size_t w = 0; w < nw; ++w) {
-            for (int k = 1; k <= 8; ++k) acc[k] += (double)(ts[w * 10 + k] - ts[w * 10 + k - 1]);
-            tmin = std::min(tmin, ts[w * 10]);
-            tmax = std::max(tmax, ts[w * 10 + 8]);
-        }
-        const char* nm[9] = {"", "load+geom", "key+hash", "stamp2", "root eval", "retry", "obs_row", "rows+ballot", "barrier..end"};
-        fprintf(stderr, "[LK_TIMING] waves %zu, kernel span %llu ticks; mean ticks per wave:", nw, tmax - tmin);
-        double tot = 0;
-        for (int k = 1; k <= 8; ++k) {
-            fprintf(stderr, " %s=%.0f", nm[k], acc[k] / nw);
-            tot += acc[k] / nw;
-        }
-        fprintf(stderr, " total=%.0f\n", tot);
-    }
-#endif
     if (out) {
         std::vector<lk_pose> tmp(n_scans);
         rc = fetch_poses(h, tmp.data(), S);

@@ -16,6 +16,10 @@
 #include "lk_device.h"
 
 #define LK_PB 256
+// The residual kernel runs ONE wave per workgroup: with no block barrier in it there is nothing to share, and the
+// scheduler can refill a SIMD slot the moment a wave retires instead of waiting for a 4-wave workgroup's worth of
+// slots and LDS (measured on the 1024-scan batch: 642 us per bucket at 256 threads, 582 at 128, 578 at 64).
+#define LK_RB 64
 
 struct Match {
     int node;
@@ -174,9 +178,9 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 #define LK_ROW2 15  // doubles per row: h(6) z | h(6)/R | R valid   (odd stride)
 
 #if LK_OPT_WAVES
-#define LK_RES_BOUNDS __launch_bounds__(LK_PB, LK_OPT_WAVES)
+#define LK_RES_BOUNDS __launch_bounds__(LK_RB, LK_OPT_WAVES)
 #else
-#define LK_RES_BOUNDS __launch_bounds__(LK_PB)
+#define LK_RES_BOUNDS __launch_bounds__(LK_RB)
 #endif
 template <bool EMIT_ROWS>
 __global__ void LK_RES_BOUNDS
@@ -184,18 +188,11 @@ __global__ void LK_RES_BOUNDS
                        size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
                        ResidualOut out, size_t out_slot_stride) {
     // per-wave LDS region holding the wave's 64 observation rows (h6, z, 1/R, R)
-    __shared__ double stage[LK_PB / LK_WAVE][64 * LK_ROW2];
-#ifdef LK_TIMING
-    unsigned long long ts[8];
-#define LK_STAMP(k) ts[k] = __builtin_readcyclecounter()
-#else
-#define LK_STAMP(k)
-#endif
-    LK_STAMP(0);
+    __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
     const int slot = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int i = blockIdx.x * LK_PB + tid;
+    const int i = blockIdx.x * LK_RB + tid;
     bool ok = false;
     double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
     {
@@ -212,7 +209,6 @@ __global__ void LK_RES_BOUNDS
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
                 reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
             }
-            LK_STAMP(1);
             key_trunc(g.p_w, pr, loc, key);
             root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
         }
@@ -221,9 +217,7 @@ __global__ void LK_RES_BOUNDS
         double prob = 0;
         Match best;
         best.node = -1;
-        LK_STAMP(2);
         if (root >= 0) match_root(map, root, g, bc, pr, success, prob, best);
-        LK_STAMP(3);
         // the one-neighbour retry (KILO.cc:156-178)
         if (root >= 0 && !success) {  // KILO.cc:156-178
             neighbour_key(pr, loc, key, near);
@@ -231,10 +225,8 @@ __global__ void LK_RES_BOUNDS
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = hash_find(map, near[0], near[1], near[2]);
             if (nroot >= 0) match_root(map, nroot, g, bc, pr, success, prob, best);
         }
-        LK_STAMP(4);
         ok = success;
         if (ok) obs_row(best, pr.lidar_ratio, h, z, R);
-        LK_STAMP(5);
         if (EMIT_ROWS && i < n) {
             size_t o = (size_t)slot * out_slot_stride + i;
             out.valid[o] = ok ? 1 : 0;
@@ -261,11 +253,9 @@ __global__ void LK_RES_BOUNDS
         r[13] = ok ? R : 0.0;
         r[14] = ok ? 1.0 : 0.0;
     }
-    LK_STAMP(6);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    LK_STAMP(7);
     {
         const int q = lane & 31, half = lane >> 5;
         int a = 0, b = 0;   // component q = sum over rows of r[a] * r[b]
@@ -296,20 +286,10 @@ __global__ void LK_RES_BOUNDS
         }
         acc += __shfl_xor(acc, 32, LK_WAVE);
         if (lane < LK_NPART) {
-            const size_t wave_id = (size_t)blockIdx.x * (LK_PB / LK_WAVE) + wv;
+            const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
             partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
         }
     }
-#ifdef LK_TIMING
-    if (lane == 0 && out.h6 == nullptr && out.z != nullptr) {  // timing build: out.z doubles as the stamp buffer
-        unsigned long long tend = __builtin_readcyclecounter();
-        size_t w = ((size_t)slot * gridDim.x + blockIdx.x) * (LK_PB / LK_WAVE) + wv;
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.z) + w * 10;
-        for (int k = 0; k < 8; ++k) dst[k] = ts[k];
-        dst[8] = tend;
-        dst[9] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID etc. (debug)
-    }
-#endif
 }
 
 // ---------------------------------------------------------------- find-or-create a root voxel
