@@ -62,7 +62,7 @@ def pmc(path, counter, kernel_like):
             "select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, value from counters_collection where counter_name=?", (counter,)):
         if kernel_like not in name:
             continue
-        out.setdefault((gx // max(wx, 1), gy), []).append(val)
+        out.setdefault((gx // max(wx, 1), gy, wx), []).append(val)
     return out
 
 
@@ -75,8 +75,8 @@ for k in sorted(set(fetch) | set(write)):
     w_ = write.get(k, [])
     favg = sum(f_) / len(f_) if f_ else None
     wavg = sum(w_) / len(w_) if w_ else None
-    pts = k[0] * 256 * k[1]
-    e = {"blocks_x": k[0], "slots": k[1], "launches": len(f_), "FETCH_SIZE_KiB": favg, "WRITE_SIZE_KiB": wavg,
+    pts = k[0] * k[2] * k[1]   # workgroups x threads (one point per thread) x slots
+    e = {"blocks_x": k[0], "slots": k[1], "workgroup": k[2], "launches": len(f_), "FETCH_SIZE_KiB": favg, "WRITE_SIZE_KiB": wavg,
          "points_upper": pts}
     if favg is not None and wavg is not None:
         e["hbm_bytes_per_launch"] = (2.0 * favg + wavg) * 1024.0
