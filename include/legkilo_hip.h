@@ -214,6 +214,20 @@ int lk_update_by_points(lk_handle* h, uint32_t slot, const double* h6, const dou
 int lk_update_by_imu(lk_handle* h, uint32_t slot, const double* ki_z6, const double* ki_R6);
 int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const double* ki_z, const double* ki_R, size_t M);
 
+/* ---- local map sliding: VoxelMapManager::mapSliding voxel_map.cc:552-569, clearMemOutOfMap voxel_map.cc:571-594
+ * (configured at KILO.cc:68-70: sliding_thresh, half_map_size, map_sliding_en - the caller's gate; the reference itself
+ * never calls them).  `position` is what the reference keeps in the public member position_last_ (voxel_map.h:199);
+ * the handle keeps last_slide_position (initially the origin, voxel_map.h:201).  A slide deletes every root voxel
+ * whose key is strictly outside [k - half_map_size, k + half_map_size]^3, k = floor(position / max_voxel_size), and
+ * compacts the node / point-block pools so that device memory is bounded by the live map.
+ * *slid = the reference's return value; *n_removed = deleted root voxels (either may be NULL). */
+int lk_map_slide(lk_handle* h, const double* position /*3*/, double sliding_thresh, int32_t half_map_size, int32_t* slid,
+                 uint32_t* n_removed);
+int lk_map_clear_outside(lk_handle* h, int32_t x_max, int32_t x_min, int32_t y_max, int32_t y_min, int32_t z_max, int32_t z_min,
+                         uint32_t* n_removed);
+/* read (set = 0) or write (set != 0) last_slide_position - part of a checkpoint */
+int lk_map_slide_position(lk_handle* h, int32_t set, double* last3);
+
 /* ---- VoxelMapManager surface (voxel_map.h:180-244) ---- */
 /* BuildVoxelMap(rot, rot_cov, pos_cov) with feats_down_world_/feats_down_body_ = the two clouds
  * (xyz f32, n x 3); rot/rot_cov/pos_cov are taken from slot 0 (KILO.cc:339). */

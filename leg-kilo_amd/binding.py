@@ -18,7 +18,7 @@ EXPORTS = [
     "lk_abi_version", "lk_create", "lk_destroy", "lk_last_error", "lk_set_state", "lk_get_state", "lk_set_Q", "lk_get_Q",
     "lk_init_process_cov_q", "lk_set_times", "lk_get_times", "lk_set_acc_norm", "lk_get_fx", "lk_get_function_f",
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
-    "lk_residuals", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
+    "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
     "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
@@ -170,6 +170,30 @@ class LegKiloHip:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._chk(self.L.lk_map_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    # ---- local map sliding (voxel_map.cc:552-594) ----
+    def map_slide(self, position, sliding_thresh=8.0, half_map_size=100):
+        """VoxelMapManager::mapSliding with position_last_ = position -> (slid, n_removed)."""
+        pos = _f64(position)
+        slid, nrem = C.c_int32(0), C.c_uint32(0)
+        self._chk(self.L.lk_map_slide(self.h, _p(pos), C.c_double(sliding_thresh), C.c_int32(int(half_map_size)),
+                                      C.byref(slid), C.byref(nrem)))
+        return bool(slid.value), int(nrem.value)
+
+    def map_clear_outside(self, x_max, x_min, y_max, y_min, z_max, z_min):
+        nrem = C.c_uint32(0)
+        self._chk(self.L.lk_map_clear_outside(self.h, *(C.c_int32(int(v)) for v in (x_max, x_min, y_max, y_min, z_max, z_min)),
+                                              C.byref(nrem)))
+        return int(nrem.value)
+
+    def get_last_slide_position(self):
+        out = np.zeros(3)
+        self._chk(self.L.lk_map_slide_position(self.h, C.c_int32(0), _p(out)))
+        return out
+
+    def set_last_slide_position(self, p):
+        p = _f64(p).copy()
+        self._chk(self.L.lk_map_slide_position(self.h, C.c_int32(1), _p(p)))
 
     def map_export(self):
         nbytes = C.c_size_t(0)

@@ -39,6 +39,7 @@ struct lk_handle {
     hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
     int replay_groups = 3;
+    double last_slide_position[3] = {0.0, 0.0, 0.0};  // voxel_map.h:201
     unsigned int hash_cap = 0;
     LkFilter* d_filters = nullptr;
     double* d_Q = nullptr;
@@ -565,6 +566,120 @@ int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, doub
     HIPCHK(h, hipMemcpyAsync(R, ro.R, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(valid, ro.valid, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
+// clearMemOutOfMap (voxel_map.cc:571-594) as a pool compaction; see lk_map_kernels.h
+static int clear_outside(lk_handle* h, const LkSlideBox& box, uint32_t* n_removed) {
+    if (n_removed) *n_removed = 0;
+    unsigned int ctr[LK_CTR_COUNT];
+    HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const unsigned int n_nodes = std::min(ctr[LK_CTR_NODES], h->map.max_nodes), n_blocks = std::min(ctr[LK_CTR_BLOCKS], h->map.max_blocks),
+                       n_roots = ctr[LK_CTR_ROOTS];
+    if (n_roots == 0) return LK_OK;
+    struct Scratch {  // freed on every exit path
+        std::vector<void*> p;
+        ~Scratch() {
+            for (void* q : p) hipFree(q);
+        }
+        void* get(size_t bytes) {
+            void* q = nullptr;
+            if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+            p.push_back(q);
+            return q;
+        }
+    } sc;
+    unsigned int* alive_node = (unsigned int*)sc.get(sizeof(unsigned int) * n_nodes);
+    unsigned int* alive_block = (unsigned int*)sc.get(sizeof(unsigned int) * std::max(n_blocks, 1u));
+    unsigned int* new_node = (unsigned int*)sc.get(sizeof(unsigned int) * n_nodes);
+    unsigned int* new_block = (unsigned int*)sc.get(sizeof(unsigned int) * std::max(n_blocks, 1u));
+    lk_root_rec* kept = (lk_root_rec*)sc.get(sizeof(lk_root_rec) * n_roots);
+    unsigned int* cnt = (unsigned int*)sc.get(sizeof(unsigned int) * 2);
+    if (!alive_node || !alive_block || !new_node || !new_block || !kept || !cnt) return fail(h, LK_ERR_HIP, "map slide: out of device memory");
+    HIPCHK(h, hipMemsetAsync(alive_node, 0, sizeof(unsigned int) * n_nodes, h->stream));
+    HIPCHK(h, hipMemsetAsync(alive_block, 0, sizeof(unsigned int) * std::max(n_blocks, 1u), h->stream));
+    HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(unsigned int) * 2, h->stream));
+    hipLaunchKernelGGL(lk_slide_mark_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, h->map, box, h->hash_cap,
+                       alive_node, alive_block, kept, cnt);
+    unsigned int hc[2];
+    HIPCHK(h, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (hc[0] + hc[1] != n_roots) return fail(h, LK_ERR_STATE, "hash table and root counter disagree");
+    if (n_removed) *n_removed = hc[1];
+    if (hc[1] == 0) return LK_OK;
+    // dense new ids
+    size_t t1 = 0, t2 = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, t1, alive_node, new_node, 0u, n_nodes, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, t2, alive_block, new_block, 0u, std::max(n_blocks, 1u), rocprim::plus<unsigned int>(), h->stream));
+    void* tmp = sc.get(std::max(t1, t2));
+    if (!tmp) return fail(h, LK_ERR_HIP, "map slide: out of device memory");
+    HIPCHK(h, rocprim::exclusive_scan(tmp, t1, alive_node, new_node, 0u, n_nodes, rocprim::plus<unsigned int>(), h->stream));
+    if (n_blocks)
+        HIPCHK(h, rocprim::exclusive_scan(tmp, t2, alive_block, new_block, 0u, n_blocks, rocprim::plus<unsigned int>(), h->stream));
+    unsigned int last[4] = {0, 0, 0, 0};  // new_node[n-1], alive_node[n-1], new_block[n-1], alive_block[n-1]
+    HIPCHK(h, hipMemcpyAsync(&last[0], new_node + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&last[1], alive_node + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    if (n_blocks) {
+        HIPCHK(h, hipMemcpyAsync(&last[2], new_block + n_blocks - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&last[3], alive_block + n_blocks - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const unsigned int live_nodes = last[0] + last[1], live_blocks = last[2] + last[3];
+    lk_node_rec* tn = (lk_node_rec*)sc.get(sizeof(lk_node_rec) * live_nodes);
+    lk_plane_rec* tp = (lk_plane_rec*)sc.get(sizeof(lk_plane_rec) * live_nodes);
+    lk_match_rec* tm = (lk_match_rec*)sc.get(sizeof(lk_match_rec) * live_nodes);
+    lk_block_rec* tb = (lk_block_rec*)sc.get(sizeof(lk_block_rec) * std::max(live_blocks, 1u));
+    if (!tn || !tp || !tm || !tb) return fail(h, LK_ERR_HIP, "map slide: out of device memory");
+    hipLaunchKernelGGL(lk_slide_move_nodes_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, h->stream, h->map, n_nodes, alive_node,
+                       new_node, new_block, tn, tp, tm);
+    if (n_blocks)
+        hipLaunchKernelGGL(lk_slide_move_blocks_kernel, dim3(n_blocks), dim3(64), 0, h->stream, h->map, alive_block, new_block, tb);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->map.nodes, tn, sizeof(lk_node_rec) * live_nodes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->map.planes, tp, sizeof(lk_plane_rec) * live_nodes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->map.match, tm, sizeof(lk_match_rec) * live_nodes, hipMemcpyDeviceToDevice, h->stream));
+    if (live_blocks)
+        HIPCHK(h, hipMemcpyAsync(h->map.blocks, tb, sizeof(lk_block_rec) * live_blocks, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(lk_slide_hash_clear_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, h->map, h->hash_cap);
+    if (hc[0]) {
+        hipLaunchKernelGGL(lk_slide_remap_roots_kernel, dim3((hc[0] + 255) / 256), dim3(256), 0, h->stream, kept, hc[0], new_node);
+        hipLaunchKernelGGL(lk_hash_insert_kernel, dim3((hc[0] + 255) / 256), dim3(256), 0, h->stream, h->map, h->pr, kept, (int)hc[0]);
+    }
+    hipLaunchKernelGGL(lk_slide_counters_kernel, dim3(1), dim3(1), 0, h->stream, h->map, live_nodes, live_blocks, hc[0]);
+    HIPCHK(h, hipGetLastError());
+    return check_map_errors(h);  // synchronises: the scratch buffers may be released after this
+}
+
+int lk_map_clear_outside(lk_handle* h, int32_t x_max, int32_t x_min, int32_t y_max, int32_t y_min, int32_t z_max, int32_t z_min,
+                         uint32_t* n_removed) {
+    CHECK_H(h);
+    return clear_outside(h, LkSlideBox{x_max, x_min, y_max, y_min, z_max, z_min}, n_removed);
+}
+
+int lk_map_slide(lk_handle* h, const double* position, double sliding_thresh, int32_t half_map_size, int32_t* slid, uint32_t* n_removed) {
+    CHECK_H(h);
+    if (!position) return fail(h, LK_ERR_INVALID, "position is null");
+    if (slid) *slid = 0;
+    if (n_removed) *n_removed = 0;
+    const double dx = position[0] - h->last_slide_position[0], dy = position[1] - h->last_slide_position[1],
+                 dz = position[2] - h->last_slide_position[2];
+    if (sqrt(dx * dx + dy * dy + dz * dz) < sliding_thresh) return LK_OK;  // voxel_map.cc:553
+    for (int i = 0; i < 3; ++i) h->last_slide_position[i] = position[i];
+    const double vs = h->cfg.max_voxel_size;  // the DOUBLE voxel size (voxel_map.cc:561)
+    const int ix = (int)floor(position[0] / vs), iy = (int)floor(position[1] / vs), iz = (int)floor(position[2] / vs);
+    if (slid) *slid = 1;
+    return clear_outside(h, LkSlideBox{ix + half_map_size, ix - half_map_size, iy + half_map_size, iy - half_map_size, iz + half_map_size,
+                                       iz - half_map_size}, n_removed);
+}
+
+int lk_map_slide_position(lk_handle* h, int32_t set, double* last3) {
+    CHECK_H(h);
+    if (!last3) return fail(h, LK_ERR_INVALID, "last3 is null");
+    for (int i = 0; i < 3; ++i) {
+        if (set) h->last_slide_position[i] = last3[i];
+        else last3[i] = h->last_slide_position[i];
+    }
     return LK_OK;
 }
 

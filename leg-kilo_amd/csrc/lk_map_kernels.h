@@ -1117,3 +1117,112 @@ __global__ void __launch_bounds__(256) lk_hash_insert_kernel(LkMap map, LkParams
     }
     atomicOr(&map.counters[LK_CTR_ERR], LK_E_HASH_FULL);
 }
+
+// ------------------------------------------------------------------ local map sliding (voxel_map.cc:552-594)
+// clearMemOutOfMap deletes every root voxel (and its whole octree) whose key lies strictly outside a key-space box.
+// Here that is a COMPACTION of the pools, so a long run's device memory is bounded by the live map:
+//   lk_slide_mark_kernel   one thread per hash slot: roots inside the box are appended to `kept` and their subtree's
+//                          nodes / point blocks flagged alive; roots outside are counted
+//   (rocPRIM exclusive scans of the two flag arrays give the dense new ids; order = old order, deterministic)
+//   lk_slide_move_*        copy alive records to their new index in temporaries, child / block links renumbered
+//   lk_slide_hash_clear + lk_slide_remap_roots + lk_hash_insert_kernel   rebuild the table from the kept roots
+// Nothing on the per-bucket path changes: allocation stays a bump pointer (+ the point-block free list, which is
+// emptied here because retired blocks are not alive).
+struct LkSlideBox {
+    int x_max, x_min, y_max, y_min, z_max, z_min;
+};
+
+__global__ void __launch_bounds__(256)
+    lk_slide_mark_kernel(LkMap map, LkSlideBox box, unsigned int n_hash, unsigned int* __restrict__ alive_node,
+                         unsigned int* __restrict__ alive_block, lk_root_rec* __restrict__ kept,
+                         unsigned int* __restrict__ cnt /* [0] kept, [1] removed */) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hash) return;
+    const int4 e = map.hash[i];
+    if (e.w < 0) return;
+    const bool should_remove = e.x > box.x_max || e.x < box.x_min || e.y > box.y_max || e.y < box.y_min ||
+                               e.z > box.z_max || e.z < box.z_min;  // voxel_map.cc:578-579
+    if (should_remove) {
+        atomicAdd(&cnt[1], 1u);
+        return;
+    }
+    const unsigned int k = atomicAdd(&cnt[0], 1u);
+    kept[k].key[0] = e.x, kept[k].key[1] = e.y, kept[k].key[2] = e.z;
+    kept[k].node = e.w;
+    // pre-order walk of the subtree (depth <= LK_MAX_LAYER)
+    int st_node[LK_MAX_LAYER + 2], st_ci[LK_MAX_LAYER + 2];
+    int depth = 0;
+    st_node[0] = e.w, st_ci[0] = 0;
+    alive_node[e.w] = 1u;
+    {
+        const int b = map.nodes[e.w].block;
+        if (b >= 0) alive_block[b] = 1u;
+    }
+    while (depth >= 0) {
+        const int ci = st_ci[depth];
+        if (ci == 8) {
+            --depth;
+            continue;
+        }
+        st_ci[depth] = ci + 1;
+        const int child = map.nodes[st_node[depth]].child[ci];
+        if (child < 0) continue;
+        alive_node[child] = 1u;
+        const int b = map.nodes[child].block;
+        if (b >= 0) alive_block[b] = 1u;
+        if (depth + 1 < LK_MAX_LAYER + 2) {
+            ++depth;
+            st_node[depth] = child, st_ci[depth] = 0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    lk_slide_move_nodes_kernel(LkMap map, unsigned int n_nodes, const unsigned int* __restrict__ alive_node,
+                               const unsigned int* __restrict__ new_node, const unsigned int* __restrict__ new_block,
+                               lk_node_rec* __restrict__ tn, lk_plane_rec* __restrict__ tp, lk_match_rec* __restrict__ tm) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes || !alive_node[i]) return;
+    const unsigned int j = new_node[i];
+    lk_node_rec r = map.nodes[i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (r.child[c] >= 0) r.child[c] = (int)new_node[r.child[c]];
+    if (r.block >= 0) r.block = (int)new_block[r.block];
+    r.list_head = -1;  // bucket-local queue state is not carried across a slide
+    r.pad_[0] = 0;
+    tn[j] = r;
+    tp[j] = map.planes[i];
+    tm[j] = map.match[i];
+}
+
+// one 64-thread workgroup per alive point block (3744 B = 234 x 16 B)
+__global__ void __launch_bounds__(64)
+    lk_slide_move_blocks_kernel(LkMap map, const unsigned int* __restrict__ alive_block,
+                                const unsigned int* __restrict__ new_block, lk_block_rec* __restrict__ tb) {
+    const unsigned int b = blockIdx.x;
+    if (!alive_block[b]) return;
+    const uint4* src = reinterpret_cast<const uint4*>(&map.blocks[b]);
+    uint4* dst = reinterpret_cast<uint4*>(&tb[new_block[b]]);
+    for (unsigned int k = threadIdx.x; k < sizeof(lk_block_rec) / 16; k += 64) dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(256) lk_slide_hash_clear_kernel(LkMap map, unsigned int n_hash) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_hash) map.hash[i] = make_int4((int)0x80000000, (int)0x80000000, (int)0x80000000, LK_EMPTY);
+}
+
+__global__ void __launch_bounds__(256)
+    lk_slide_remap_roots_kernel(lk_root_rec* __restrict__ kept, unsigned int n, const unsigned int* __restrict__ new_node) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) kept[i].node = (int)new_node[kept[i].node];
+}
+
+__global__ void lk_slide_counters_kernel(LkMap map, unsigned int n_nodes, unsigned int n_blocks, unsigned int n_roots) {
+    map.counters[LK_CTR_NODES] = n_nodes;
+    map.counters[LK_CTR_BLOCKS] = n_blocks;
+    map.counters[LK_CTR_ROOTS] = n_roots;
+    map.counters[LK_CTR_FREE] = 0;
+    map.counters[LK_CTR_FREED] = 0;
+}
+

@@ -219,6 +219,18 @@ class VoxelMapManager {
         }
         dev_->check(lk_map_update(dev_->h(), pw.data(), var.data(), input_points.size()));
     }
+    // voxel_map.cc:552-569.  position_last_ is the public member the caller sets (voxel_map.h:199); last_slide_position
+    // (voxel_map.h:201) lives in the device handle.
+    Vec3D position_last_{};
+    bool mapSliding() {
+        int32_t slid = 0;
+        dev_->check(lk_map_slide(dev_->h(), position_last_.data(), config_setting_.sliding_thresh, config_setting_.half_map_size, &slid, nullptr));
+        return slid != 0;
+    }
+    // voxel_map.cc:571-594
+    void clearMemOutOfMap(const int& x_max, const int& x_min, const int& y_max, const int& y_min, const int& z_max, const int& z_min) {
+        dev_->check(lk_map_clear_outside(dev_->h(), x_max, x_min, y_max, y_min, z_max, z_min, nullptr));
+    }
     // Residual build of KILO.cc:122-210 for a whole bucket (replaces the per-point build_single_residual calls).
     void BuildResidualList(const PointCloudType& body, size_t i0, size_t i1, ObsShared& obs, std::vector<uint8_t>& valid) {
         size_t n = i1 - i0;

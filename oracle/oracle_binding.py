@@ -156,6 +156,27 @@ class Oracle:
         self.L.lko_residuals(self.h, _p(b), C.c_size_t(n), _p(h6), _p(z), _p(R), _p(valid))
         return h6, z, R, valid
 
+    def map_slide(self, position, sliding_thresh=8.0, half_map_size=100):
+        """VoxelMapManager::mapSliding (voxel_map.cc:552-569) -> (slid, n_removed)."""
+        pos = _f64(position)
+        slid, nrem = C.c_int(0), C.c_uint32(0)
+        self.L.lko_map_slide(self.h, _p(pos), C.c_double(sliding_thresh), C.c_int(half_map_size), C.byref(slid), C.byref(nrem))
+        return bool(slid.value), int(nrem.value)
+
+    def map_clear_outside(self, x_max, x_min, y_max, y_min, z_max, z_min):
+        nrem = C.c_uint32(0)
+        self.L.lko_map_clear_outside(self.h, *(C.c_int(int(v)) for v in (x_max, x_min, y_max, y_min, z_max, z_min)), C.byref(nrem))
+        return int(nrem.value)
+
+    def get_last_slide_position(self):
+        out = np.zeros(3)
+        self.L.lko_map_slide_position(self.h, 0, _p(out))
+        return out
+
+    def set_last_slide_position(self, p):
+        p = _f64(p).copy()
+        self.L.lko_map_slide_position(self.h, 1, _p(p))
+
     def map_export(self):
         nbytes = C.c_size_t(0)
         self.L.lko_map_export(self.h, None, C.byref(nbytes))

@@ -340,6 +340,31 @@ int lko_map_export(lko_handle* h, void* blob, size_t* bytes) {
     return 0;
 }
 
+// VoxelMapManager::mapSliding with the caller-set position_last_ and the two parameters of voxel_map.h:54,56
+int lko_map_slide(lko_handle* h, const double* position3, double sliding_thresh, int half_map_size, int* slid, uint32_t* n_removed) {
+    auto* m = h->kilo->map_manager_.get();
+    m->config_setting_.sliding_thresh = sliding_thresh;
+    m->config_setting_.half_map_size = half_map_size;
+    m->position_last_ = vec3(position3[0], position3[1], position3[2]);
+    const size_t before = m->voxel_map_.size();
+    const bool s = m->mapSliding();
+    if (slid) *slid = s ? 1 : 0;
+    if (n_removed) *n_removed = (uint32_t)(before - m->voxel_map_.size());
+    return 0;
+}
+int lko_map_clear_outside(lko_handle* h, int x_max, int x_min, int y_max, int y_min, int z_max, int z_min, uint32_t* n_removed) {
+    const int n = h->kilo->map_manager_->clearMemOutOfMap(x_max, x_min, y_max, y_min, z_max, z_min);
+    if (n_removed) *n_removed = (uint32_t)n;
+    return 0;
+}
+int lko_map_slide_position(lko_handle* h, int set, double* last3) {
+    auto* m = h->kilo->map_manager_.get();
+    for (int i = 0; i < 3; ++i) {
+        if (set) m->last_slide_position[i] = last3[i];
+        else last3[i] = m->last_slide_position[i];
+    }
+    return 0;
+}
 int lko_map_stats(lko_handle* h, uint32_t* n_roots) {
     *n_roots = (uint32_t)h->kilo->map_manager_->voxel_map_.size();
     return 0;

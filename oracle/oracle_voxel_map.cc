@@ -256,6 +256,35 @@ VoxelMapManager::~VoxelMapManager() {
     for (auto& kv : voxel_map_) delete kv.second;
 }
 
+// voxel_map.cc:552-569
+bool VoxelMapManager::mapSliding() {
+    if (norm(position_last_ - last_slide_position) < config_setting_.sliding_thresh) return false;
+    last_slide_position = position_last_;
+    Vec3i k = voxelKeyFloor(position_last_, config_setting_.max_voxel_size_);  // the DOUBLE voxel size here
+    const int hm = config_setting_.half_map_size;
+    clearMemOutOfMap(k[0] + hm, k[0] - hm, k[1] + hm, k[1] - hm, k[2] + hm, k[2] - hm);
+    return true;
+}
+
+// voxel_map.cc:571-594: erase (and delete) every root voxel whose key lies strictly outside the box.
+// Returns the number of deleted roots (the reference only counts them for a commented-out debug print).
+int VoxelMapManager::clearMemOutOfMap(int x_max, int x_min, int y_max, int y_min, int z_max, int z_min) {
+    int delete_voxel_cout = 0;
+    for (auto it = voxel_map_.begin(); it != voxel_map_.end();) {
+        const Vec3i& loc = it->first;
+        bool should_remove =
+            loc[0] > x_max || loc[0] < x_min || loc[1] > y_max || loc[1] < y_min || loc[2] > z_max || loc[2] < z_min;
+        if (should_remove) {
+            delete it->second;
+            it = voxel_map_.erase(it);
+            delete_voxel_cout++;
+        } else {
+            ++it;
+        }
+    }
+    return delete_voxel_cout;
+}
+
 // voxel_map.cc:287-334
 void VoxelMapManager::BuildVoxelMap(const Mat3 rot, const Mat3 rot_cov, const Mat3 pos_cov) {
     float voxel_size = config_setting_.max_voxel_size_;

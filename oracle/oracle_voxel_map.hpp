@@ -40,6 +40,10 @@ struct VoxelMapConfig {
     double beam_err_;
     double dept_err_;
     double sigma_num_;
+    // local map sliding, voxel_map.h:53-56 (loaded at KILO.cc:68-70; the reference never calls mapSliding itself)
+    double sliding_thresh = 8;
+    bool map_sliding_en = false;
+    int half_map_size = 100;
 };
 
 // voxel_map.h:59-78
@@ -122,6 +126,13 @@ class VoxelMapManager {
     void UpdateVoxelMap(const std::vector<pointWithVar>& input_points);          // voxel_map.cc:336-361
     void build_single_residual(pointWithVar& pv, const VoxelOctoTree* current_octo, const int current_layer,
                                bool& is_success, double& prob, PointToPlane& single_ptpl);  // voxel_map.cc:363-427
+
+    // local map sliding.  position_last_ is a public member the caller sets (voxel_map.h:199; nothing in the
+    // reference writes it), last_slide_position starts at the origin (voxel_map.h:201).
+    Vec3 position_last_ = Vec3::Zero();
+    Vec3 last_slide_position = Vec3::Zero();
+    bool mapSliding();                                                              // voxel_map.cc:552-569
+    int clearMemOutOfMap(int x_max, int x_min, int y_max, int y_min, int z_max, int z_min);  // voxel_map.cc:571-594
 };
 
 extern int voxel_plane_id;  // voxel_map.h:39

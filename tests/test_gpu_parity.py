@@ -475,6 +475,83 @@ def test_checkpoint_resume_is_bit_identical(scene, hip_lib, tmp_path):
     b.close()
 
 
+def count_tree(blob_bytes):
+    """(nodes, point blocks) reachable from the roots of a blob."""
+    cm = scenes.canon_map(blob_bytes)
+
+    def walk(n):
+        nn, nb = 1, 1 if n["pts"] is not None else 0
+        for c in n["children"].values():
+            a, b = walk(c)
+            nn, nb = nn + a, nb + b
+        return nn, nb
+
+    tot = [walk(n) for n in cm.values()]
+    return sum(t[0] for t in tot), sum(t[1] for t in tot)
+
+
+def test_map_sliding_parity_and_compaction(scene, oracle_lib, hip_lib, tmp_path):
+    """mapSliding / clearMemOutOfMap (voxel_map.cc:552-594).  Same decision, same surviving map as
+    the oracle; the device pools are COMPACTED to the live map; the path keeps running on the compacted pools with
+    results identical to the oracle's; last_slide_position travels with a checkpoint."""
+    from legkilo_amd import checkpoint
+
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 1.0
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0)
+    ro = scenes.replay_vlp(o, scene, t0, 3)
+    rg = scenes.replay_vlp(g, scene, t0, 3)
+    roots0, nodes0, blocks0 = g.map_stats()
+    pos = rg[-1][1][9:12]
+    # below the threshold (distance from the origin): no slide on either side
+    far = float(np.linalg.norm(pos)) + 1.0
+    assert o.map_slide(pos, sliding_thresh=far, half_map_size=4) == (False, 0)
+    assert g.map_slide(pos, sliding_thresh=far, half_map_size=4) == (False, 0)
+    assert g.map_stats() == (roots0, nodes0, blocks0)
+    # slide: keep +-8 voxels (4 m) around the robot
+    so = o.map_slide(ro[-1][1][9:12], sliding_thresh=0.0, half_map_size=8)
+    sg = g.map_slide(pos, sliding_thresh=0.0, half_map_size=8)
+    assert so == sg and sg[0] and 0 < sg[1] < roots0, (so, sg, roots0)
+    assert np.allclose(g.get_last_slide_position(), pos, rtol=0, atol=0)
+    blob_g = g.map_export()
+    scenes.compare_maps(o.map_export(), blob_g, rtol=1e-6, ptol=1e-7)
+    roots1, nodes1, blocks1 = g.map_stats()
+    live_nodes, live_blocks = count_tree(blob_g)
+    assert roots1 == roots0 - sg[1]
+    assert (nodes1, blocks1) == (live_nodes, live_blocks), "pools must be compacted to the live map"
+    assert nodes1 < nodes0
+    # a second call inside the threshold does nothing
+    assert o.map_slide(ro[-1][1][9:12], sliding_thresh=1.0, half_map_size=8) == (False, 0)
+    assert g.map_slide(pos, sliding_thresh=1.0, half_map_size=8) == (False, 0)
+    # the path keeps running on the compacted pools (new roots / children / blocks are bump-allocated again)
+    ro2 = scenes.replay_vlp(o, scene, t0, 3, start=3)
+    rg2 = scenes.replay_vlp(g, scene, t0, 3, start=3)
+    for k, ((po, xo), (pg, xg)) in enumerate(zip(ro2, rg2)):
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (pg.n_buckets, pg.n_updates, pg.n_effect), k
+        assert np.allclose(xo, xg, rtol=1e-7, atol=1e-8), (k, np.abs(xo - xg).max())
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-6, ptol=1e-6)
+    # clearMemOutOfMap with an explicit, asymmetric box
+    k = np.floor(pos / 0.5).astype(int)
+    box = (k[0] + 3, k[0] - 6, k[1] + 5, k[1] - 2, k[2] + 8, k[2] - 8)
+    assert o.map_clear_outside(*box) == g.map_clear_outside(*box)
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-6, ptol=1e-6)
+    # checkpoint carries last_slide_position
+    checkpoint.save(tmp_path / "ck.npz", g)
+    b = hip_lib.LegKiloHip(scene.cfg())
+    checkpoint.restore(tmp_path / "ck.npz", b)
+    assert np.array_equal(b.get_last_slide_position(), g.get_last_slide_position())
+    b.close()
+    # everything removed: an empty map is a valid map
+    roots_left = g.map_stats()[0]
+    assert g.map_clear_outside(-1000, -1001, 0, 0, 0, 0) == roots_left
+    assert g.map_stats() == (0, 0, 0)
+    g.close()
+    o.close()
+
+
 def test_no_device_fallback_is_loud(hip_lib, scene):
     bad = scene.cfg(device_id=99)
     with pytest.raises(hip_lib.LegKiloError):

@@ -203,3 +203,34 @@ def test_residual_gates_and_neighbour_retry(o):
     # x: 2.5 > 1.375 -> +1 ; y: +1 ; z: 1.02 > 0.875 -> +1  => neighbour (3,3,2) does not exist -> no match
     assert v[1] == 0
     assert R[0] > 0
+
+
+def test_map_sliding_semantics(o):
+    """voxel_map.cc:552-594: threshold on the travelled distance since the last slide (initially the origin), box in
+    KEY space centred on floor(position / max_voxel_size), strict comparisons, whole root voxels deleted."""
+    vs = 0.5
+    keys = [(x, 0, 0) for x in range(-8, 9)] + [(0, y, 0) for y in (-5, -4, 4, 5)] + [(0, 0, 3), (0, 0, -3)]
+    var = (np.eye(3) * 1e-4).reshape(1, 9)
+    for k in keys:
+        o.map_update(((np.array(k) + 0.5) * vs)[None, :], var)
+    assert set(scenes.canon_map(o.map_export())) == set(keys)
+    # travelled less than sliding_thresh since (0,0,0): nothing happens, last_slide_position keeps its value
+    assert o.map_slide([0.9, 0.0, 0.0], sliding_thresh=1.0, half_map_size=2) == (False, 0)
+    assert np.array_equal(o.get_last_slide_position(), [0.0, 0.0, 0.0])
+    # exactly at the threshold: `<` is false -> it slides.  k = floor(-1.0 / 0.5) = -2: box x in [-6, 2], y, z in [-4, 4]
+    slid, nrem = o.map_slide([-1.0, 0.0, 0.0], sliding_thresh=1.0, half_map_size=4)
+    left = set(scenes.canon_map(o.map_export()))
+    gone = set(keys) - left
+    assert slid and nrem == len(gone)
+    assert gone == {(-8, 0, 0), (-7, 0, 0)} | {(x, 0, 0) for x in range(3, 9)} | {(0, -5, 0), (0, 5, 0)}
+    assert (-6, 0, 0) in left and (2, 0, 0) in left and (0, 4, 0) in left and (0, -4, 0) in left   # on the faces: kept
+    assert np.array_equal(o.get_last_slide_position(), [-1.0, 0.0, 0.0])
+    # the distance is now measured from the new last_slide_position
+    assert o.map_slide([-1.5, 0.0, 0.0], sliding_thresh=1.0, half_map_size=1) == (False, 0)
+    # clearMemOutOfMap on its own, asymmetric box
+    n = o.map_clear_outside(1, -1, 0, 0, 3, 0)
+    left2 = set(scenes.canon_map(o.map_export()))
+    assert left2 == {(-1, 0, 0), (0, 0, 0), (1, 0, 0), (0, 0, 3)} and n == len(left) - len(left2)
+    # a surviving voxel keeps accepting points (the tree object was not touched)
+    o.map_update((np.array([0.25, 0.25, 0.25]))[None, :], var)
+    assert node_of(o, (0, 0, 0))["npts"] == 2
