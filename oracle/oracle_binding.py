@@ -177,6 +177,19 @@ class Oracle:
         p = _f64(p).copy()
         self.L.lko_map_slide_position(self.h, 1, _p(p))
 
+    def match_voxel(self, key, pw, var):
+        """build_single_residual on root voxel `key` (is_success = False, prob = 0 on entry) ->
+        dict(found, success, prob, normal, center, d, dis_to_plane, layer)."""
+        key = np.ascontiguousarray(key, dtype=np.int32)
+        pw, var = _f64(pw).reshape(3), _f64(var).reshape(9)
+        found, ok, layer = C.c_int(0), C.c_int(0), C.c_int(-1)
+        prob, d, dis = C.c_double(0), C.c_double(0), C.c_float(0)
+        n, c = np.zeros(3), np.zeros(3)
+        self.L.lko_match_voxel(self.h, _p(key), _p(pw), _p(var), C.byref(found), C.byref(ok), C.byref(prob), _p(n), _p(c),
+                               C.byref(d), C.byref(dis), C.byref(layer))
+        return dict(found=bool(found.value), success=bool(ok.value), prob=prob.value, normal=n, center=c, d=d.value,
+                    dis_to_plane=dis.value, layer=layer.value)
+
     def map_export(self):
         nbytes = C.c_size_t(0)
         self.L.lko_map_export(self.h, None, C.byref(nbytes))
@@ -230,11 +243,121 @@ class Oracle:
         return pose, w
 
 
+# ---- the reference's own eskf.cc / voxel_map.cc (oracle/_ref, built by `make ref` against oracle/shim) ----
+_REF_LIB = os.path.join(_HERE, "_ref", "liblegkilo_ref.so")
+_REF_SRC = "/root/reference/legkilo/src/core/slam/eskf.cc"
+_ref = None
+
+
+def build_ref(force=False):
+    """Compile oracle/_ref from the reference tree when it is present (this container); a prebuilt library is used
+    as is where the tree does not exist (GPU box).  Returns the path, or None when neither exists."""
+    if os.path.exists(_REF_SRC):
+        deps = [os.path.join(_HERE, "ref_capi.cc"), os.path.join(_HERE, "export_blob.hpp"), _REF_SRC,
+                _REF_SRC.replace("eskf.cc", "voxel_map.cc"), os.path.join(_HERE, "shim", "Eigen", "Dense")]
+        if force or not os.path.exists(_REF_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_REF_LIB) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "ref"], stdout=subprocess.DEVNULL)
+    return _REF_LIB if os.path.exists(_REF_LIB) else None
+
+
+class _Renamed:
+    """lko_* attribute access answered by the lkr_* symbol of the reference library."""
+
+    def __init__(self, cdll):
+        self._l = cdll
+
+    def __getattr__(self, name):
+        return getattr(self._l, name.replace("lko_", "lkr_", 1))
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        path = build_ref()
+        if path is None:
+            return None
+        l = C.CDLL(path)
+        l.lkr_create.restype = C.c_void_p
+        l.lkr_hash_vec3.restype = C.c_size_t
+        _ref = _Renamed(l)
+    return _ref
+
+
+class Reference(Oracle):
+    """The reference's OWN ESKF + VoxelMapManager (no KILO glue): the subset of the Oracle surface that eskf.cc and
+    voxel_map.cc implement — state / covariance access, predict, the three updates, BuildVoxelMap, UpdateVoxelMap,
+    build_single_residual on a voxel, map export / sliding."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.L = ref_lib()
+        assert self.L is not None, "oracle/_ref is not built and /root/reference is absent"
+        self.h = C.c_void_p(self.L.lko_create(C.byref(cfg), 1))
+
+
+def write_reference_yaml(path, params, imu_mode_only):
+    """A flat YAML with the keys KILO::initializeFromYaml reads (KILO.cc:25-83), from a parameter dict keyed like the
+    reference's config files (legkilo_amd.config.LEG_FUSION / DITER)."""
+    p = dict(params)
+    p.update(only_imu_use=bool(imu_mode_only))
+    p.setdefault("pub_plane_en", False)
+    p.setdefault("map_sliding_en", False)
+    p.setdefault("half_map_size", 100)
+    p.setdefault("sliding_thresh", 8)
+    with open(path, "w") as f:
+        for k, v in p.items():
+            if isinstance(v, bool):
+                v = "true" if v else "false"
+            elif isinstance(v, (list, tuple)):
+                v = "[" + ", ".join(repr(float(x)) if isinstance(x, float) else str(x) for x in v) + "]"
+            elif isinstance(v, float):
+                v = repr(v)
+            f.write(f"{k}: {v}\n")
+    return path
+
+
+class _RenamedK(_Renamed):
+    def __getattr__(self, name):
+        return getattr(self._l, name.replace("lko_", "lkk_", 1))
+
+
+class ReferenceKilo(Oracle):
+    """The reference's OWN legkilo::KILO: KILO::process (first frame, bucket loop, predictUpdatePoint / Imu / KinImu)
+    behind the whole-scan part of the Oracle surface (set/get_state, set_times, set_acc_norm, map_build, first_frame,
+    process_scan, map_export)."""
+
+    def __init__(self, params, imu_mode_only, yaml_path):
+        rl = ref_lib()
+        assert rl is not None, "oracle/_ref is not built and /root/reference is absent"
+        self.L = _RenamedK(rl._l)
+        self.L._l.lkk_create.restype = C.c_void_p
+        self.L._l.lkk_get_acc_norm.restype = C.c_double
+        write_reference_yaml(yaml_path, params, imu_mode_only)
+        self.h = C.c_void_p(self.L._l.lkk_create(str(yaml_path).encode()))
+        assert self.h, "KILO(config_file) failed"
+
+
+def _hooks(which):
+    return ref_lib() if which == "ref" else lib()
+
+
+def state_minus(xa, xb, which="oracle"):
+    xa, xb, d = _f64(xa), _f64(xb), np.zeros(30)
+    _hooks(which).lko_state_minus(_p(xa), _p(xb), _p(d))
+    return d
+
+
+def key_floor(p, voxel_size, which="oracle"):
+    p, k = _f64(p), np.zeros(3, dtype=np.int32)
+    _hooks(which).lko_key_floor(_p(p), C.c_double(voxel_size), _p(k))
+    return tuple(int(v) for v in k)
+
+
 # ---- unit-level hooks ----
-def calc_body_cov(pb, range_inc, degree_inc):
+def calc_body_cov(pb, range_inc, degree_inc, which="oracle"):
     pb = _f64(pb)
     cov = np.zeros(9)
-    lib().lko_calc_body_cov(_p(pb), C.c_float(range_inc), C.c_float(degree_inc), _p(cov))
+    _hooks(which).lko_calc_body_cov(_p(pb), C.c_float(range_inc), C.c_float(degree_inc), _p(cov))
     return cov.reshape(3, 3)
 
 
@@ -245,20 +368,20 @@ def eig_sym3(A):
     return ev, V.reshape(3, 3)
 
 
-def init_plane(pw, var9, planer_threshold=0.01):
+def init_plane(pw, var9, planer_threshold=0.01, which="oracle"):
     pw, var9 = _f64(pw), _f64(var9)
     rec = np.zeros(1, dtype=abi.blob_dtypes()[2])
     pv = np.zeros(36)
-    lib().lko_init_plane(_p(pw), _p(var9), C.c_size_t(len(pw)), C.c_float(planer_threshold), _p(rec), _p(pv))
+    _hooks(which).lko_init_plane(_p(pw), _p(var9), C.c_size_t(len(pw)), C.c_float(planer_threshold), _p(rec), _p(pv))
     return rec[0], pv.reshape(6, 6)
 
 
-def exp_log(v):
+def exp_log(v, which="oracle"):
     v = _f64(v)
     a, b, l = np.zeros(9), np.zeros(9), np.zeros(3)
-    lib().lko_exp_log(_p(v), _p(a), _p(b), _p(l))
+    _hooks(which).lko_exp_log(_p(v), _p(a), _p(b), _p(l))
     return a.reshape(3, 3), b.reshape(3, 3), l
 
 
-def hash_vec3(x, y, z):
-    return lib().lko_hash_vec3(C.c_int(x), C.c_int(y), C.c_int(z))
+def hash_vec3(x, y, z, which="oracle"):
+    return _hooks(which).lko_hash_vec3(C.c_int(x), C.c_int(y), C.c_int(z))

@@ -9,6 +9,7 @@
 #include <map>
 #include <string>
 
+#include "export_blob.hpp"
 #include "oracle_kilo.hpp"
 
 using namespace lko;
@@ -227,117 +228,12 @@ int lko_process_scan(lko_handle* h, const lk_point* sorted_pts, size_t n, double
     return 0;
 }
 
-// ---- blob export in the format of include/legkilo_hip.h (canonical order: roots sorted by key,
-//      nodes in DFS pre-order, children by octant index) ----
-namespace {
-struct Exporter {
-    std::vector<lk_root_rec> roots;
-    std::vector<lk_node_rec> nodes;
-    std::vector<lk_plane_rec> planes;
-    std::vector<lk_block_rec> blocks;
-    int max_layer;
-
-    int add(const VoxelOctoTree* t, const Vec3i* key) {
-        int id = (int)nodes.size();
-        nodes.emplace_back();
-        planes.emplace_back();
-        lk_node_rec n;
-        std::memset(&n, 0, sizeof(n));
-        lk_plane_rec p;
-        std::memset(&p, 0, sizeof(p));
-        for (int c = 0; c < 3; ++c) n.voxel_center[c] = t->voxel_center_[c];
-        n.quater_length = t->quater_length_;
-        n.layer = t->layer_;
-        n.npts = (int)t->temp_points_.size();
-        n.new_points = t->new_points_;
-        n.state = (t->init_octo_ ? LK_NODE_INIT_OCTO : 0u) | (t->update_enable_ ? LK_NODE_UPDATE_ENABLE : 0u) |
-                  (t->octo_state_ ? LK_NODE_OCTO_STATE : 0u);
-        n.block = -1;
-        n.list_head = -1;
-        if (key)
-            for (int c = 0; c < 3; ++c) n.key[c] = (*key)[c];
-        const VoxelPlane& pl = *t->plane_ptr_;
-        bool dead = t->init_octo_ && !pl.is_plane_ && t->layer_ < max_layer;  // points never read again
-        if (!dead && n.npts > 0) {
-            if (n.npts <= LK_BLOCK_PTS) {
-                n.block = (int)blocks.size();
-                blocks.emplace_back();
-                lk_block_rec& b = blocks.back();
-                std::memset(&b, 0, sizeof(b));
-                for (int i = 0; i < n.npts; ++i) {
-                    const pointWithVar& pv = t->temp_points_[i];
-                    for (int c = 0; c < 3; ++c) b.pts[i].pw[c] = pv.point_w[c];
-                    b.pts[i].var[0] = pv.var(0, 0), b.pts[i].var[1] = pv.var(0, 1), b.pts[i].var[2] = pv.var(0, 2);
-                    b.pts[i].var[3] = pv.var(1, 1), b.pts[i].var[4] = pv.var(1, 2), b.pts[i].var[5] = pv.var(2, 2);
-                }
-            } else {
-                n.state |= LK_NODE_PTS_DROPPED;
-            }
-        }
-        for (int c = 0; c < 3; ++c) p.center[c] = pl.center_[c], p.normal[c] = pl.normal_[c];
-        p.d = pl.d_;
-        p.radius = pl.radius_;
-        p.flags = (pl.is_plane_ ? LK_PLANE_IS_PLANE : 0u) | (pl.is_init_ ? LK_PLANE_IS_INIT : 0u);
-        p.points_size = pl.points_size_;
-        int k = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) p.plane_var[k++] = pl.plane_var_(r, c);
-        p.min_eigen_value = pl.min_eigen_value_;
-        p.mid_eigen_value = pl.mid_eigen_value_;
-        p.max_eigen_value = pl.max_eigen_value_;
-        for (int l = 0; l < 8; ++l) n.child[l] = -1;
-        nodes[id] = n;
-        planes[id] = p;
-        for (int l = 0; l < 8; ++l)
-            if (t->leaves_[l]) {
-                int cid = add(t->leaves_[l], nullptr);
-                nodes[id].child[l] = cid;
-            }
-        return id;
-    }
-};
-}  // namespace
-
+// ---- blob export in the format of include/legkilo_hip.h: export_blob.hpp (shared with the reference-side wrapper)
 int lko_map_export(lko_handle* h, void* blob, size_t* bytes) {
     auto& m = *h->kilo->map_manager_;
-    std::map<Vec3i, VoxelOctoTree*> sorted(m.voxel_map_.begin(), m.voxel_map_.end());
-    Exporter ex;
-    ex.max_layer = m.config_setting_.max_layer_;
-    for (auto& kv : sorted) {
-        int id = ex.add(kv.second, &kv.first);
-        ex.roots.push_back(lk_root_rec{{kv.first[0], kv.first[1], kv.first[2]}, id});
-    }
-    lk_blob_header hd;
-    std::memset(&hd, 0, sizeof(hd));
-    hd.magic = LK_BLOB_MAGIC;
-    hd.version = LK_ABI_VERSION;
-    hd.n_roots = (uint32_t)ex.roots.size();
-    hd.n_nodes = (uint32_t)ex.nodes.size();
-    hd.n_blocks = (uint32_t)ex.blocks.size();
-    hd.block_pts = LK_BLOCK_PTS;
-    hd.voxel_size = m.config_setting_.max_voxel_size_;
-    hd.max_layer = m.config_setting_.max_layer_;
-    hd.max_points_num = m.config_setting_.max_points_num_;
-    size_t total = sizeof(hd) + ex.roots.size() * sizeof(lk_root_rec) + ex.nodes.size() * sizeof(lk_node_rec) +
-                   ex.planes.size() * sizeof(lk_plane_rec) + ex.blocks.size() * sizeof(lk_block_rec);
-    hd.bytes = total;
-    if (!blob) {
-        *bytes = total;
-        return 0;
-    }
-    if (*bytes < total) return -1;
-    char* p = (char*)blob;
-    std::memcpy(p, &hd, sizeof(hd));
-    p += sizeof(hd);
-    std::memcpy(p, ex.roots.data(), ex.roots.size() * sizeof(lk_root_rec));
-    p += ex.roots.size() * sizeof(lk_root_rec);
-    std::memcpy(p, ex.nodes.data(), ex.nodes.size() * sizeof(lk_node_rec));
-    p += ex.nodes.size() * sizeof(lk_node_rec);
-    std::memcpy(p, ex.planes.data(), ex.planes.size() * sizeof(lk_plane_rec));
-    p += ex.planes.size() * sizeof(lk_plane_rec);
-    std::memcpy(p, ex.blocks.data(), ex.blocks.size() * sizeof(lk_block_rec));
-    *bytes = total;
-    return 0;
+    return lkx::export_map<VoxelOctoTree, VoxelPlane, pointWithVar>(m.voxel_map_, m.config_setting_.max_voxel_size_,
+                                                                   m.config_setting_.max_layer_,
+                                                                   m.config_setting_.max_points_num_, blob, bytes);
 }
 
 // VoxelMapManager::mapSliding with the caller-set position_last_ and the two parameters of voxel_map.h:54,56
@@ -363,6 +259,46 @@ int lko_map_slide_position(lko_handle* h, int set, double* last3) {
         if (set) m->last_slide_position[i] = last3[i];
         else last3[i] = m->last_slide_position[i];
     }
+    return 0;
+}
+// build_single_residual (voxel_map.cc:363-427) on the root voxel `key3`, started like KILO.cc:150-155
+int lko_match_voxel(lko_handle* h, const int* key3, const double* pw3, const double* var9, int* found, int* success,
+                    double* prob, double* normal3, double* center3, double* d, float* dis_to_plane, int* layer) {
+    auto& m = *h->kilo->map_manager_;
+    Vec3i key{key3[0], key3[1], key3[2]};
+    auto it = m.voxel_map_.find(key);
+    *found = it != m.voxel_map_.end();
+    *success = 0, *prob = 0;
+    if (!*found) return 0;
+    pointWithVar pv;
+    pv.point_w = vec3(pw3[0], pw3[1], pw3[2]);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) pv.var(r, c) = var9[3 * r + c];
+    PointToPlane pl;
+    bool ok = false;
+    double pr = 0;
+    m.build_single_residual(pv, it->second, 0, ok, pr, pl);
+    *success = ok ? 1 : 0;
+    *prob = pr;
+    if (ok) {
+        for (int c = 0; c < 3; ++c) normal3[c] = pl.normal_[c], center3[c] = pl.center_[c];
+        *d = pl.d_;
+        *dis_to_plane = pl.dis_to_plane_;
+        *layer = pl.layer_;
+    }
+    return 0;
+}
+int lko_state_minus(const double* xa36, const double* xb36, double* delta30) {
+    State a, b;
+    x36_to_state(xa36, a);
+    x36_to_state(xb36, b);
+    StateVec d = a - b;
+    for (int i = 0; i < 30; ++i) delta30[i] = d[i];
+    return 0;
+}
+int lko_key_floor(const double* p3, double voxel_size, int* key3) {
+    Vec3i k = voxelKeyFloor(vec3(p3[0], p3[1], p3[2]), voxel_size);
+    for (int i = 0; i < 3; ++i) key3[i] = k[i];
     return 0;
 }
 int lko_map_stats(lko_handle* h, uint32_t* n_roots) {

@@ -87,3 +87,56 @@ def test_host_mirror_example_runs(hip_lib):
     assert r.returncode == 0, r.stderr[-1500:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1500:])
+
+
+# ----------------------------------------------------------------------------- golden vectors made BY THE REFERENCE
+GR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kilo_small.npz")
+
+
+def replay_ref_golden(obj, g, mode):
+    """tests/golden/make_golden_ref.py's call sequence (KILO::process of the reference build, oracle/_ref)."""
+    obj.set_state(g[f"{mode}_x0"], 1e-6 * np.eye(30))
+    obj.init_process_cov_q()
+    obj.set_acc_norm(9.81)
+    t0 = float(g[f"{mode}_t0"])
+    obj.set_times(t0, t0)
+    obj.map_build(g[f"{mode}_build_world"], g[f"{mode}_build_body"])
+    po = np.r_[0, np.cumsum(g[f"{mode}_len"])]
+    ao = np.r_[0, np.cumsum(g[f"{mode}_aux_len"])]
+    for k in range(len(g[f"{mode}_len"])):
+        pts, aux = g[f"{mode}_pts"][po[k]:po[k + 1]], g[f"{mode}_aux"][ao[k]:ao[k + 1]]
+        kw = dict(kins=aux) if mode == "kin" else dict(imus=aux)
+        pose, _ = obj.process_scan(pts, float(g[f"{mode}_tb"][k]), **kw)
+        x, _ = obj.get_state()
+        yield k, pose, x
+
+
+def check_ref_golden(make, tol_state, tol_cov, ptol):
+    from legkilo_amd import config
+
+    g = np.load(GR)
+    for mode in ("imu", "kin"):
+        sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3) if mode == "kin" else None, **CAPS)
+        obj = make(sc, mode)
+        for k, pose, x in replay_ref_golden(obj, g, mode):
+            assert int(pose.n_effect) == int(g[f"{mode}_n_effect"][k]), (mode, k, pose.n_effect, g[f"{mode}_n_effect"][k])
+            assert np.allclose(x, g[f"{mode}_x"][k], rtol=0, atol=tol_state), (mode, k, np.abs(x - g[f"{mode}_x"][k]).max())
+        _, P = obj.get_state()
+        assert np.abs(P - g[f"{mode}_P"]).max() <= tol_cov * np.abs(g[f"{mode}_P"]).max(), mode
+        tp, tu = obj.get_times()
+        assert (tp, tu) == tuple(g[f"{mode}_times"]), mode
+        if mode == "imu":
+            scenes.compare_maps(g["imu_map_blob"], obj.map_export(), rtol=1e-5, ptol=ptol)
+        obj.close()
+
+
+def test_oracle_reproduces_what_the_reference_computed(oracle_lib):
+    """The oracle against outputs of the reference's own KILO::process (no reference tree needed to run this)."""
+    check_ref_golden(lambda sc, mode: oracle_lib.Oracle(sc.cfg(), imu_mode_only=(mode == "imu")), 1e-8, 1e-6, 1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_what_the_reference_computed(hip_lib):
+    """The HIP path, through the C-ABI, against outputs of the reference's own KILO::process: identical match counts
+    on every scan, states to 1e-6, the same map."""
+    check_ref_golden(lambda sc, mode: hip_lib.LegKiloHip(sc.cfg()), 1e-6, 1e-5, 1e-6)
