@@ -19,7 +19,8 @@ Workload (BASELINE.json metric "LiDAR scans/sec (per-point ESKF update), 100k-pt
             latency-bound, reported as `stream_scans_per_s`.
 The JSON line carries `roofline` (dominant kernel = lk_residual_kernel, HBM bound, algorithmic
 176 B/point (SURVEY's 288 B figure is reported beside it), duration from HIP events on the handle's stream) and `cpu_baseline` (the oracle — a
-port, the reference cannot be built here — single thread, bounded sample of the same workload).
+port: the reference build that pins it, oracle/_ref, only has the literal N x N update of eskf.cc:105-112,
+O(N^3) at 20 000 points per bucket, and cannot run this workload — single thread, bounded sample of the same workload).
 """
 import argparse
 import json

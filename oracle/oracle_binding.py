@@ -1,7 +1,8 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes wrapper over oracle/liblegkilo_oracle.so.
 
 Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-The product (leg-kilo_amd/) never imports this module.  PARITY UNPINNED (see smallmat.hpp).
+The product (leg-kilo_amd/) never imports this module.  Parity: pinned against oracle/_ref, the reference's own
+sources compiled here (see smallmat.hpp); `Reference` / `ReferenceKilo` below drive that build.
 """
 import ctypes as C
 import os

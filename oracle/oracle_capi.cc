@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 // extern "C" surface of liblegkilo_oracle.so, loaded with ctypes by tests/, by
 // __graft_entry__.smoke() and by bench.py's cpu_baseline leg — nowhere else.
 // Mirrors the lk_* calls of include/legkilo_hip.h with an lko_ prefix so a parity

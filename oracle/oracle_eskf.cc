@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 // Restatement of legkilo/src/core/slam/eskf.cc.
 #include "oracle_eskf.hpp"
 

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 //
 // CPU restatement of legkilo/src/core/slam/eskf.{h,cc}: the 30-dof error-state
 // Kalman filter.  Each function cites the reference lines it follows.

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 // Restatement of legkilo/src/core/slam/KILO.cc:86-399 and preprocess/state_initial.hpp:34-118.
 #include "oracle_kilo.hpp"
 

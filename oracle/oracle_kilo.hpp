@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 //
 // CPU restatement of the estimation part of legkilo/src/core/slam/KILO.cc
 // (:86-399) and of preprocess/state_initial.hpp:34-118.  ROS / PCL / YAML types

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 // Restatement of legkilo/src/core/slam/voxel_map.cc:22-427.
 #include "oracle_voxel_map.hpp"
 

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see smallmat.hpp header).  PARITY PINNED through oracle/_ref (see smallmat.hpp header).
 //
 // CPU restatement of legkilo/src/core/slam/voxel_map.{h,cc} (lines 22-427, the live
 // part: the viz / sliding code at :429-594 is dead in the reference and not restated)

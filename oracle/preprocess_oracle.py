@@ -6,7 +6,8 @@
       fields incl. `curvature` accumulated in float, divided by the count)
   std::sort by curvature at KILO.cc:369-370.
 
-PARITY UNPINNED: PCL's result order inside a cell (std::sort of (idx, point) pairs is unstable) and its output
+PARITY UNPINNED for THIS file (PCL and the ROS message decode cannot be built here; the path itself is pinned through
+oracle/_ref): PCL's result order inside a cell (std::sort of (idx, point) pairs is unstable) and its output
 order are not defined by the reference; this restatement fixes them: points of a cell are summed sequentially in
 input order (float32), cells are emitted in ascending idx, the time sort is stable.
 """

@@ -1,6 +1,13 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product; nothing under
-// leg-kilo_amd/ may include, link or call this.  PARITY UNPINNED: the reference
-// cannot be built here (no Eigen/PCL/ROS) and ships no golden vectors.
+// leg-kilo_amd/ may include, link or call this.
+//
+// PARITY: the reference ships no golden vectors, and its own build cannot run here (Eigen / PCL / ROS / glog /
+// yaml-cpp are absent).  The restatement is pinned all the same against the reference ITSELF: oracle/_ref is the
+// reference's eskf.cc, voxel_map.cc and KILO.cc compiled unmodified, where they lie, against the stand-in headers of
+// oracle/shim (oracle/Makefile, target `ref`); tests/test_reference_pin.py compares every routine and whole
+// KILO::process replays, and tests/golden/ref_kilo_small.npz holds outputs of that build.  What stays restated on
+// BOTH sides is third-party arithmetic only: Eigen's inverse() / EigenSolver (here: below; there: shim/Eigen/Dense),
+// pcl::VoxelGrid (identity on the pinned inputs) and the choice of the stable instance of KILO.cc's std::sort.
 //
 // Minimal dependency-free fp64 dense helpers standing in for the Eigen
 // operations the reference path uses (Eigen::Matrix products, PartialPivLU

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Generates tests/golden/path_small.npz with the ORACLE (the reference cannot be built or run here and
-ships no vectors of its own: SURVEY.md 4 / 8c — parity unpinned by the reference).
+"""Generates tests/golden/path_small.npz with the ORACLE (the reference ships no vectors of its own).
+The oracle itself is pinned against the reference's own sources (oracle/_ref, tests/test_reference_pin.py);
+make_golden_ref.py next to this file generates vectors with that reference build directly.
 
 The file is self-contained: inputs (first-frame clouds, prior state, query / bucket points) AND the oracle's
 outputs, so the GPU box needs neither /root/reference nor the synthetic generator to check against it.
