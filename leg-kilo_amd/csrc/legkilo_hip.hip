@@ -203,6 +203,8 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.slots, sizeof(int) * (size_t)LK_SLOTS * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.groups, sizeof(int) * 8 * 2 * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.gidx, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.free_list, sizeof(int) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&m.freed_next, sizeof(int) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
@@ -231,7 +233,7 @@ void lk_destroy(lk_handle* h) {
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
-                    h->map.next, h->map.slots, h->map.scratch, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
+                    h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -412,36 +414,19 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
-#ifdef LK_TIMING
-    if (do_insert && !h->map.dbg) hipMalloc(&h->map.dbg, sizeof(unsigned long long) * 4 * (size_t)h->map.max_scan);
-#endif
     if (do_insert) {
         LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
                                                      h->d_filters, d_pts, n));
-        // 1 wave per root, 1 resident wave per SIMD (255 VGPRs): 256 blocks x 4 waves is exactly one resident round on
-        // 256 CUs; more blocks would only be empty waves queueing for dispatch (the loop inside is grid-stride)
-        int grid = std::min(std::max((n + 3) / 4, 1), 256);
-        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+        // ordered part: group pass (one wave per root, light), apply pass (one wave per leaf group; 2 resident waves
+        // per SIMD at 206 VGPRs: 512 blocks x 4 waves is exactly one resident round on 256 CUs), then the generic
+        // fallback for the few groups that need it; all loops are grid-stride and read their work counts on the device
+        int grid = std::min(std::max((n + 3) / 4, 1), 512);
+        LAUNCH(h, "insert_group", hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                     h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
-#ifdef LK_TIMING
-        {
-            hipStreamSynchronize(h->stream);
-            unsigned int ctr[LK_CTR_COUNT];
-            hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost);
-            unsigned int nh = ctr[LK_CTR_HEAVY];
-            std::vector<unsigned long long> d(4 * (size_t)nh);
-            if (nh) hipMemcpy(d.data(), h->map.dbg, d.size() * 8, hipMemcpyDeviceToHost);
-            std::vector<size_t> order(nh);
-            for (size_t i = 0; i < nh; ++i) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return d[4 * a + 1] > d[4 * b + 1]; });
-            unsigned long long tot = 0, totm = 0;
-            for (size_t i = 0; i < nh; ++i) tot += d[4 * i + 1], totm += d[4 * i];
-            fprintf(stderr, "[LK_TIMING insert] n=%d touched=%u heavy=%u sum_m=%llu mean_cycles=%.0f; longest:", n, ctr[LK_CTR_TOUCHED], nh, totm, nh ? (double)tot / nh : 0.0);
-            for (size_t i = 0; i < std::min<size_t>(6, nh); ++i)
-                fprintf(stderr, " [m=%llu cyc=%llu kind=0x%llx]", d[4 * order[i]], d[4 * order[i] + 1], d[4 * order[i] + 2]);
-            fprintf(stderr, "\n");
-        }
-#endif
+        LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 64)), dim3(LK_MB), 0, h->stream,
+                                                        h->map, h->pr, h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
     }
     return LK_OK;
 }
@@ -530,8 +515,12 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
-    LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+    LAUNCH(h, "insert_pv_group", hipLaunchKernelGGL(lk_insert_group_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                    h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
+    LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_apply_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                               h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
+    LAUNCH(h, "insert_pv_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<true>, dim3(std::min(grid, 64)), dim3(LK_MB), 0, h->stream,
+                                                       h->map, h->pr, h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     int rc = check_map_errors(h);
     hipFree(d_pv);
     return rc;

@@ -40,7 +40,8 @@
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,
        LK_CTR_HEAVY = 6, LK_CTR_FREE = 7 /* signed: blocks poppable this bucket */, LK_CTR_FREED = 8 /* blocks retired
-       during this bucket */, LK_CTR_COUNT = 16 };
+       during this bucket */, LK_CTR_GROUPS = 9 /* leaf groups of this bucket */, LK_CTR_GIDX = 10 /* their indices */, LK_CTR_FALLBACK = 11 /* groups handed to the generic code */,
+       LK_CTR_COUNT = 16 };
 
 struct LkFilter {
     double x[LK_STATE_DOUBLES];  // rot(9) pos vel ba bw grav imu_a imu_w bv contact
@@ -110,10 +111,11 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     unsigned int* counters;      // LK_CTR_*
     int* touched;                // roots touched by the current bucket
     int* heavy;                  // subset of touched that needs the wave-per-root state machine
-    unsigned long long* dbg;     // LK_TIMING builds only: per heavy root {m, cycles, kind, root}
     int* next;                   // per-point list links (bucket-local index): overflow beyond LK_SLOTS
     int* slots;                  // [max_nodes][LK_SLOTS] bucket-local point indices queued on a root
     int* scratch;                // per-root gathered indices
+    int* groups;                 // 2 x [max_scan] x 8 ints: leaf-group descriptors of the current bucket (LkGroup), then the fallback items
+    int* gidx;                   // [max_scan] bucket-local point indices of the groups, input order inside a group
     int* free_list;              // point blocks that may be re-allocated during this bucket
     int* freed_next;             // point blocks retired during this bucket (allocatable from the next bucket on)
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;

@@ -1,6 +1,7 @@
 // lk_map_kernels.h — voxel-map mutation: one WAVE (64 lanes) owns one root voxel.
 //
-//   lk_insert_kernel      UpdateVoxelMap / UpdateOctoTree (voxel_map.cc:336-361, :185-241) for the points
+//   lk_insert_group_kernel + lk_insert_apply_kernel
+//                         UpdateVoxelMap / UpdateOctoTree (voxel_map.cc:336-361, :185-241) for the points
 //                         the re-projection kernel queued on each touched root.  Points of one root are
 //                         replayed in input order (successive-minimum selection over the root's list);
 //                         different roots are independent, so the order ACROSS roots is free.
@@ -554,30 +555,59 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
 // FROM_PV = false: points are re-derived from the scan (lk_point) and the post-update state — the same
 //                  point_geom() call the re-projection kernel hashed them with (bit-identical);
 // FROM_PV = true : points are caller-supplied pointWithVar records (VoxelMapManager::UpdateVoxelMap).
+// ------------------------------------------------------------------ the ordered insert, in two passes
+// Work unit = one LEAF GROUP: the points of this bucket that land in the same leaf (or in the same not-yet-existing
+// child) of one root voxel, in input order.  Groups of one root touch disjoint subtrees (distinct leaves; distinct
+// child slots of a parent), so they are independent; the order INSIDE a group is the input order, which the
+// reference's result depends on.
+//   lk_insert_group_kernel   one wave per root on the work list: sort the root's queued indices in registers, walk
+//                            every point (read-only) to its target, form the groups with ballots, and emit per group
+//                            a descriptor + its indices in order.  No octree state is written here (only the root's
+//                            bucket-local queue is reset).  Small and latency-light: ~40 VGPRs.
+//   lk_insert_apply_kernel   one wave per GROUP: the register simulation of voxel_map.cc:186-237 for that leaf, with
+//                            the per-point state machine as the fallback.  A root with six leaf groups is six work
+//                            items running side by side; before the split the slowest root (4-6 groups one after the
+//                            other, 80-150 k cycles against a mean of 36 k) set the kernel's duration.
+struct LkGroup {       // 32 B
+    int leaf;          // target leaf, or -1: child `oct` of `parent` has to be created first
+    int parent, oct;
+    int off, count;    // indices map.gidx[off .. off+count) in input order; LONG: map.scratch[off .. off+count) unsorted
+    int kind;          // 0 = leaf group, 1 = LONG (a root with more than 64 queued points: per-point replay)
+    int root, pad;
+};
+
+template <bool FROM_PV>
+__device__ __forceinline__ void insert_point_pw(const LkParams& pr, const BucketConst& bc, const lk_point* __restrict__ pts,
+                                                const lk_pt_rec* __restrict__ pv, int idx, double* pw) {
+    if (FROM_PV) {
+        pw[0] = pv[idx].pw[0], pw[1] = pv[idx].pw[1], pw[2] = pv[idx].pw[2];
+    } else {  // the same inlined transform as everywhere else (identical bits)
+        const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+        V3 pb = V3{(double)p.x, (double)p.y, (double)p.z};
+        V3 e = mat3_mul_v(pr.ext_R, pb);
+        V3 pi = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
+        V3 w = mat3_mul_v(bc.R, pi);
+        pw[0] = w.x + bc.p[0], pw[1] = w.y + bc.p[1], pw[2] = w.z + bc.p[2];
+    }
+}
+
 template <bool FROM_PV>
 __global__ void __launch_bounds__(LK_MB)
-    lk_insert_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                     const lk_pt_rec* __restrict__ pv, int n) {
+    lk_insert_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * LK_MB) >> 6;
     // scan points: only the roots the light pre-pass could not finish; pointWithVar input: every touched root
     const int n_touched = (int)map.counters[FROM_PV ? LK_CTR_TOUCHED : LK_CTR_HEAVY];
     const int* worklist = FROM_PV ? map.touched : map.heavy;
+    LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
     BucketConst bc;
-    if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
+    if (!FROM_PV) load_bucket_const<false>(&filters[0], pr, bc);
     for (int t = wave; t < n_touched; t += nwaves) {
         const int root = bcast0(worklist[t]);
         lk_node_rec* nd = &map.nodes[root];
         const int m = bcast0((int)nd->pad_[0]);
-#ifdef LK_TIMING
-        const unsigned long long t_begin = __builtin_readcyclecounter();
-        const unsigned int st0 = nd->state, pf0 = map.planes[root].flags;
-        struct DbgAtExit {
-            unsigned long long* p; unsigned long long t0; int m; unsigned int kind; int root; int lane;
-            __device__ ~DbgAtExit() { if (lane == 0 && p) { p[0] = (unsigned long long)m; p[1] = __builtin_readcyclecounter() - t0; p[2] = kind; p[3] = (unsigned long long)root; } }
-        } dbg_exit{map.dbg ? map.dbg + 4 * (size_t)t : nullptr, t_begin, m, (st0 & 7u) | ((pf0 & 1u) << 4), root, lane};
-#endif
         int base = 0;
         const bool in_slots = m <= LK_SLOTS;  // the common case: every queued index sits in the root's slot line
         if (in_slots) {
@@ -602,50 +632,49 @@ __global__ void __launch_bounds__(LK_MB)
             }
             wave_fence();
         }
-        auto point_of = [&](int idx, PtU& pt) {
-            if (FROM_PV) {
-                load_pt(pv, nullptr, idx, pt.pw, pt.var);
-            } else {
-                const float4 p = reinterpret_cast<const float4*>(pts)[idx];
-                PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
-                pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
-                pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
-                pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
+        if (m > LK_WAVE) {  // very long list: handed over whole
+            if (lane == 0) {
+                const unsigned int g = atomicAdd(&map.counters[LK_CTR_GROUPS], 1u);
+                if (g < map.max_scan) groups[g] = LkGroup{root, -1, 0, base, m, 1, root, 0};
+                else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
             }
-        };
-        if (m <= LK_WAVE) {
-            // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
-            const int myidx = (lane < m) ? (in_slots ? map.slots[(size_t)root * LK_SLOTS + lane] : map.scratch[base + lane]) : 0x7fffffff;
-            int rank = 0;
-            for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
-            const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
-            const bool mine = lane < m;
-            // every lane derives its point once and walks (read-only) to the node the point would be pushed into:
-            // down through initialised non-planar nodes below max_layer (voxel_map.cc:205-223); these never change
-            // again, so the walk is exact for the whole bucket.  tnode < 0: child `toct` of `tparent` does not exist.
-            PtU mypt;
-            int tnode = -1, tparent = -1, toct = 0;
-            if (mine) {
-                point_of(sidx, mypt);
-                int node = root;
-                for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
-                    const lk_node_rec* nr = &map.nodes[node];
-                    const unsigned int st = nr->state;
-                    const bool pl = (map.planes[node].flags & LK_PLANE_IS_PLANE) != 0;
-                    if (!(st & LK_NODE_INIT_OCTO) || pl || nr->layer >= pr.max_layer) {
-                        tnode = node;
-                        break;
-                    }
-                    const int oct = octant_of(mypt.pw, nr->voxel_center);
-                    const int child = nr->child[oct];
-                    if (child < 0) {
-                        tnode = -1, tparent = node, toct = oct;
-                        break;
-                    }
-                    node = child;
+            continue;
+        }
+        // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
+        const int myidx = (lane < m) ? (in_slots ? map.slots[(size_t)root * LK_SLOTS + lane] : map.scratch[base + lane]) : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
+        const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
+        const bool mine = lane < m;
+        // every lane walks (read-only) to the node its point would be pushed into: down through initialised
+        // non-planar nodes below max_layer (voxel_map.cc:205-223); these never change again, so the walk is exact
+        // for the whole bucket.  tnode < 0: child `toct` of `tparent` does not exist.
+        int tnode = -1, tparent = -1, toct = 0;
+        if (mine) {
+            double pw[3];
+            insert_point_pw<FROM_PV>(pr, bc, pts, pv, sidx, pw);
+            int node = root;
+            for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
+                const lk_node_rec* nr = &map.nodes[node];
+                const unsigned int st = nr->state;
+                const bool pl = (map.planes[node].flags & LK_PLANE_IS_PLANE) != 0;
+                if (!(st & LK_NODE_INIT_OCTO) || pl || nr->layer >= pr.max_layer) {
                     tnode = node;
+                    break;
                 }
+                const int oct = octant_of(pw, nr->voxel_center);
+                const int child = nr->child[oct];
+                if (child < 0) {
+                    tnode = -1, tparent = node, toct = oct;
+                    break;
+                }
+                node = child;
+                tnode = node;
             }
+        }
+        // one descriptor per distinct target; the group's indices in lane (= input) order
+        int ngroups = 0;
+        {
             unsigned long long todo = __ballot(mine);
             while (todo) {
                 const int leader = __ffsll((long long)todo) - 1;
@@ -653,156 +682,237 @@ __global__ void __launch_bounds__(LK_MB)
                           To = __builtin_amdgcn_readlane(toct, leader);
                 const unsigned long long grp = __ballot(mine && tnode == Tn && tparent == Tp && toct == To) & todo;
                 todo &= ~grp;
-                int leaf = Tn;
-                if (leaf < 0) {  // voxel_map.cc:214-222: first point of a new octant creates the child
-                    const lk_node_rec* pn = &map.nodes[Tp];
-                    double pc[3] = {pn->voxel_center[0], pn->voxel_center[1], pn->voxel_center[2]};
-                    leaf = create_child(map, Tp, To, pc, pn->quater_length, bcast0(pn->layer));
-                }
-                // ---------------- one leaf, its points = lanes of grp in lane (= input) order
-                lk_node_rec* ln = &map.nodes[leaf];
-                NodeRegs r = node_load(ln);
-                const bool lplane = (bcast0((int)map.planes[leaf].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+                ++ngroups;
+            }
+        }
+        int gbase = 0, ibase = 0;
+        if (lane == 0) {
+            gbase = (int)atomicAdd(&map.counters[LK_CTR_GROUPS], (unsigned int)ngroups);
+            ibase = (int)atomicAdd(&map.counters[LK_CTR_GIDX], (unsigned int)m);
+        }
+        gbase = bcast0(gbase), ibase = bcast0(ibase);
+        if (gbase + ngroups > (int)map.max_scan || ibase + m > (int)map.max_scan) {
+            if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+            continue;
+        }
+        {
+            unsigned long long todo = __ballot(mine);
+            int gi = 0, off = ibase;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int Tn = __builtin_amdgcn_readlane(tnode, leader), Tp = __builtin_amdgcn_readlane(tparent, leader),
+                          To = __builtin_amdgcn_readlane(toct, leader);
+                const unsigned long long grp = __ballot(mine && tnode == Tn && tparent == Tp && toct == To) & todo;
+                todo &= ~grp;
                 const int g = __popcll(grp);
-                const int L = r.layer;
-                const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
-                const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
-                const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
-                if (!uninit && !live && (lplane || maxnp)) continue;  // frozen leaf ignores its points
-                int consumed = 0;
-                if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts + g <= LK_WAVE) {
-                    // lane Ln holds node point Ln: existing points from the block, then the group's points in order
-                    const int n0 = r.npts;
-                    double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
-                    if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
-                    {
-                        int rr = lane - n0, src = 0;  // src = position of the rr-th set bit of grp
-                        if (rr >= 0 && rr < g) {
-                            int rem = rr;
-#pragma unroll
-                            for (int w = 32; w > 0; w >>= 1) {
-                                const unsigned long long low = ((w == 64) ? ~0ull : ((1ull << w) - 1ull)) << src;
-                                const int cbits = __popcll(grp & low);
-                                if (rem >= cbits) rem -= cbits, src += w;
-                            }
-                        } else {
-                            src = lane;
-                        }
-                        const int qidx = __builtin_amdgcn_ds_bpermute(src << 2, sidx);
-                        if (rr >= 0 && rr < g) {
-                            PtU pt;
-                            point_of(qidx, pt);
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) ppw[c] = pt.pw[c];
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
-                        }
-                    }
-                    const int thr = pr.layer_init_num[L];
-                    int cur = n0, newp = r.new_points;
-                    int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
-                    bool frozen = false, general_init = false, stop = false, fitted = false, flipped_to_tree = false;
-                    PlaneFit fit;
-                    fit.is_plane = lplane;
-                    int fit_count = 0;
-                    while (consumed < g && !stop) {
-                        const int rem = g - consumed;
-                        if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
-                            const int k = max(min(rem, thr + 1 - cur), 1);
-                            cur += k, newp += k, consumed += k;
-                            if (cur > thr) {
-                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                                fit_count = cur, fitted = true, newp = 0;
-                                if (fit.is_plane) {
-                                    mode = 1;
-                                    if (cur > pr.max_points_num) frozen = true, stop = true;
-                                } else if (L >= pr.max_layer) {
-                                    mode = 2;  // cut_octo_tree returns at once at max_layer (:140-143)
-                                } else {
-                                    general_init = true, stop = true;  // the generic code cuts the voxel
-                                }
-                            }
-                        } else if (mode == 1) {  // voxel_map.cc:191-204
-                            const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
-                            cur += k, newp += k, consumed += k;
-                            if (newp > 5) {
-                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                                fit_count = cur, fitted = true, newp = 0;
-                                if (!fit.is_plane) {
-                                    if (L < pr.max_layer) flipped_to_tree = true, stop = true;
-                                    else mode = 2;
-                                }
-                            }
-                            if (cur >= pr.max_points_num) frozen = true, stop = true;
-                        } else {  // voxel_map.cc:224-237
-                            const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
-                            cur += k, newp += k, consumed += k;
-                            if (newp > 5) {
-                                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                                fit_count = cur, fitted = true, newp = 0;
-                                if (fit.is_plane) mode = 1;
-                            }
-                            if (cur > pr.max_points_num) frozen = true, stop = true;
-                        }
-                    }
-                    // ---- commit points, counters, one full fit
-                    if (cur > n0 && r.block < 0) r.block = alloc_block(map);
-                    if (lane >= n0 && lane < cur) {
-                        lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) dst->var[c] = pvar[c];
-                    }
-                    r.npts = cur;
-                    if (general_init) {
-                        r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
-                        node_store(ln, r);
-                        switch (L) {
-                            case 0: dev_init_octo<0>(map, pr, leaf); break;
-                            case 1: dev_init_octo<1>(map, pr, leaf); break;
-                            case 2: dev_init_octo<2>(map, pr, leaf); break;
-                            default: dev_init_octo<3>(map, pr, leaf); break;
-                        }
-                    } else {
-                        r.new_points = newp;
-                        if (fitted) {
-                            // the one full fit of this leaf in this bucket: the state of its LAST refit event
-                            const bool decided = fit.is_plane;
-                            fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold);
-                            fit.is_plane = decided;  // control flow above already followed the event's decision
-                            double acc21[21];
-                            if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
-                            plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
-                            r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
-                            if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
-                        }
-                        if (frozen) node_freeze(map, r);
-                        node_store(ln, r);
-                        if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
-                    }
-                }
-                // ---------------- whatever is left of the group: the per-point state machine from this node down
-                for (int tpos = consumed; tpos < g; ++tpos) {
-                    int src = 0, rem = tpos;
-#pragma unroll
-                    for (int w = 32; w > 0; w >>= 1) {
-                        const unsigned long long low = ((1ull << w) - 1ull) << src;
-                        const int cbits = __popcll(grp & low);
-                        if (rem >= cbits) rem -= cbits, src += w;
-                    }
+                if ((grp >> lane) & 1ull) map.gidx[off + __popcll(grp & ((1ull << lane) - 1ull))] = sidx;
+                if (lane == 0) groups[gbase + gi] = LkGroup{Tn, Tp, To, off, g, 0, root, 0};
+                off += g;
+                ++gi;
+            }
+        }
+    }
+}
+
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_apply_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LK_MB) >> 6;
+    const int n_groups = (int)min(map.counters[LK_CTR_GROUPS], map.max_scan);
+    const LkGroup* groups = reinterpret_cast<const LkGroup*>(map.groups);
+    BucketConst bc;
+    if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
+    auto point_of = [&](int idx, PtU& pt) {
+        if (FROM_PV) {
+            load_pt(pv, nullptr, idx, pt.pw, pt.var);
+        } else {
+            const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+            PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
+            pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
+            pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
+            pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
+        }
+    };
+    // groups that need the generic per-point code are queued behind the descriptors of this pass (kind 1: whole long
+    // list; kind 2: leaf `leaf`, optional init_octo_tree (oct != 0, layer in pad), then gidx[off .. off+count) one by one)
+    auto defer = [&](const LkGroup& d) {
+        if (lane == 0) {
+            const unsigned int q = atomicAdd(&map.counters[LK_CTR_FALLBACK], 1u);
+            if (q < map.max_scan) reinterpret_cast<LkGroup*>(map.groups)[map.max_scan + q] = d;
+            else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+        }
+    };
+    for (int t = wave; t < n_groups; t += nwaves) {
+        const int4 d0 = reinterpret_cast<const int4*>(&groups[t])[0], d1 = reinterpret_cast<const int4*>(&groups[t])[1];
+        const int Tn = bcast0(d0.x), Tp = bcast0(d0.y), To = bcast0(d0.z), off = bcast0(d0.w), g = bcast0(d1.x),
+                  kind = bcast0(d1.y), root = bcast0(d1.z);
+        if (kind == 1) {  // very long list: the per-point replay of lk_insert_fallback_kernel
+            defer(LkGroup{root, -1, 0, off, g, 1, root, 0});
+            continue;
+        }
+        int leaf = Tn;
+        if (leaf < 0) {  // voxel_map.cc:214-222: first point of a new octant creates the child
+            const lk_node_rec* pn = &map.nodes[Tp];
+            double pc[3] = {pn->voxel_center[0], pn->voxel_center[1], pn->voxel_center[2]};
+            leaf = create_child(map, Tp, To, pc, pn->quater_length, bcast0(pn->layer));
+        }
+        // ---------------- one leaf, its points = gidx[off .. off+g) in input order
+        lk_node_rec* ln = &map.nodes[leaf];
+        NodeRegs r = node_load(ln);
+        const bool lplane = (bcast0((int)map.planes[leaf].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+        const int L = r.layer;
+        const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
+        const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
+        const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
+        if (!uninit && !live && (lplane || maxnp)) continue;  // frozen leaf ignores its points
+        int consumed = 0;
+        bool need_init = false;
+        if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts < LK_WAVE) {
+            // lane Ln holds node point Ln: existing points from the block, then the group's points in order.  Only the
+            // first gs points fit in the wave; that is always enough to reach the freeze of a leaf (npts <=
+            // max_points_num + 1 <= 64), after which the rest of the group is ignored anyway; in the other cases the
+            // remainder goes through the per-point state machine below.
+            const int n0 = r.npts;
+            const int gs = min(g, LK_WAVE - n0);
+            double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
+            if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
+            {
+                const int rr = lane - n0;
+                if (rr >= 0 && rr < gs) {
                     PtU pt;
-                    point_of(__builtin_amdgcn_readlane(sidx, src), pt);
-                    dev_update_octo(map, pr, leaf, pt);
+                    point_of(map.gidx[off + rr], pt);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ppw[c] = pt.pw[c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
                 }
             }
+            const int thr = pr.layer_init_num[L];
+            int cur = n0, newp = r.new_points;
+            int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
+            bool frozen = false, general_init = false, stop = false, fitted = false, flipped_to_tree = false;
+            PlaneFit fit;
+            fit.is_plane = lplane;
+            int fit_count = 0;
+            while (consumed < gs && !stop) {
+                const int rem = gs - consumed;
+                if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
+                    const int k = max(min(rem, thr + 1 - cur), 1);
+                    cur += k, newp += k, consumed += k;
+                    if (cur > thr) {
+                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                        fit_count = cur, fitted = true, newp = 0;
+                        if (fit.is_plane) {
+                            mode = 1;
+                            if (cur > pr.max_points_num) frozen = true, stop = true;
+                        } else if (L >= pr.max_layer) {
+                            mode = 2;  // cut_octo_tree returns at once at max_layer (:140-143)
+                        } else {
+                            general_init = true, stop = true;  // the generic code cuts the voxel
+                        }
+                    }
+                } else if (mode == 1) {  // voxel_map.cc:191-204
+                    const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
+                    cur += k, newp += k, consumed += k;
+                    if (newp > 5) {
+                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                        fit_count = cur, fitted = true, newp = 0;
+                        if (!fit.is_plane) {
+                            if (L < pr.max_layer) flipped_to_tree = true, stop = true;
+                            else mode = 2;
+                        }
+                    }
+                    if (cur >= pr.max_points_num) frozen = true, stop = true;
+                } else {  // voxel_map.cc:224-237
+                    const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
+                    cur += k, newp += k, consumed += k;
+                    if (newp > 5) {
+                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                        fit_count = cur, fitted = true, newp = 0;
+                        if (fit.is_plane) mode = 1;
+                    }
+                    if (cur > pr.max_points_num) frozen = true, stop = true;
+                }
+            }
+            // ---- commit points, counters, one full fit
+            if (cur > n0 && r.block < 0) r.block = alloc_block(map);
+            if (lane >= n0 && lane < cur) {
+                lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dst->var[c] = pvar[c];
+            }
+            r.npts = cur;
+            if (general_init) {
+                r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
+                node_store(ln, r);
+                need_init = true;    // the generic code cuts the voxel: lk_insert_fallback_kernel
+            } else {
+                r.new_points = newp;
+                if (fitted) {
+                    // the one full fit of this leaf in this bucket: the state of its LAST refit event
+                    const bool decided = fit.is_plane;
+                    fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold);
+                    fit.is_plane = decided;  // control flow above already followed the event's decision
+                    double acc21[21];
+                    if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
+                    plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
+                    r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
+                    if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
+                }
+                if (frozen) node_freeze(map, r);
+                node_store(ln, r);
+                if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
+            }
+        }
+        // ---------------- a cut and / or whatever is left of the group: the generic state machine, in its own kernel
+        if (need_init || consumed < g) defer(LkGroup{leaf, -1, need_init ? 1 : 0, off + consumed, g - consumed, 2, root, L});
+    }
+}
+
+
+// The generic code path of the insert for the few groups the register simulation hands over (a voxel that has to be
+// cut: init_octo_tree / cut_octo_tree voxel_map.cc:119-183; leftover points after a flip to a tree; roots with more
+// than 64 queued points): one wave per item, the per-point state machine dev_update_octo / dev_init_octo<L>.
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_fallback_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                              const lk_pt_rec* __restrict__ pv, int n) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * LK_MB) >> 6;
+    const int n_items = (int)min(map.counters[LK_CTR_FALLBACK], map.max_scan);
+    if (n_items == 0) return;
+    const LkGroup* items = reinterpret_cast<const LkGroup*>(map.groups) + map.max_scan;
+    BucketConst bc;
+    if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
+    auto point_of = [&](int idx, PtU& pt) {
+        if (FROM_PV) {
+            load_pt(pv, nullptr, idx, pt.pw, pt.var);
         } else {
+            const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+            PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
+            pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
+            pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
+            pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
+        }
+    };
+    for (int t = wave; t < n_items; t += nwaves) {
+        const int4 d0 = reinterpret_cast<const int4*>(&items[t])[0], d1 = reinterpret_cast<const int4*>(&items[t])[1];
+        const int leaf = bcast0(d0.x), do_init = bcast0(d0.z), off = bcast0(d0.w), g = bcast0(d1.x), kind = bcast0(d1.y),
+                  root = bcast0(d1.z), L = bcast0(d1.w);
+        if (kind == 1) {
             // very long list: successive-minimum selection, one point at a time
+            lk_node_rec* nd = &map.nodes[root];
             int last = -1;
-            for (int step = 0; step < m; ++step) {
+            for (int step = 0; step < g; ++step) {
                 int best = 0x7fffffff;
-                for (int j = lane; j < m; j += LK_WAVE) {
-                    int v = map.scratch[base + j];
+                for (int j = lane; j < g; j += LK_WAVE) {
+                    int v = map.scratch[off + j];
                     if (v > last && v < best) best = v;
                 }
                 best = wave_min_i(best);
@@ -814,6 +924,20 @@ __global__ void __launch_bounds__(LK_MB)
                 unsigned int pf = (unsigned int)bcast0((int)map.planes[root].flags);
                 if ((st & LK_NODE_INIT_OCTO) && (pf & LK_PLANE_IS_PLANE) && !(st & LK_NODE_UPDATE_ENABLE)) break;
             }
+            continue;
+        }
+        if (do_init) {
+            switch (L) {
+                case 0: dev_init_octo<0>(map, pr, leaf); break;
+                case 1: dev_init_octo<1>(map, pr, leaf); break;
+                case 2: dev_init_octo<2>(map, pr, leaf); break;
+                default: dev_init_octo<3>(map, pr, leaf); break;
+            }
+        }
+        for (int tpos = 0; tpos < g; ++tpos) {
+            PtU pt;
+            point_of(bcast0(map.gidx[off + tpos]), pt);
+            dev_update_octo(map, pr, leaf, pt);
         }
     }
 }
@@ -821,7 +945,7 @@ __global__ void __launch_bounds__(LK_MB)
 // Light pre-pass of the insert: ONE THREAD per touched root.  Most touched roots only need their few new points
 // appended — an un-initialised root that stays at <= layer_init_num points, or a plane root that reaches neither
 // its 6th new point (refit, voxel_map.cc:195) nor max_points_num (freeze, :199).  Those are finished here, in input
-// order (8-input sorting network on the list indices); every other root is queued for lk_insert_kernel.
+// order (8-input sorting network on the list indices); every other root is queued for the group / apply passes.
 __device__ __forceinline__ void cswap(int& a, int& b) {
     int lo = a < b ? a : b, hi = a < b ? b : a;
     a = lo, b = hi;
@@ -1061,6 +1185,9 @@ __global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) {
         map.counters[LK_CTR_TOUCHED] = 0;
         map.counters[LK_CTR_SCRATCH] = 0;
         map.counters[LK_CTR_HEAVY] = 0;
+        map.counters[LK_CTR_GROUPS] = 0;
+        map.counters[LK_CTR_GIDX] = 0;
+        map.counters[LK_CTR_FALLBACK] = 0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nfreed; i += 256) map.free_list[base + i] = map.freed_next[i];
