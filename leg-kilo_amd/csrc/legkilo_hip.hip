@@ -395,14 +395,23 @@ int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const 
     return LK_OK;
 }
 
+// lk_bucket_begin_kernel + lk_predict_kernel in one launch (on a single dependent stream every kernel boundary costs
+// ~8-10 us; the two pieces touch disjoint data)
+static_assert(LK_FB == 256, "dev_bucket_begin strides by 256 threads");
+__global__ void __launch_bounds__(LK_FB) lk_begin_predict_kernel(LkMap map, LkFilter* filters, const double* __restrict__ Q, double t) {
+    __shared__ FilterSmem sm;
+    dev_bucket_begin(map);
+    dev_predict(&filters[0], Q, t, sm);
+}
+
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
-    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, m);
-    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
+    // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
+    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_begin_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_Q, t));
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
     ro.world = d_world;
@@ -425,7 +434,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
                                                      h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
-        LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 64)), dim3(LK_MB), 0, h->stream,
+        LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
                                                         h->map, h->pr, h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
     }
     return LK_OK;
@@ -519,7 +528,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
                                                     h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_apply_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                               h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
-    LAUNCH(h, "insert_pv_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<true>, dim3(std::min(grid, 64)), dim3(LK_MB), 0, h->stream,
+    LAUNCH(h, "insert_pv_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<true>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
                                                        h->map, h->pr, h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     int rc = check_map_errors(h);
     hipFree(d_pv);

@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(LK_MB)
 
 // Start of a bucket's insert phase: clear the per-bucket counters and make the blocks retired during the previous
 // bucket allocatable (see pop_or_bump_block).  One workgroup.
-__global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) {
+__device__ __forceinline__ void dev_bucket_begin(const LkMap& map) {
     __shared__ int base, nfreed;
     if (threadIdx.x == 0) {
         int fc = (int)map.counters[LK_CTR_FREE];
@@ -1197,6 +1197,7 @@ __global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) {
         map.counters[LK_CTR_FREED] = 0;
     }
 }
+__global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) { dev_bucket_begin(map); }
 
 // ------------------------------------------------------------------ pool initialisation
 __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned int n_hash) {

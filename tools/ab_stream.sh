@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of library variants on the single-stream path (config 3): tools/ab_stream.sh lib_a.so lib_b.so ...
 for v in "$@"; do
-  for i in 1 2; do
-    LEGKILO_HIP_LIB=$PWD/leg-kilo_amd/$v python bench.py --steps 2 --warmup 1 --cpu-sample 0 --scans-per-gpu 32 --stream-scans 16 2>/dev/null > /tmp/ab_st.json
+  for i in 1 2 3 4; do
+    LEGKILO_HIP_LIB=$PWD/leg-kilo_amd/$v python bench.py --steps 2 --warmup 1 --cpu-sample 0 --scans-per-gpu 32 --stream-scans 24 2>/dev/null > /tmp/ab_st.json
     python - "$v" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab_st.json").read().strip().splitlines()[-1])
