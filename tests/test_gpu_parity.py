@@ -246,6 +246,61 @@ def test_update_points_bucket_and_insert(pair, scene):
     scenes.compare_maps(o.map_export(), g.map_export())
 
 
+def test_update_points_edge_cases(pair, scene):
+    """Buckets the reference's loop can meet: nothing matches (no update; the covariance is then propagated again from
+    the LAST update time on the next bucket - KILO.cc:110-111 - and every point still goes into the map), exactly one
+    match (the +1e-4 branch of eskf.cc:98-104), sizes around the wave width, and more than 64 points piled into one
+    voxel (the long-list replay of the insert).  Same state, covariance, times, counts and map as the oracle each time;
+    empty and oversized inputs are loud errors."""
+    o, g = pair
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    xs, Ps = o.get_state()
+    g.set_state(xs, Ps)
+    g.init_process_cov_q()
+    g.set_acc_norm(9.81)
+    tp, tu = o.get_times()
+    g.set_times(tp, tu)
+    rng = np.random.default_rng(4242)
+    ds = scenes.xyz_of(scenes.vlp_scan_input(scene, tp + 0.01, 55))
+    far = (rng.uniform(-1, 1, (40, 3)) + np.array([300.0, -200.0, 50.0])).astype(np.float32)      # no voxel anywhere near
+    pile = (np.array([310.0, -210.0, 40.0]) + rng.uniform(0.02, 0.23, (90, 3))).astype(np.float32)  # 90 points, one new voxel
+    cases = [("no match", far), ("after no match", ds[:700]), ("pile > 64 into one voxel", pile), ("one point", ds[700:701]),
+             ("63", ds[701:764]), ("64", ds[764:828]), ("65", ds[828:893]), ("257", ds[893:1150])]
+    cases.insert(2, ("single match", None))   # built below from the state at that moment
+    t = tp
+    seen_zero = seen_one = False
+    for name, xb in cases:
+        t += 0.004
+        if xb is None:  # exactly ONE match: a point the oracle's matcher accepts right now, plus points that hit nothing
+            valid = o.residuals(ds[1150:])[3]
+            k = 1150 + int(np.flatnonzero(valid)[0])
+            xb = np.concatenate([ds[k:k + 1], far[:5] + 7.0])
+        wo, io_, neo = o.update_points(t, xb)
+        wg, ig, neg = g.update_points(t, xb)
+        assert neo == neg, (name, neo, neg)
+        seen_zero |= neo == 0
+        seen_one |= neo == 1
+        assert np.array_equal(io_, ig), name
+        assert np.abs(wo - wg).max() < 2e-4, (name, np.abs(wo - wg).max())   # f32 world points at |x| ~ 300 m
+        (xo, Po), (xg, Pg) = o.get_state(), g.get_state()
+        assert np.allclose(xg, xo, rtol=1e-9, atol=1e-9), (name, np.abs(xg - xo).max())
+        assert rel_err(Pg, Po) < 1e-7, name
+        assert o.get_times() == g.get_times(), name
+    assert seen_zero and seen_one, "the no-match and the single-match branch must both have been exercised"
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+    cm = scenes.canon_map(g.map_export())
+    assert any(k[0] > 500 for k in cm), "the far points must have created voxels"
+    from legkilo_amd import binding
+
+    dss = scenes.vlp_scan_input(scene, tp + 0.5, 56)
+    with pytest.raises(binding.LegKiloError):
+        g.process_scan(dss[:0], t + 0.1)                                   # empty scan
+    with pytest.raises(binding.LegKiloError):
+        g.update_points(t + 0.1, np.zeros((g.cfg.max_scan_points + 1, 3), dtype=np.float32))   # bucket larger than max_scan_points
+
+
 # ----------------------------------------------------------------------------- full sequences
 @pytest.mark.parametrize("literal", [True, False])
 def test_sequence_imu_mode(pair, scene, literal, tmp_path):
