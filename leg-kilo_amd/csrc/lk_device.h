@@ -358,13 +358,18 @@ __host__ __device__ __forceinline__ unsigned int lk_hash3(int x, int y, int z) {
     h ^= h >> 16;
     return h;
 }
+// Linear probing, two consecutive slots per round trip: a wave waits for its slowest lane, and with ~14 distinct keys
+// per wave at load factor 0.3 some lane almost always needs a second probe; both slots are requested together.
 __device__ __forceinline__ int hash_find(const LkMap& m, int kx, int ky, int kz) {
     unsigned int s = lk_hash3(kx, ky, kz) & m.hash_mask;
-    for (unsigned int probe = 0; probe <= m.hash_mask; ++probe) {
-        int4 e = m.hash[s];
-        if (e.w == LK_EMPTY) return -1;
-        if (e.w >= 0 && e.x == kx && e.y == ky && e.z == kz) return e.w;
-        s = (s + 1) & m.hash_mask;
+    for (unsigned int probe = 0; probe <= m.hash_mask; probe += 2) {
+        const int4 e0 = m.hash[s];
+        const int4 e1 = m.hash[(s + 1) & m.hash_mask];
+        if (e0.w == LK_EMPTY) return -1;
+        if (e0.w >= 0 && e0.x == kx && e0.y == ky && e0.z == kz) return e0.w;
+        if (e1.w == LK_EMPTY) return -1;
+        if (e1.w >= 0 && e1.x == kx && e1.y == ky && e1.z == kz) return e1.w;
+        s = (s + 2) & m.hash_mask;
     }
     return -1;
 }
