@@ -254,7 +254,8 @@ def build_ref(force=False):
     """Compile oracle/_ref from the reference tree when it is present (this container); a prebuilt library is used
     as is where the tree does not exist (GPU box).  Returns the path, or None when neither exists."""
     if os.path.exists(_REF_SRC):
-        deps = [os.path.join(_HERE, "ref_capi.cc"), os.path.join(_HERE, "export_blob.hpp"), _REF_SRC,
+        deps = [os.path.join(_HERE, "ref_capi.cc"), os.path.join(_HERE, "ref_kilo_capi.cc"), os.path.join(_HERE, "ref_decode_capi.cc"),
+                os.path.join(_HERE, "export_blob.hpp"), os.path.join(_HERE, "Makefile"), _REF_SRC, _REF_SRC.replace("eskf.cc", "KILO.cc"),
                 _REF_SRC.replace("eskf.cc", "voxel_map.cc"), os.path.join(_HERE, "shim", "Eigen", "Dense")]
         if force or not os.path.exists(_REF_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_REF_LIB) for d in deps):
             subprocess.check_call(["make", "-C", _HERE, "-B", "ref"], stdout=subprocess.DEVNULL)
@@ -336,6 +337,21 @@ class ReferenceKilo(Oracle):
         write_reference_yaml(yaml_path, params, imu_mode_only)
         self.h = C.c_void_p(self.L._l.lkk_create(str(yaml_path).encode()))
         assert self.h, "KILO(config_file) failed"
+
+
+def ref_decode(raw, layout, time_scale, filter_num, blind, header_stamp=0.0):
+    """The reference's own LidarProcessing::processing (lidar_processing.cc:25-108, oracle/_ref) on a PointCloud2 payload
+    given as a packed numpy record array + the lk_cloud_layout dict the C-ABI takes -> (points, begin, end)."""
+    rl = ref_lib()
+    assert rl is not None
+    raw = np.ascontiguousarray(raw)
+    lay = abi.lk_cloud_layout(**layout)
+    out = np.zeros(len(raw), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("curvature", "<f4")]))
+    n, tb, te = C.c_size_t(0), C.c_double(0), C.c_double(0)
+    rc = rl._l.lkd_decode(_p(raw), C.c_size_t(len(raw)), C.byref(lay), C.c_double(time_scale), C.c_int(filter_num), C.c_float(blind),
+                          C.c_double(header_stamp), _p(out), C.byref(n), C.byref(tb), C.byref(te))
+    assert rc == 0, rc
+    return out[: n.value], tb.value, te.value
 
 
 def _hooks(which):

@@ -6,8 +6,9 @@
       fields incl. `curvature` accumulated in float, divided by the count)
   std::sort by curvature at KILO.cc:369-370.
 
-PARITY UNPINNED for THIS file (PCL and the ROS message decode cannot be built here; the path itself is pinned through
-oracle/_ref): PCL's result order inside a cell (std::sort of (idx, point) pairs is unstable) and its output
+PARITY: decode() below is PINNED against the reference's own lidar_processing.cc (compiled into oracle/_ref with a
+restated pcl::fromROSMsg; tests/test_reference_pin.py::test_decode_matches_the_reference: points bit for bit).  The
+voxel-grid filter stays UNPINNED by the reference - it is PCL's code, not the reference's: PCL's result order inside a cell (std::sort of (idx, point) pairs is unstable) and its output
 order are not defined by the reference; this restatement fixes them: points of a cell are summed sequentially in
 input order (float32), cells are emitted in ascending idx, the time sort is stable.
 """

@@ -329,3 +329,27 @@ def test_kilo_first_frame_initialisation(tmp_path, imu_only):
     scenes.compare_maps(o.map_export(), k.map_export(), rtol=1e-6, ptol=1e-9)
     o.close()
     k.close()
+
+
+# ----------------------------------------------------------------------------- in front of the path: the sensor decode
+@pytest.mark.parametrize("lidar_type", [1, 2, 3])
+def test_decode_matches_the_reference(lidar_type):
+    """The reference's own LidarProcessing::{velodyne,ouster,hesai}Handler (lidar_processing.cc:25-108: every
+    filter_num-th point outside the blind radius, curvature = round((t - t_first) * 500) / 500 in the handler's own
+    arithmetic type, begin / end times) on a PointCloud2 payload vs oracle/preprocess_oracle.decode - bit for bit.
+    (The device decode lk_decode_scan is bit-exact against that oracle: tests/test_preprocess.py.)"""
+    import preprocess_oracle as po
+    import test_preprocess as tp
+
+    sc = scenes.Scene()
+    for t, stamp, fnum, blind in ((1.0, 50.0, 3, 1.5), (2.3, 1234.5, 1, 0.5), (3.1, 0.0, 4, 4.0)):
+        raw, layout, scale = tp.raw_message(sc, t, lidar_type)
+        want, wb, we = po.decode(raw, lidar_type, scale, fnum, blind, header_stamp=stamp)
+        got, gb, ge = ob.ref_decode(raw, layout, scale, fnum, blind, header_stamp=stamp)
+        assert len(got) == len(want) > 300, (len(got), len(want))
+        for f in ("x", "y", "z", "curvature"):
+            assert np.array_equal(got[f], want[f]), (lidar_type, f, int((got[f] != want[f]).sum()))
+        # begin / end go through a `float` temporary in the reference (lidar_processing.cc:30-34,59-63); g++ -O3 keeps it in
+        # double for the Ouster handler (-O0..-O2 round it like the oracle does), so the time stamps are compared to float
+        # precision only.  They stamp the first frame; no point arithmetic depends on them.
+        assert abs(gb - wb) <= 1e-7 * max(1.0, abs(wb)) and abs(ge - we) <= 1e-7 * max(1.0, abs(we)), (gb, wb, ge, we)
