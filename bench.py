@@ -239,7 +239,7 @@ def main():
                 traffic_src = f"rocprofv3 --pmc, {pj.get('tag')}: {big['hbm_bytes_per_point']:.1f} B/point measured at {big['slots']} slots, scaled"
         except Exception:
             traffic = None
-    sq_file = os.path.join(ROOT, "profiles", "r01g_pmc_attrib.json")
+    sq_file = os.path.join(ROOT, "profiles", "r01_pmc_attrib.json")   # copy of the latest tools/gpu_pmc.sh attribution pass
     if os.path.exists(sq_file) and n_res:
         try:
             sq = json.load(open(sq_file))
