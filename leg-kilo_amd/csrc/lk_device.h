@@ -19,11 +19,8 @@
 #include "../../include/legkilo_hip.h"
 
 // build-time knobs kept for A/B runs (tools/ab.sh); both measured neutral on MI355X
-#ifndef LK_OPT_SLIM
-#define LK_OPT_SLIM 0
-#endif
 #ifndef LK_OPT_WAVES
-#define LK_OPT_WAVES 0
+#define LK_OPT_WAVES 5   // residual kernel: 5 waves per SIMD (<= 96 VGPRs, 28 B of spills); measured 562 -> 520 us per 20.5 M points
 #endif
 #define LK_WAVE 64
 #define LK_EMPTY (-1)
@@ -288,8 +285,9 @@ __device__ __forceinline__ PointGeom point_geom(float bx, float by, float bz, co
 // from the reference's matrix route by rounding only (~1e-16 relative), ~60 flops per candidate instead of ~230 per
 // point + 12 per candidate, and ~40 fewer live VGPRs.
 struct PointLite {
-    V3 p_i, p_w, pb;       // pb: body point with the z == 0 guard of calcBodyCov applied
+    V3 p_i, p_w;
     double alpha_n, beta;  // alpha / |pb|^2, beta
+    float gz;              // 1e-4 when calcBodyCov's z == 0 guard fired (voxel_map.cc:23), else 0
 };
 __device__ __forceinline__ PointLite point_lite(float bx, float by, float bz, const BucketConst& bc, const LkParams& pr) {
     PointLite g;
@@ -298,8 +296,8 @@ __device__ __forceinline__ PointLite point_lite(float bx, float by, float bz, co
     g.p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
     V3 w = mat3_mul_v(bc.R, g.p_i);
     g.p_w = V3{w.x + bc.p[0], w.y + bc.p[1], w.z + bc.p[2]};
-    if (pb.z == 0) pb.z = 0.0001;
-    g.pb = pb;
+    g.gz = 0.f;
+    if (pb.z == 0) pb.z = 0.0001, g.gz = 0.0001f;
     const double n2 = dot3(pb.x, pb.x, pb.y, pb.y, pb.z, pb.z);
     const double r = (double)(float)sqrt(n2);            // float range, voxel_map.cc:24
     g.beta = (r * r) * pr.dir_var;
@@ -314,7 +312,9 @@ __device__ __forceinline__ PlaneTerms plane_terms(const PointLite& g, const Buck
     PlaneTerms t;
     const V3 u = mat3T_mul_v(bc.R, n);
     const V3 m = mat3T_mul_v(pr.ext_R, u);
-    const double dm = dot3(g.pb.x, m.x, g.pb.y, m.y, g.pb.z, m.z);
+    // pb.m = pb^T ext_R^T u = (ext_R pb).u = (p_i - ext_T).u  (+ the guard's 1e-4 along ext_R's third column = 1e-4 m.z):
+    // the body point itself need not stay in registers
+    const double dm = dot3(g.p_i.x - pr.ext_T[0], u.x, g.p_i.y - pr.ext_T[1], u.y, g.p_i.z - pr.ext_T[2], u.z) + (double)g.gz * m.z;
     const double mm = dot3(m.x, m.x, m.y, m.y, m.z, m.z);
     t.ta = __builtin_fma(g.alpha_n * dm, dm, g.beta * mm);
     t.w = V3{-g.p_i.z * u.y + g.p_i.y * u.z, g.p_i.z * u.x - g.p_i.x * u.z, -g.p_i.y * u.x + g.p_i.x * u.y};

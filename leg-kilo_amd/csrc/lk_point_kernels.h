@@ -21,14 +21,13 @@
 // slots and LDS (measured on the 1024-scan batch: 642 us per bucket at 256 threads, 582 at 128, 578 at 64).
 #define LK_RB 64
 
+// The winning candidate's row is parked in the lane's own LDS row the moment it is taken (row[0..2] = w = p_i x (R^T n),
+// row[3..5] = n, row[6] = z = -dis, row[13] = sig_r) instead of being carried in ~15 VGPRs through the octree walk: the
+// kernel's occupancy is set by registers, and the row has to go to LDS anyway.
 struct Match {
-    int node;
-    int layer;
-    V3 n;          // plane normal
-    V3 w;          // p_i x (R^T n): rotation part of the H row
-    float dis;     // signed distance stored as float (voxel_map.h:92, .cc:401-402)
-    double sig_r;  // J_nq plane_var J_nq^T + n^T (R ext_R) body_cov (R ext_R)^T n  (KILO.cc:205-206, before lidar_ratio)
-    double lazy_d, lazy_sig;  // |d| and sigma_l of the first passing candidate (deferred probability)
+    double* row;       // this lane's LDS row (LK_ROW2 doubles)
+    float lazy_d;      // |d| and sigma_l of the first passing candidate (deferred probability)
+    double lazy_sig;
 };
 
 // voxel_map.cc:371-413 for one plane node.  q0..q2 / tail = the first 64 B of the node's match record (center,
@@ -65,23 +64,22 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
     if (!success) {
         take = true;
         prob = -1.0;
-        best.lazy_d = (double)dis_to_plane;
+        best.lazy_d = dis_to_plane;
         best.lazy_sig = sigma_l;
     } else {
         if (prob < 0.0)
-            prob = 1.0 / (sqrt(best.lazy_sig)) * exp(-0.5 * best.lazy_d * best.lazy_d / best.lazy_sig);
+            prob = 1.0 / (sqrt(best.lazy_sig)) * exp(-0.5 * (double)best.lazy_d * (double)best.lazy_d / best.lazy_sig);
         const double this_prob = 1.0 / sqrt(sigma_l) * exp(-0.5 * d2 / sigma_l);
         take = this_prob > prob;
         if (take) prob = this_prob;
     }
     success = true;
     if (take) {
-        best.node = node;
-        best.layer = layer;
-        best.n = n;
-        best.w = t.w;
-        best.dis = (float)sd;
-        best.sig_r = sig_r;
+        double* r = best.row;
+        r[0] = t.w.x, r[1] = t.w.y, r[2] = t.w.z;
+        r[3] = n.x, r[4] = n.y, r[5] = n.z;
+        r[6] = -(double)(float)sd;  // z = -dis_to_plane_, the signed distance stored as float (voxel_map.h:92, .cc:401-402)
+        r[13] = sig_r;              // J_nq plane_var J_nq^T + n^T (R ext_R) body_cov (R ext_R)^T n (KILO.cc:205-206, before lidar_ratio)
     }
 }
 
@@ -157,14 +155,6 @@ __device__ __forceinline__ void neighbour_key(const LkParams& pr, const float* l
     }
 }
 
-// KILO.cc:195-209: h (1x6), z, R for a matched point — everything was already derived while gating the winner
-__device__ __forceinline__ void obs_row(const Match& b, double ratio, double* h, double& z, double& R) {
-    h[0] = b.w.x, h[1] = b.w.y, h[2] = b.w.z;
-    h[3] = b.n.x, h[4] = b.n.y, h[5] = b.n.z;
-    z = -(double)b.dis;
-    R = ratio * b.sig_r;  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
-}
-
 struct ResidualOut {       // optional per-point outputs (config 2 / lk_residuals); any may be null
     double* h6;            // n x 6 row-major
     double* z;
@@ -199,8 +189,6 @@ __global__ void LK_RES_BOUNDS
         BucketConst bc;
         load_bucket_const<false>(&filters[slot], pr, bc);
         PointLite g;
-        float loc[3] = {0.f, 0.f, 0.f};
-        int key[3] = {0, 0, 0}, near[3] = {0, 0, 0};
         int root = -1, nroot = -1;
         if (i < n) {
             const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
@@ -209,6 +197,8 @@ __global__ void LK_RES_BOUNDS
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
                 reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
             }
+            float loc[3];
+            int key[3];
             key_trunc(g.p_w, pr, loc, key);
             root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
         }
@@ -216,17 +206,26 @@ __global__ void LK_RES_BOUNDS
         bool success = false;
         double prob = 0;
         Match best;
-        best.node = -1;
+        best.row = reinterpret_cast<double*>(&stage[wv][0]) + lane * LK_ROW2;
         if (root >= 0) match_root(map, root, g, bc, pr, success, prob, best);
         // the one-neighbour retry (KILO.cc:156-178)
         if (root >= 0 && !success) {  // KILO.cc:156-178
+            float loc[3];     // re-derived here rather than kept alive across the home voxel's walk
+            int key[3], near[3];
+            key_trunc(g.p_w, pr, loc, key);
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = hash_find(map, near[0], near[1], near[2]);
             if (nroot >= 0) match_root(map, nroot, g, bc, pr, success, prob, best);
         }
         ok = success;
-        if (ok) obs_row(best, pr.lidar_ratio, h, z, R);
+        if (ok) {  // KILO.cc:195-209: h (1x6), z, R for the matched point, from the parked row
+            const double* r = best.row;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) h[a] = r[a];
+            z = r[6];
+            R = pr.lidar_ratio * r[13];  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
+        }
         if (EMIT_ROWS && i < n) {
             size_t o = (size_t)slot * out_slot_stride + i;
             out.valid[o] = ok ? 1 : 0;
