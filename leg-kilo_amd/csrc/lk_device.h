@@ -18,7 +18,7 @@
 
 #include "../../include/legkilo_hip.h"
 
-// build-time knobs kept for A/B runs (tools/ab.sh); both measured neutral on MI355X
+// occupancy target of the residual kernel (tools/ab_libs.sh A/B: DESIGN.md section 6)
 #ifndef LK_OPT_WAVES
 #define LK_OPT_WAVES 5   // residual kernel: 5 waves per SIMD (<= 96 VGPRs, 28 B of spills); measured 562 -> 520 us per 20.5 M points
 #endif
