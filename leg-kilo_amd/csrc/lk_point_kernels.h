@@ -257,25 +257,12 @@ __global__ void LK_RES_BOUNDS
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
         const int q = lane & 31, half = lane >> 5;
-        int a = 0, b = 0;   // component q = sum over rows of r[a] * r[b]
-        if (q < 21) {       // A(i,j) = sum (h_i / R) h_j, upper triangle in row-major order
-            int i = 0, rem = q;
-            while (rem >= 6 - i) {
-                rem -= 6 - i;
-                ++i;
-            }
-            a = 7 + i;
-            b = i + rem;
-        } else if (q < 27) {  // b_i = sum (h_i / R) z
-            a = 7 + (q - 21);
-            b = 6;
-        } else if (q == 27) {  // sum R
-            a = 13;
-            b = 14;
-        } else {               // count
-            a = 14;
-            b = 14;
-        }
+        // component q = sum over rows of r[a] * r[b]:  A(i,j) = sum (h_i / R) h_j (upper triangle, row-major: q < 21,
+        // a = 7 + i, b = j), b_i = sum (h_i / R) z (q = 21 + i: a = 7 + i, b = 6), sum R (q = 27: 13, 14), count (14, 14).
+        // Packed as a | b << 4, eight entries per 64-bit word.
+        const unsigned long long tw = (q < 8) ? 0x2818574737271707ull : (q < 16) ? 0x3a59493929584838ull : (q < 24) ? 0x6968675c5b4b5a4aull : 0xeeeeeeeeed6c6b6aull;
+        const unsigned int ab = (unsigned int)(tw >> ((q & 7) * 8)) & 0xffu;
+        const int a = (int)(ab & 15u), b = (int)(ab >> 4);
         const double* base = rows + (half * 32) * LK_ROW2;
         double acc = 0.0;
 #pragma unroll
