@@ -109,8 +109,9 @@ def main():
     ap.add_argument("--scans-per-gpu", type=int, default=1024, help="BASELINE config 5: a batch of 1024 scans (fits one GPU)")
     ap.add_argument("--unique-scans", type=int, default=16, help="distinct synthetic scans generated per GPU (tiled to the batch)")
     ap.add_argument("--map-warm", type=int, default=6)
-    ap.add_argument("--stream-scans", type=int, default=6)
-    ap.add_argument("--cpu-sample", type=int, default=4, help="scans the oracle replays for cpu_baseline (0 = skip)")
+    ap.add_argument("--stream-scans", type=int, default=24, help="consecutive scans of the single-stream (config 3) measurement")
+    ap.add_argument("--cpu-sample", type=int, default=240, help="scans the oracle replays for cpu_baseline (0 = skip); the default "
+                    "is ~6 s of single-thread work on the frozen-map workload plus ~2 s on the full path with insert")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 2x, 16 B/slot)")
     args = ap.parse_args()
 
@@ -323,7 +324,7 @@ def main():
             build_map(o, world, traj, P, t0, args.map_warm)
             o.set_map_insert(False)
             tcs = []
-            for s in range(args.cpu_sample):
+            for s in range(min(args.cpu_sample, S)):
                 o.set_state(xs[s], Ps[s])
                 o.set_times(0.0, 0.0)
                 tc = time.perf_counter()
@@ -337,14 +338,16 @@ def main():
             if not sscans:
                 sscans = [synth.dense_scan(world, traj, t_after + 0.1 * k, P, n=N_PTS, n_buckets=N_BUCKETS, seed_scan=8008 + k,
                                            seed_noise=8108 + k) for k in range(3)]
-            for k in range(min(3, len(sscans))):
+            n_full = min(len(sscans), max(3, args.cpu_sample // 6))   # consecutive scans: the map keeps growing as in a run
+            for k in range(n_full):
                 tc = time.perf_counter()
                 o.process_scan(sscans[k], t_after + 0.1 * k, with_sort=True)
                 tfull.append(time.perf_counter() - tc)
             cpu_baseline = {
                 "value": round(1.0 / float(np.median(tcs)), 3), "unit": "scans/s", "cores": 1, "kind": "port",
                 "sample": f"{args.cpu_sample} of the batch's 100k-pt scans (5 buckets, frozen map, 6x6-form update), "
-                          "median, sort included (KILO.cc:367-396)",
+                          f"{sum(tcs):.1f} s of CPU time, median per scan, sort included (KILO.cc:367-396); full path with insert: "
+                          f"{len(tfull)} consecutive scans, {sum(tfull):.1f} s",
                 "full_path_with_insert_scans_per_s": round(1.0 / float(np.median(tfull)), 3),
                 "host_cores_available": os.cpu_count(),
                 "literal_form": "not timed: the reference's literal N x N updateByPoints (eskf.cc:105-112) is O(N^3) per bucket - "
