@@ -404,22 +404,64 @@ __global__ void __launch_bounds__(LK_FB) lk_begin_predict_kernel(LkMap map, LkFi
     dev_predict(&filters[0], Q, t, sm);
 }
 
+// Small buckets (the reference's 2 ms time bins hold tens to hundreds of points on a real scan) are pure per-bucket
+// latency: for n <= LK_SMALL_MAX the bookkeeping, the predict, the residual pass and the update run as ONE
+// single-workgroup kernel - block barriers instead of three dependent launches.  The tiles of the bucket are spread
+// over the workgroup's four waves (same residual_tile code as lk_residual_kernel); wave partials are combined in a
+// fixed order.
+#define LK_SMALL_MAX 512
+__global__ void __launch_bounds__(LK_FB)
+    lk_small_bucket_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, double t,
+                           const lk_point* __restrict__ pts, int n, float* world) {
+    __shared__ FilterSmem sm;
+    __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
+    __shared__ double red[LK_FB / LK_WAVE][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    LkFilter* f = &filters[0];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    dev_bucket_begin(map);
+    dev_predict(f, Q, t, sm);  // ends with a workgroup barrier: the propagated state is visible to every thread
+    BucketConst bc;
+    load_bucket_const<false>(f, pr, bc);
+    ResidualOut ro;
+    ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = world;
+    double acc = 0.0;
+    for (int base = wv * LK_WAVE; base < n; base += LK_FB) {
+        __builtin_amdgcn_wave_barrier();  // the previous tile's reads of this wave's rows are complete
+        acc += residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
+    }
+    if (lane < LK_NPART) red[wv][lane] = (lane < 29) ? acc : 0.0;
+    __syncthreads();
+    if (tid < LK_NPART) {
+        double s = 0.0;
+        for (int w = 0; w < LK_FB / LK_WAVE; ++w) s += red[w][tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    dev_update_from_totals(f, sm, tot, t);
+}
+
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
-    // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
-    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_begin_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_Q, t));
-    ResidualOut ro;
-    memset(&ro, 0, sizeof(ro));
-    ro.world = d_world;
-    LAUNCH(h, "residual",
-           hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
-                              d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
-    LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                           h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
+    if (n <= LK_SMALL_MAX) {
+        LAUNCH(h, "small_bucket", hipLaunchKernelGGL(lk_small_bucket_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
+                                                     h->d_Q, t, d_pts, n, d_world));
+    } else {
+        // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
+        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_begin_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_Q, t));
+        ResidualOut ro;
+        memset(&ro, 0, sizeof(ro));
+        ro.world = d_world;
+        LAUNCH(h, "residual",
+               hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
+                                  d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
+                                               h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
+    }
     if (d_world || do_insert)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));

@@ -270,6 +270,33 @@ __device__ void dev_point_update(LkFilter* f, FilterSmem& sm, const double* A21,
     dev_kalman_apply(f, sm, 6);
 }
 
+// The bucket's totals [A(21) b(6) sumR count] are in tot[] (LDS, visible to the whole workgroup): bookkeeping of
+// KILO.cc:193,211-212 and the information-form update.  Called by all LK_FB threads.
+__device__ void dev_update_from_totals(LkFilter* f, FilterSmem& sm, double* tot, double t) {
+    const int tid = threadIdx.x;
+    const int N = (int)(tot[28] + 0.5);
+    if (tid == 0) {
+        f->n_buckets += 1;
+        f->last_N = N;
+        f->updated = N > 0;
+        if (N > 0) {
+            f->n_updates += 1;
+            f->n_effect += (unsigned long long)N;
+            f->last_update_t = t;  // KILO.cc:212
+        }
+    }
+    if (N > 0) {
+        if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
+            double r = tot[27];
+            double sc = r / (r + 0.0001);
+            __syncthreads();
+            if (tid < 27) tot[tid] *= sc;
+        }
+        __syncthreads();
+        dev_point_update(f, sm, &tot[0], &tot[21]);
+    }
+}
+
 // reduce the per-wave partial records (fixed order -> deterministic) and update; partials: [nblk][LK_NPART] per slot.
 // do_predict != 0 (batch replay on a frozen map, where nothing reads the state between update(k) and predict(k+1)):
 // the predict of the NEXT bucket (time t_next) runs in the same launch.
@@ -303,27 +330,7 @@ __global__ void __launch_bounds__(LK_FB)
         tot[tid] = s;
     }
     __syncthreads();
-    const int N = (int)(tot[28] + 0.5);
-    if (tid == 0) {
-        f->n_buckets += 1;
-        f->last_N = N;
-        f->updated = N > 0;
-        if (N > 0) {
-            f->n_updates += 1;
-            f->n_effect += (unsigned long long)N;
-            f->last_update_t = t;  // KILO.cc:212
-        }
-    }
-    if (N > 0) {
-        if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
-            double r = tot[27];
-            double sc = r / (r + 0.0001);
-            __syncthreads();
-            if (tid < 27) tot[tid] *= sc;
-        }
-        __syncthreads();
-        dev_point_update(f, sm, &tot[0], &tot[21]);
-    }
+    dev_update_from_totals(f, sm, tot, t);
     if (do_predict) {
         __syncthreads();  // f->x, f->P, f->last_update_t written above are re-read by dev_predict
         dev_predict(f, Q, t_next, sm);

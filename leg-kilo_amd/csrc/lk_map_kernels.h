@@ -592,12 +592,9 @@ __device__ __forceinline__ void insert_point_pw(const LkParams& pr, const Bucket
 }
 
 template <bool FROM_PV>
-__global__ void __launch_bounds__(LK_MB)
-    lk_insert_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                           const lk_pt_rec* __restrict__ pv, int n) {
+__device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * LK_MB) >> 6;
     // scan points: only the roots the light pre-pass could not finish; pointWithVar input: every touched root
     const int n_touched = (int)map.counters[FROM_PV ? LK_CTR_TOUCHED : LK_CTR_HEAVY];
     const int* worklist = FROM_PV ? map.touched : map.heavy;
@@ -715,12 +712,9 @@ __global__ void __launch_bounds__(LK_MB)
 }
 
 template <bool FROM_PV>
-__global__ void __launch_bounds__(LK_MB)
-    lk_insert_apply_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                           const lk_pt_rec* __restrict__ pv, int n) {
+__device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * LK_MB) >> 6;
     const int n_groups = (int)min(map.counters[LK_CTR_GROUPS], map.max_scan);
     const LkGroup* groups = reinterpret_cast<const LkGroup*>(map.groups);
     BucketConst bc;
@@ -879,12 +873,9 @@ __global__ void __launch_bounds__(LK_MB)
 // cut: init_octo_tree / cut_octo_tree voxel_map.cc:119-183; leftover points after a flip to a tree; roots with more
 // than 64 queued points): one wave per item, the per-point state machine dev_update_octo / dev_init_octo<L>.
 template <bool FROM_PV>
-__global__ void __launch_bounds__(LK_MB)
-    lk_insert_fallback_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                              const lk_pt_rec* __restrict__ pv, int n) {
+__device__ __forceinline__ void dev_insert_fallback(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                              const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * LK_MB) >> 6;
     const int n_items = (int)min(map.counters[LK_CTR_FALLBACK], map.max_scan);
     if (n_items == 0) return;
     const LkGroup* items = reinterpret_cast<const LkGroup*>(map.groups) + map.max_scan;
@@ -942,6 +933,25 @@ __global__ void __launch_bounds__(LK_MB)
     }
 }
 
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n) {
+    dev_insert_group<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+}
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_apply_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n) {
+    dev_insert_apply<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+}
+template <bool FROM_PV>
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_fallback_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                           const lk_pt_rec* __restrict__ pv, int n) {
+    dev_insert_fallback<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+}
+
 // Light pre-pass of the insert: ONE THREAD per touched root.  Most touched roots only need their few new points
 // appended — an un-initialised root that stays at <= layer_init_num points, or a plane root that reaches neither
 // its 6th new point (refit, voxel_map.cc:195) nor max_points_num (freeze, :199).  Those are finished here, in input
@@ -950,10 +960,8 @@ __device__ __forceinline__ void cswap(int& a, int& b) {
     int lo = a < b ? a : b, hi = a < b ? b : a;
     a = lo, b = hi;
 }
-__global__ void __launch_bounds__(256)
-    lk_insert_light_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int)map.counters[LK_CTR_TOUCHED]) return;
+__device__ __forceinline__ void dev_insert_light_root(const LkMap& map, const LkParams& pr, const LkFilter* __restrict__ filters,
+                                                      const lk_point* __restrict__ pts, const int t) {
     const int root = map.touched[t];
     lk_node_rec* nd = &map.nodes[root];
     const int m = (int)nd->pad_[0];
@@ -1012,6 +1020,12 @@ __global__ void __launch_bounds__(256)
     nd->npts = npts;
     nd->new_points = newp + m;
     nd->block = block;
+}
+__global__ void __launch_bounds__(256)
+    lk_insert_light_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int)map.counters[LK_CTR_TOUCHED]) return;
+    dev_insert_light_root(map, pr, filters, pts, t);
 }
 
 // hashing half of UpdateVoxelMap for caller-supplied pointWithVar records

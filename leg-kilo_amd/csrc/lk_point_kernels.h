@@ -172,44 +172,40 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 #else
 #define LK_RES_BOUNDS __launch_bounds__(LK_RB)
 #endif
+// One 64-point tile of the residual pass, executed by one wave: K1 (transform + covariance terms), K2 (home voxel, one
+// neighbour retry), the observation row, and K3 for the tile.  `rows` is the wave's private LDS region (64 x LK_ROW2
+// doubles).  Returns, in lane (q, half) = (lane & 31, lane >> 5), component q of [A(21) b(6) sumR count] summed over the
+// tile's 64 rows (both halves hold the same value).  Shared by lk_residual_kernel (one tile per single-wave workgroup)
+// and lk_small_bucket_kernel (legkilo_hip.hip: a small bucket's tiles inside one workgroup).
 template <bool EMIT_ROWS>
-__global__ void LK_RES_BOUNDS
-    lk_residual_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                       size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
-                       ResidualOut out, size_t out_slot_stride) {
-    // per-wave LDS region holding the wave's 64 observation rows (h6, z, 1/R, R)
-    __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
-    const int slot = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int i = blockIdx.x * LK_RB + tid;
+__device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams& pr, const BucketConst& bc,
+                                                const float4* __restrict__ spts, int i, int n, double* rows, int lane,
+                                                const ResidualOut& out, size_t out_base) {
     bool ok = false;
     double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
     {
-        BucketConst bc;
-        load_bucket_const<false>(&filters[slot], pr, bc);
         PointLite g;
         int root = -1, nroot = -1;
         if (i < n) {
-            const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
+            const float4 p = spts[i];
             g = point_lite(p.x, p.y, p.z, bc, pr);
             if (out.world) {
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
-                reinterpret_cast<float4*>(out.world + (size_t)slot * out_slot_stride * 4)[i] = w;
+                reinterpret_cast<float4*>(out.world + out_base * 4)[i] = w;
             }
             float loc[3];
             int key[3];
             key_trunc(g.p_w, pr, loc, key);
             root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
         }
-        // K2: home voxel first (the root's 256-B record is fetched in one round trip inside match_root)
+        // K2: home voxel first (the root's 144-B record is fetched in one round trip inside match_root)
         bool success = false;
         double prob = 0;
         Match best;
-        best.row = reinterpret_cast<double*>(&stage[wv][0]) + lane * LK_ROW2;
+        best.row = rows + lane * LK_ROW2;
         if (root >= 0) match_root(map, root, g, bc, pr, success, prob, best);
         // the one-neighbour retry (KILO.cc:156-178)
-        if (root >= 0 && !success) {  // KILO.cc:156-178
+        if (root >= 0 && !success) {
             float loc[3];     // re-derived here rather than kept alive across the home voxel's walk
             int key[3], near[3];
             key_trunc(g.p_w, pr, loc, key);
@@ -227,7 +223,7 @@ __global__ void LK_RES_BOUNDS
             R = pr.lidar_ratio * r[13];  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
         }
         if (EMIT_ROWS && i < n) {
-            size_t o = (size_t)slot * out_slot_stride + i;
+            size_t o = out_base + i;
             out.valid[o] = ok ? 1 : 0;
             out.z[o] = z;
             out.R[o] = R;
@@ -239,8 +235,7 @@ __global__ void LK_RES_BOUNDS
     // it did not match) in the wave's LDS region; lane (q = lane & 31, half = lane >> 5) then accumulates component q
     // of [A(21) b(6) sumR count] over the 32 rows of its half, in row order, branch-free and with ONE fma per row
     // (ds_read_b64 broadcasts, all loads independent of the arithmetic); the two halves are combined with one
-    // cross-lane read.  One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
-    double* rows = reinterpret_cast<double*>(&stage[wv][0]);
+    // cross-lane read.
     {
         double* r = rows + lane * LK_ROW2;
         const double ri = ok ? 1.0 / R : 0.0;
@@ -255,26 +250,42 @@ __global__ void LK_RES_BOUNDS
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        const int q = lane & 31, half = lane >> 5;
-        // component q = sum over rows of r[a] * r[b]:  A(i,j) = sum (h_i / R) h_j (upper triangle, row-major: q < 21,
-        // a = 7 + i, b = j), b_i = sum (h_i / R) z (q = 21 + i: a = 7 + i, b = 6), sum R (q = 27: 13, 14), count (14, 14).
-        // Packed as a | b << 4, eight entries per 64-bit word.
-        const unsigned long long tw = (q < 8) ? 0x2818574737271707ull : (q < 16) ? 0x3a59493929584838ull : (q < 24) ? 0x6968675c5b4b5a4aull : 0xeeeeeeeeed6c6b6aull;
-        const unsigned int ab = (unsigned int)(tw >> ((q & 7) * 8)) & 0xffu;
-        const int a = (int)(ab & 15u), b = (int)(ab >> 4);
-        const double* base = rows + (half * 32) * LK_ROW2;
-        double acc = 0.0;
+    const int q = lane & 31, half = lane >> 5;
+    // component q = sum over rows of r[a] * r[b]:  A(i,j) = sum (h_i / R) h_j (upper triangle, row-major: q < 21,
+    // a = 7 + i, b = j), b_i = sum (h_i / R) z (q = 21 + i: a = 7 + i, b = 6), sum R (q = 27: 13, 14), count (14, 14).
+    // Packed as a | b << 4, eight entries per 64-bit word.
+    const unsigned long long tw = (q < 8) ? 0x2818574737271707ull : (q < 16) ? 0x3a59493929584838ull : (q < 24) ? 0x6968675c5b4b5a4aull : 0xeeeeeeeeed6c6b6aull;
+    const unsigned int ab = (unsigned int)(tw >> ((q & 7) * 8)) & 0xffu;
+    const int a = (int)(ab & 15u), b = (int)(ab >> 4);
+    const double* base = rows + (half * 32) * LK_ROW2;
+    double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const double* r = base + j * LK_ROW2;
-            acc = __builtin_fma(r[a], r[b], acc);
-        }
-        acc += __shfl_xor(acc, 32, LK_WAVE);
-        if (lane < LK_NPART) {
-            const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
-            partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
-        }
+    for (int j = 0; j < 32; ++j) {
+        const double* r = base + j * LK_ROW2;
+        acc = __builtin_fma(r[a], r[b], acc);
+    }
+    acc += __shfl_xor(acc, 32, LK_WAVE);
+    return acc;
+}
+
+// One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
+template <bool EMIT_ROWS>
+__global__ void LK_RES_BOUNDS
+    lk_residual_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                       size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
+                       ResidualOut out, size_t out_slot_stride) {
+    // per-wave LDS region holding the wave's 64 observation rows
+    __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
+    const int slot = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    BucketConst bc;
+    load_bucket_const<false>(&filters[slot], pr, bc);
+    const double acc = residual_tile<EMIT_ROWS>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
+                                                blockIdx.x * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
+    if (lane < LK_NPART) {
+        const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
+        partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
     }
 }
 
@@ -363,11 +374,9 @@ __device__ __forceinline__ void queue_point_on_root(const LkMap& map, int root, 
 }
 
 // KILO.cc:216-230 + voxel_map.cc:343-358 (hash half).  pts are the bucket's points (bucket-local i).
-__global__ void __launch_bounds__(LK_PB)
-    lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                        int n, float* __restrict__ world /* n x 4 or null */, int do_insert) {
-    const int i = blockIdx.x * LK_PB + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkParams& pr, const LkFilter* __restrict__ filters,
+                                                    const lk_point* __restrict__ pts, float* __restrict__ world /* n x 4 or null */,
+                                                    const int do_insert, const int i) {
     const LkFilter* f = &filters[0];
     BucketConst bc;
     load_bucket_const(f, pr, bc);
@@ -409,4 +418,11 @@ __global__ void __launch_bounds__(LK_PB)
         if (ignore) return;
     }
     queue_point_on_root(map, root, i);
+}
+__global__ void __launch_bounds__(LK_PB)
+    lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                        int n, float* __restrict__ world /* n x 4 or null */, int do_insert) {
+    const int i = blockIdx.x * LK_PB + threadIdx.x;
+    if (i >= n) return;
+    dev_reproject_point(map, pr, filters, pts, world, do_insert, i);
 }

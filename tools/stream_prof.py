@@ -21,7 +21,7 @@ for k in range(1, 4):
     g.process_scan_dev(d + k * B.N_PTS * 16, B.N_PTS, t_after + 0.1 * k, off, dt)
 g.profile_enable(0)
 tot = 0
-for name in ("predict", "residual", "update", "reproject", "insert_light", "insert_group", "insert", "insert_fallback"):
+for name in ("small_bucket", "predict", "residual", "update", "reproject", "insert_light", "insert_group", "insert", "insert_fallback"):
     n, ms = g.profile_get(name)
     print(f"{name:14s} launches {n:3d}  avg {1e3*ms/max(n,1):8.1f} us")
     tot += ms
