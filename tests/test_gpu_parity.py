@@ -391,6 +391,38 @@ def test_config3_full_size(big):
     assert set(so) == set(sg)
 
 
+def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
+    """16 consecutive 100 k-point scans (5 buckets each) with map insert on a moving trajectory: the map keeps growing,
+    leaves refit / freeze / get cut, point blocks are recycled, the generic insert fallback and the long-list replay get
+    their share.  Match counts within 2 per scan (a gate within rounding of its threshold may flip), positions to 1e-6,
+    the same map at the end, no pool overflow."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 8.0
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, dense=60000)
+    worst = 0.0
+    for k in range(16):
+        tb = t0 + 0.1 * k
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=4100 + k, seed_noise=4200 + k)
+        po, _ = o.process_scan(pts, tb)
+        pg, _ = g.process_scan(pts, tb)
+        assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (5, 5), k
+        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (k, po.n_effect, pg.n_effect)
+        xo, _ = o.get_state()
+        xg, _ = g.get_state()
+        worst = max(worst, float(np.abs(xo[9:12] - xg[9:12]).max()))
+        assert np.allclose(xo, xg, rtol=1e-6, atol=1e-6), (k, np.abs(xo - xg).max())
+    assert worst < 1e-6, worst
+    so, sg = scenes.canon_map(o.map_export()), scenes.canon_map(g.map_export())
+    assert set(so) == set(sg)
+    roots, nodes, blocks = g.map_stats()
+    assert nodes >= roots > 20000 and blocks > 1000
+    g.close()
+    o.close()
+
+
 def test_config2_full_size_residuals(big, hip_lib):
     """Config 2: 100 000 points, one state, residual rows only, against the map the ORACLE built (SURVEY.md 8d:
     'map pre-built by replaying warm-up scans through the oracle') - isolates K1+K2 at full size."""
