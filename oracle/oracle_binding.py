@@ -254,7 +254,7 @@ def build_ref(force=False):
     """Compile oracle/_ref from the reference tree when it is present (this container); a prebuilt library is used
     as is where the tree does not exist (GPU box).  Returns the path, or None when neither exists."""
     if os.path.exists(_REF_SRC):
-        deps = [os.path.join(_HERE, "ref_capi.cc"), os.path.join(_HERE, "ref_kilo_capi.cc"), os.path.join(_HERE, "ref_decode_capi.cc"),
+        deps = [os.path.join(_HERE, "ref_capi.cc"), os.path.join(_HERE, "ref_kilo_capi.cc"), os.path.join(_HERE, "ref_decode_capi.cc"), os.path.join(_HERE, "ref_tum_capi.cc"),
                 os.path.join(_HERE, "export_blob.hpp"), os.path.join(_HERE, "Makefile"), _REF_SRC, _REF_SRC.replace("eskf.cc", "KILO.cc"),
                 _REF_SRC.replace("eskf.cc", "voxel_map.cc"), os.path.join(_HERE, "shim", "Eigen", "Dense")]
         if force or not os.path.exists(_REF_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_REF_LIB) for d in deps):
@@ -352,6 +352,20 @@ def ref_decode(raw, layout, time_scale, filter_num, blind, header_stamp=0.0):
                           C.c_double(header_stamp), _p(out), C.byref(n), C.byref(tb), C.byref(te))
     assert rc == 0, rc
     return out[: n.value], tb.value, te.value
+
+
+def ref_write_tum(stamps, rots, poss):
+    """The reference's own TrajectorySaver::write (trajectory_saver.hpp:43-50, oracle/_ref) -> text of the file it wrote."""
+    rl = ref_lib()
+    assert rl is not None
+    t, R, p = _f64(stamps), _f64(rots).reshape(-1, 9), _f64(poss).reshape(-1, 3)
+    buf = C.create_string_buffer(1024)
+    rc = rl._l.lkt_write_tum(_p(t), _p(R), _p(p), C.c_size_t(len(t)), buf, C.c_size_t(1024))
+    assert rc == 0, rc
+    path = buf.value.decode()
+    text = open(path).read()
+    os.remove(path)
+    return text
 
 
 def _hooks(which):

@@ -353,3 +353,26 @@ def test_decode_matches_the_reference(lidar_type):
         # double for the Ouster handler (-O0..-O2 round it like the oracle does), so the time stamps are compared to float
         # precision only.  They stamp the first frame; no point arithmetic depends on them.
         assert abs(gb - wb) <= 1e-7 * max(1.0, abs(wb)) and abs(ge - we) <= 1e-7 * max(1.0, abs(we)), (gb, wb, ge, we)
+
+
+# ----------------------------------------------------------------------------- around the path: the TUM trajectory writer
+def test_tum_writer_matches_the_reference(tmp_path):
+    """TrajectorySaver::write (trajectory_saver.hpp:43-50: `t tx ty tz qx qy qz qw`, fixed, 9 decimals, quaternion from the
+    rotation matrix) vs legkilo_amd.tum.write_tum - the same text, line for line, over all four branches of the
+    matrix-to-quaternion conversion."""
+    from legkilo_amd import tum
+
+    rng = np.random.default_rng(21)
+    rots = [np.eye(3)]
+    for ax in range(3):                       # rotations by ~pi about each axis: trace < 0, each diagonal branch
+        v = np.zeros(3)
+        v[ax] = 3.1
+        rots.append(ob.exp_log(v + rng.normal(0, 0.02, 3))[0])
+    rots += [ob.exp_log(rng.normal(0, 1.5, 3))[0] for _ in range(40)]
+    stamps = 1.7e9 + np.cumsum(rng.uniform(0.05, 0.15, len(rots)))
+    poss = rng.normal(0, 50, (len(rots), 3))
+    want = ob.ref_write_tum(stamps, np.array(rots), poss)
+    tum.write_tum(tmp_path / "a.tum", stamps, rots, poss)
+    got = open(tmp_path / "a.tum").read()
+    assert got.count("\n") == len(rots)
+    assert got == want
