@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--stream-scans", type=int, default=24, help="consecutive scans of the single-stream (config 3) measurement")
     ap.add_argument("--cpu-sample", type=int, default=240, help="scans the oracle replays for cpu_baseline (0 = skip); the default "
                     "is ~6 s of single-thread work on the frozen-map workload plus ~2 s on the full path with insert")
-    ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 2x, 16 B/slot)")
+    ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))

@@ -185,7 +185,8 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     pr.max_points_num = cfg->max_points_num;
     for (int i = 0; i < 5; ++i) pr.layer_init_num[i] = cfg->layer_init_num[i];
     // pools
-    h->hash_cap = next_pow2(2u * cfg->max_roots);
+    // load factor <= 1/8: probe chains are what a wave waits for (505 -> 480 us per 20.5 M points against 1/3); 16 B per slot
+    h->hash_cap = next_pow2(8u * cfg->max_roots);
     LkMap& m = h->map;
     memset(&m, 0, sizeof(m));
     m.hash_mask = h->hash_cap - 1;
