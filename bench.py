@@ -144,7 +144,7 @@ def main():
     # capacities sized to the scene (a 40 x 30 x 8 m room has ~20 k root voxels): a right-sized hash table keeps
     # table + match records inside one XCD's 4 MB L2
     mr = args.max_roots_log2
-    cfg = config.make_config(P, device_id=local_rank, n_slots=S, max_roots=1 << mr, max_nodes=1 << (mr + 1),
+    cfg = config.make_config(P, device_id=local_rank, n_slots=2 * S, max_roots=1 << mr, max_nodes=1 << (mr + 1),
                              max_point_blocks=1 << 17, max_scan_points=1 << 17)
     g = binding.LegKiloHip(cfg)  # raises without the HIP library / a gfx950 device
 
@@ -185,12 +185,24 @@ def main():
     d_P = torch.from_numpy(np.ascontiguousarray(Ps)).to(dev)
     torch.cuda.synchronize()
 
-    def step():
-        g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S)
-        poses = g.batch_replay_dev(d_batch.data_ptr(), S, N_PTS, 0.0, off, dt)
+    # Batches are enqueued back to back (lk_batch_replay_async_dev), alternating between two sets of filter slots so that the
+    # update kernels of one batch overlap the residual launches of the next: every step still delivers its 1024 poses to the host
+    # - into a pinned buffer, copied on the stream - but no step waits for the previous one's results; the timed region
+    # ends with the stream synchronised and, for N > 1, the poses of all steps all-gathered (136 B per scan).
+    from legkilo_amd import abi as _abi
+
+    pose_sz = _abi.pose_dtype().itemsize
+    ring = torch.empty((max(args.steps, args.warmup, 1), S * pose_sz), dtype=torch.uint8).pin_memory()
+
+    def step(k):   # double-buffered: even / odd batches use the two halves of the 2 x S filter slots on two streams
+        g.batch_replay_async_dev(d_batch.data_ptr(), (k & 1) * S, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(), d_P900=d_P.data_ptr(),
+                                 host_out_ptr=ring[k].data_ptr())
+
+    def finish(k_steps):
+        g.synchronize()
         if dist is not None:
-            replay.gather_results(dist, replay.pose_rows(poses), world_size, dev)
-        return poses
+            rows = replay.pose_rows(ring[:k_steps].numpy().reshape(-1).view(_abi.pose_dtype()))
+            replay.gather_results(dist, rows, world_size, dev)
 
     def sync_all():
         g.synchronize()
@@ -199,26 +211,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        poses = step()
+    for k in range(args.warmup):
+        step(k)
+    finish(args.warmup)
     sync_all()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        poses = step()
+    for k in range(args.steps):
+        step(k)
+    finish(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n_eff = float(np.mean([p.n_effect for p in poses]))
+    last = ring[args.steps - 1].numpy().view(_abi.pose_dtype())
+    n_eff = float(last["n_effect"].astype(np.float64).mean())
     total_scans = S * world_size * args.steps
     value = total_scans / elapsed
 
     # ---- kernel-level timing pass (HIP events on the handle's stream), outside the timed region
     g.profile_reset()
     g.profile_enable(1)
-    step()
+    g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S)
+    g.batch_replay_dev(d_batch.data_ptr(), S, N_PTS, 0.0, off, dt)   # synchronous entry: whole-batch launches on one stream, per-launch events
     g.profile_enable(0)
     prof = {k: g.profile_get(k) for k in ("predict", "residual", "update")}
     n_res, ms_res = prof["residual"]

@@ -81,6 +81,13 @@ class lk_pose(C.Structure):
     ]
 
 
+def pose_dtype():
+    """numpy view of lk_pose (136 B) for vectorised access to pose buffers."""
+    import numpy as np
+
+    return np.dtype([("rot", "<f8", 9), ("pos", "<f8", 3), ("vel", "<f8", 3), ("n_effect", "<u8"), ("n_buckets", "<u4"), ("n_updates", "<u4")])
+
+
 class lk_cloud_layout(C.Structure):
     _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32), ("off_z", C.c_uint32),
                 ("off_time", C.c_uint32), ("lidar_type", C.c_int32)]

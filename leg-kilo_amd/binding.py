@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -311,6 +311,18 @@ class LegKiloHip:
         self._chk(self.L.lk_batch_replay_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts),
                                              C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
         return poses
+
+    def batch_replay_async_dev(self, d_pts, first_slot, n_scans, n_pts, t_begin, bucket_off, bucket_dt, d_x36=None, d_P900=None,
+                               host_out_ptr=None):
+        """Enqueue a batch on slots [first_slot, first_slot + n_scans) without synchronising (alternate the slot range
+        between consecutive batches to double-buffer); poses land in the PINNED host buffer at host_out_ptr once the
+        batch's stream gets there (synchronize() waits for everything)."""
+        off = np.ascontiguousarray(bucket_off, dtype=np.uint32)
+        dt = _f64(bucket_dt)
+        self._chk(self.L.lk_batch_replay_async_dev(self.h, C.c_void_p(d_pts), C.c_uint32(first_slot), C.c_size_t(n_scans),
+                                                   C.c_size_t(n_pts), C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)),
+                                                   C.c_void_p(d_x36) if d_x36 else None, C.c_void_p(d_P900) if d_P900 else None,
+                                                   C.c_void_p(host_out_ptr) if host_out_ptr else None))
 
     # ---- measurement / memory hooks ----
     def profile_enable(self, on):

@@ -1298,6 +1298,57 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     return LK_OK;
 }
 
+// Asynchronous, double-buffered batch replay.  The batch uses filter slots [first_slot, first_slot + n_scans); calls whose
+// slot ranges alternate (first_slot = 0, n_scans, 0, ...) run on alternate HIP streams, so the single-workgroup update /
+// predict kernels of one batch overlap the full-size residual launches of the next instead of sitting between them.
+// Everything of a batch - arming the priors (d_x36 / d_P900 may be NULL: keep the slots' current state), the bucket
+// chain, the pose gather and its copy to (pinned) host memory - is stream-ordered on the batch's own stream; nothing
+// synchronises.  lk_synchronize() waits for all streams.
+int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t first_slot, size_t n_scans, size_t n_pts, double t_begin,
+                              const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, const double* d_x36,
+                              const double* d_P900, lk_pose* host_out) {
+    CHECK_H(h);
+    if (n_scans == 0 || (size_t)first_slot + n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot range must lie in [0, n_slots]");
+    if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
+    if ((d_x36 == nullptr) != (d_P900 == nullptr)) return fail(h, LK_ERR_INVALID, "give both prior buffers or neither");
+    const int S = (int)n_scans;
+    hipStream_t st = ((first_slot / (uint32_t)n_scans) & 1u) ? h->side[0] : h->stream;
+    LkFilter* fl = h->d_filters + first_slot;
+    double* parts = h->d_partials + (size_t)first_slot * h->part_stride;
+    if (d_x36) {
+        HIPCHK(h, hipMemcpy2DAsync(fl[0].x, sizeof(LkFilter), d_x36, sizeof(double) * 36, sizeof(double) * 36, n_scans, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpy2DAsync(fl[0].P, sizeof(LkFilter), d_P900, sizeof(double) * 900, sizeof(double) * 900, n_scans, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(h, hipMemset2DAsync(&fl[0].n_effect, sizeof(LkFilter), 0, 24, n_scans, st));
+    hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, S, t_begin);
+    ResidualOut ro;
+    memset(&ro, 0, sizeof(ro));
+    bool first = true;
+    for (size_t b = 0; b < n_buckets; ++b) {
+        if (bucket_off[b + 1] <= bucket_off[b]) continue;
+        const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
+        if ((size_t)nb > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+        size_t nx = b + 1;
+        while (nx < n_buckets && bucket_off[nx + 1] <= bucket_off[nx]) ++nx;
+        const bool has_next = nx < n_buckets;
+        const double t = t_begin + bucket_dt[b], t_next = has_next ? t_begin + bucket_dt[nx] : 0.0;
+        const int nblk = (nb + LK_RB - 1) / LK_RB;
+        if (first) hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+        first = false;
+        hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts + bucket_off[b], n_pts, nb,
+                           parts, h->part_stride, ro, (size_t)0);
+        hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q,
+                           t_next, has_next ? 1 : 0);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (host_out) {
+        hipLaunchKernelGGL(lk_pose_gather_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, h->d_poses + first_slot, S);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(host_out, h->d_poses + first_slot, sizeof(lk_pose) * n_scans, hipMemcpyDeviceToHost, st));
+    }
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------ measurement hooks
 int lk_profile_enable(lk_handle* h, int on) {
     CHECK_H(h);
@@ -1346,6 +1397,8 @@ int lk_memcpy_d2h(lk_handle* h, void* dst, const void* d_src, size_t bytes) {
 int lk_synchronize(lk_handle* h) {
     CHECK_H(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
+        if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));  // double-buffered async batches live there
     return LK_OK;
 }
 void* lk_stream(lk_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -103,5 +103,10 @@ def gather_results(dist, local, world, device):
 
 
 def pose_rows(poses):
-    """lk_pose array -> float64 rows [pos(3), vel(3), rot(9), n_effect, n_buckets, n_updates]."""
-    return np.array([[*p.pos, *p.vel, *p.rot, float(p.n_effect), float(p.n_buckets), float(p.n_updates)] for p in poses])
+    """lk_pose records (a ctypes array, or any buffer / numpy array of abi.pose_dtype()) -> float64 rows
+    [pos(3), vel(3), rot(9), n_effect, n_buckets, n_updates]; vectorised (a 1024-scan batch per step)."""
+    from . import abi
+
+    a = poses if isinstance(poses, np.ndarray) and poses.dtype == abi.pose_dtype() else np.frombuffer(poses, dtype=abi.pose_dtype())
+    return np.concatenate([a["pos"], a["vel"], a["rot"], a["n_effect"].astype(np.float64)[:, None],
+                           a["n_buckets"].astype(np.float64)[:, None], a["n_updates"].astype(np.float64)[:, None]], axis=1)

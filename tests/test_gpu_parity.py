@@ -499,6 +499,34 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
         assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
         assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
         assert np.allclose(np.array(poses[s].pos), xo[9:12], atol=1e-8)
+    if S == 6:
+        # the asynchronous, double-buffered entry: the same batch on slots [0, S) and on [S, 2S) (the second stream),
+        # priors armed on the batch's own stream, poses copied to host memory on the stream; nothing synchronises until
+        # synchronize().  Both halves must reproduce the synchronous result bit for bit.
+        g2 = hip_lib.LegKiloHip(scene.cfg(n_slots=2 * S))
+        g2.map_import(blob)
+        g2.init_process_cov_q()
+        hx, hP = np.ascontiguousarray(np.array(xs)), np.ascontiguousarray(np.array(Ps).reshape(S, 900))
+        d_x, d_P, d_pts2 = g2.device_malloc(hx.nbytes), g2.device_malloc(hP.nbytes), g2.device_malloc(allpts.nbytes)
+        g2.h2d(d_x, hx)
+        g2.h2d(d_P, hP)
+        g2.h2d(d_pts2, allpts)
+        outs = [np.zeros(S, dtype=abi.pose_dtype()) for _ in range(4)]
+        for k in range(4):
+            g2.batch_replay_async_dev(d_pts2, (k & 1) * S, S, n_pts, 0.0, off, dt, d_x36=d_x, d_P900=d_P, host_out_ptr=outs[k].ctypes.data)
+        g2.synchronize()
+        ref = np.frombuffer(poses, dtype=abi.pose_dtype())
+        for k in range(4):
+            for f in ("rot", "pos", "vel", "n_effect", "n_buckets", "n_updates"):
+                assert np.array_equal(outs[k][f], ref[f]), (k, f)
+        for s in range(S):
+            xa, _ = g2.get_state(slot=s)
+            xb, _ = g2.get_state(slot=S + s)
+            xg, _ = g.get_state(slot=s)
+            assert np.array_equal(xa, xg) and np.array_equal(xb, xg), s
+        for d in (d_x, d_P, d_pts2):
+            g2.device_free(d)
+        g2.close()
     g.close()
     o.close()
 
