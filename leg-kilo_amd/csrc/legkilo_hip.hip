@@ -39,6 +39,7 @@ struct lk_handle {
     hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
     int replay_groups = 3;
+    bool wave_update = true;  // batch replay: single-wave update kernel (LEGKILO_UPDATE_CLASSIC=1 selects the 256-thread one)
     double last_slide_position[3] = {0.0, 0.0, 0.0};  // voxel_map.h:201
     unsigned int hash_cap = 0;
     LkFilter* d_filters = nullptr;
@@ -157,6 +158,7 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
+    if (const char* e = getenv("LEGKILO_UPDATE_CLASSIC")) h->wave_update = atoi(e) == 0;
     if (const char* e = getenv("LEGKILO_REPLAY_GROUPS")) h->replay_groups = std::min(std::max(atoi(e), 1), (int)lk_handle::kMaxGroups);
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -1267,18 +1269,36 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
             double* parts = h->d_partials + (size_t)s0 * h->part_stride;
             const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
             if (ngroups == 1) {
-                if (k == 0)
-                    LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
+                if (k == 0) {
+                    if (h->wave_update)
+                        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts, 0,
+                                                                h->part_stride, 0.0, h->d_Q, t, 2));
+                    else
+                        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
+                }
                 LAUNCH(h, "residual", hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl,
                                                          pts, n_pts, nb, parts, h->part_stride, ro, (size_t)0));
-                LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts,
-                                                       nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
+                if (h->wave_update)
+                    LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts,
+                                                           nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 3 : 1));
+                else
+                    LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts,
+                                                           nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, t_next, has_next ? 1 : 0));
             } else {
-                if (k == 0) hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+                if (k == 0) {
+                    if (h->wave_update)
+                        hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2);
+                    else
+                        hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+                }
                 hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl, pts, n_pts, nb, parts,
                                    h->part_stride, ro, (size_t)0);
-                hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,
-                                   h->d_Q, t_next, has_next ? 1 : 0);
+                if (h->wave_update)
+                    hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE),
+                                       h->part_stride, t, h->d_Q, t_next, has_next ? 3 : 1);
+                else
+                    hipLaunchKernelGGL(lk_update_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,
+                                       h->d_Q, t_next, has_next ? 1 : 0);
             }
         }
     }
@@ -1333,12 +1353,21 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
         const bool has_next = nx < n_buckets;
         const double t = t_begin + bucket_dt[b], t_next = has_next ? t_begin + bucket_dt[nx] : 0.0;
         const int nblk = (nb + LK_RB - 1) / LK_RB;
-        if (first) hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+        if (first) {
+            if (h->wave_update)
+                hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2);
+            else
+                hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, st, fl, h->d_Q, t);
+        }
         first = false;
         hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts + bucket_off[b], n_pts, nb,
                            parts, h->part_stride, ro, (size_t)0);
-        hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q,
-                           t_next, has_next ? 1 : 0);
+        if (h->wave_update)
+            hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,
+                               h->d_Q, t_next, has_next ? 3 : 1);
+        else
+            hipLaunchKernelGGL(lk_update_kernel, dim3(S), dim3(LK_FB), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q,
+                               t_next, has_next ? 1 : 0);
     }
     HIPCHK(h, hipGetLastError());
     if (host_out) {

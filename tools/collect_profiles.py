@@ -40,19 +40,32 @@ def db(path):
 
 rows = {}
 cur = db(f"prof_{tag}_stats").cursor()
-for name, gx, gy, wx, dur, vg, sg, lds, scr in cur.execute(
-        "select name, grid_x, grid_y, workgroup_x, duration, vgpr_count, sgpr_count, lds_size, scratch_size from kernels"):
-    key = (short(name), gx // max(wx, 1), gy)
+disp = list(cur.execute("select name, grid_x, grid_y, workgroup_x, duration, vgpr_count, sgpr_count, lds_size, scratch_size, start, end "
+                        "from kernels order by start"))
+# Launches of the asynchronous batch loop run two at a time (one per stream) and share the GPU: their trace durations
+# are not per-launch costs.  A launch is "shared" when other chip-filling launches (>= 1024 workgroups) cover more than
+# 20 % of its interval; shared and alone launches are reported on separate rows.
+big = [(d[9], d[10], i) for i, d in enumerate(disp) if (d[1] // max(d[3], 1)) * d[2] >= 1024]
+shared = [False] * len(disp)
+for i, d in enumerate(disp):
+    if (d[1] // max(d[3], 1)) * d[2] < 1024:
+        continue
+    cover = sum(max(0, min(d[10], e) - max(d[9], s)) for s, e, j in big if j != i and s < d[10] and e > d[9])
+    shared[i] = cover > 0.2 * max(d[4], 1)
+for i, (name, gx, gy, wx, dur, vg, sg, lds, scr, _s, _e) in enumerate(disp):
+    key = (short(name), gx // max(wx, 1), gy, "shared" if shared[i] else "alone")
     r = rows.setdefault(key, dict(calls=0, total_ns=0, vgpr=vg, sgpr=sg, lds=lds, scratch=scr))
     r["calls"] += 1
     r["total_ns"] += dur
 tot = sum(r["total_ns"] for r in rows.values())
 with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["kernel", "blocks_x", "blocks_y", "calls", "total_us", "avg_us", "pct", "vgpr", "sgpr", "lds_bytes", "scratch_bytes"])
+    w.writerow(["kernel", "blocks_x", "blocks_y", "gpu", "calls", "total_us", "avg_us", "pct", "vgpr", "sgpr", "lds_bytes", "scratch_bytes"])
     for key, r in sorted(rows.items(), key=lambda kv: -kv[1]["total_ns"]):
-        w.writerow([key[0], key[1], key[2], r["calls"], round(r["total_ns"] / 1e3, 1), round(r["total_ns"] / r["calls"] / 1e3, 2),
+        w.writerow([key[0], key[1], key[2], key[3], r["calls"], round(r["total_ns"] / 1e3, 1), round(r["total_ns"] / r["calls"] / 1e3, 2),
                     round(100.0 * r["total_ns"] / tot, 2), r["vgpr"], r["sgpr"], r["lds"], r["scratch"]])
+if not os.path.isdir(os.path.join(G, f"prof_{tag}_fetch")):
+    sys.exit(0)  # kernel-trace pass only
 
 
 def pmc(path, counter, kernel_like):
