@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--stream-scans", type=int, default=24, help="consecutive scans of the single-stream (config 3) measurement")
     ap.add_argument("--cpu-sample", type=int, default=240, help="scans the oracle replays for cpu_baseline (0 = skip); the default "
                     "is ~6 s of single-thread work on the frozen-map workload plus ~2 s on the full path with insert")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     args = ap.parse_args()
 
@@ -283,6 +284,33 @@ def main():
     extra = {"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
              "mean_n_effect": n_eff, "rccl_map_broadcast_ms": bcast_ms,
              "rccl_map_scatter_allgather_ms": bcast2_ms}
+    # ---- extra: the same batch step when the scans start in (pinned) host memory: upload of batch k+1 on a copy stream under
+    # the replay of batch k (the boundary also takes host buffers; this rate is never `value`)
+    if rank == 0 and world_size == 1 and not args.no_pcie:
+        try:
+            h_batch = torch.empty(d_batch.shape, dtype=d_batch.dtype).pin_memory()
+            h_batch.copy_(d_batch)
+            bufs = [d_batch, torch.empty_like(d_batch)]
+            cs = torch.cuda.Stream()
+            with torch.cuda.stream(cs):
+                bufs[1].copy_(h_batch, non_blocking=True)
+            cs.synchronize()
+            t_p = time.perf_counter()
+            KP = 3
+            for k in range(KP):
+                with torch.cuda.stream(cs):
+                    bufs[(k + 1) & 1].copy_(h_batch, non_blocking=True)
+                g.batch_replay_async_dev(bufs[k & 1].data_ptr(), (k & 1) * S, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(),
+                                         d_P900=d_P.data_ptr(), host_out_ptr=ring[0].data_ptr())
+                g.synchronize()
+                cs.synchronize()
+            t_p = (time.perf_counter() - t_p) / KP
+            extra["pcie_inclusive_scans_per_s"] = round(S / t_p, 1)
+            extra["pcie_inclusive_ms_per_step"] = round(t_p * 1e3, 3)
+            extra["pcie_h2d_GBs"] = round(d_batch.numel() / t_p / 1e9, 1)
+            del h_batch, bufs
+        except Exception as e:   # host memory for the pinned copy may be short on some boxes
+            extra["pcie_inclusive_error"] = str(e)[:120]
     cpu_baseline = None
     sscans = []
     if rank == 0 and args.stream_scans >= 2:
