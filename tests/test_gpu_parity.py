@@ -531,6 +531,71 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     o.close()
 
 
+def test_batch_update_kernels_agree_on_edge_buckets(scene, oracle_lib, hip_lib, monkeypatch):
+    """Batch replay has two implementations of update(k) + predict(k+1): the single-wave kernel (default) and the
+    256-thread one (LEGKILO_UPDATE_CLASSIC=1).  They must agree BIT FOR BIT, also on buckets that match nothing (no
+    update, predict only) and on buckets with exactly one match (the +1e-4 branch of eskf.cc:98-104), and both must
+    reproduce the oracle."""
+    S, n_pts, nb = 4, 4000, 5
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    o.set_map_insert(False)
+    tb = t0 + 1.3
+    base = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=7117, seed_noise=7227)
+    off, dt = synth.buckets_of(base)
+    rng = np.random.default_rng(7337)
+    x0 = synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5)
+    P0 = 1e-4 * np.eye(30)
+    far = base.copy()
+    fxyz = (rng.uniform(-1, 1, (n_pts, 3)) + np.array([300.0, -200.0, 50.0])).astype(np.float32)
+    far["x"], far["y"], far["z"] = fxyz[:, 0], fxyz[:, 1], fxyz[:, 2]
+    # one matching point per bucket, the rest far away: candidates that match under the prior, deep inside their gate
+    o.set_state(x0, P0)
+    valid = o.residuals(scenes.xyz_of(base))[3].astype(bool)
+    single = far.copy()
+    for b in range(nb):
+        cand = np.flatnonzero(valid[off[b]:off[b + 1]])
+        assert len(cand) > 10
+        k = off[b] + cand[len(cand) // 2]
+        for f in ("x", "y", "z"):
+            single[f][off[b]] = base[f][k]
+    mixed = base.copy()
+    mixed[: off[2]] = far[: off[2]]          # two empty buckets, then three normal ones
+    scans = [base, far, single, mixed]
+    allpts = np.concatenate(scans)
+    states = []
+    for classic in ("1", "0"):
+        monkeypatch.setenv("LEGKILO_UPDATE_CLASSIC", classic)
+        g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+        monkeypatch.delenv("LEGKILO_UPDATE_CLASSIC")
+        g.map_import(blob)
+        g.init_process_cov_q()
+        d_pts = g.device_malloc(allpts.nbytes)
+        g.h2d(d_pts, allpts)
+        g.batch_set_priors(np.array([x0] * S), np.array([P0] * S))
+        poses = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
+        states.append(([g.get_state(slot=s) for s in range(S)], [(p.n_buckets, p.n_updates, p.n_effect) for p in poses]))
+        g.device_free(d_pts)
+        g.close()
+    (st_c, cnt_c), (st_w, cnt_w) = states
+    assert cnt_c == cnt_w, (cnt_c, cnt_w)
+    for s in range(S):
+        assert np.array_equal(st_c[s][0], st_w[s][0]) and np.array_equal(st_c[s][1], st_w[s][1]), s
+    assert cnt_w[1] == (nb, 0, 0), cnt_w[1]                  # nothing matched: five predicts, no update
+    assert cnt_w[2][1] >= 1 and cnt_w[2][2] == cnt_w[2][1], cnt_w[2]   # every updating bucket of the single scan had N == 1
+    assert cnt_w[3][1] == nb - 2, cnt_w[3]
+    for s in range(S):
+        o.set_state(x0, P0)
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(scans[s], 0.0)
+        xo, Po = o.get_state()
+        assert (po.n_buckets, po.n_updates, po.n_effect) == cnt_w[s], (s, cnt_w[s])
+        assert np.allclose(xo, st_w[s][0], rtol=1e-8, atol=1e-9), (s, np.abs(xo - st_w[s][0]).max())
+        assert np.allclose(Po, st_w[s][1], rtol=1e-6, atol=1e-11), (s, np.abs(Po - st_w[s][1]).max())
+    o.close()
+
+
 def test_block_recycling_and_capacity_errors(scene, oracle_lib, hip_lib):
     """Point blocks retired by freezes / cuts are re-used from the next bucket on: the pool's high-water mark stays
     near the number of LIVE blocks instead of growing with every leaf that ever existed; exhausting a pool is a loud
