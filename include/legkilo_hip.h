@@ -309,6 +309,16 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
                               const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, const double* d_x36,
                               const double* d_P900, lk_pose* host_out);
 
+/* Ragged batch: the scans of a recorded run differ in size, in their time buckets (KILO.cc:375-378) and in their start
+ * time.  Scan s = d_pts[scan_off[s] .. scan_off[s+1]) (scan_off: n_scans + 1 entries) on filter slot s; n_buckets[s] buckets
+ * whose bounds (n_buckets[s] + 1 offsets relative to the scan's first point, first 0, last = points in the scan) and time
+ * offsets (n_buckets[s] values, added to t_begin[s]) are the next rows of bucket_off / bucket_dt (rows concatenated in
+ * scan order).  Empty buckets are skipped.  Frozen map, priors from lk_batch_set_priors(_dev); synchronous; out may be
+ * NULL.  What a bucket loop of KILO::process (KILO.cc:375-395) over each scan would give, for all scans at once. */
+int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                               const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                               const double* t_begin, lk_pose* out);
+
 /* ---- measurement hooks ---- */
 int lk_profile_enable(lk_handle* h, int on);                           /* HIP-event timing around each kernel */
 int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms);

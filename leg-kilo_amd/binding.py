@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -323,6 +323,39 @@ class LegKiloHip:
                                                    C.c_size_t(n_pts), C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)),
                                                    C.c_void_p(d_x36) if d_x36 else None, C.c_void_p(d_P900) if d_P900 else None,
                                                    C.c_void_p(host_out_ptr) if host_out_ptr else None))
+
+    def batch_replay_ragged_dev(self, d_pts, scan_off, bucket_offs, bucket_dts, t_begins, want_poses=True):
+        """Ragged batch on slots [0, n_scans): scan s = d_pts[scan_off[s]:scan_off[s+1]] with its own bucket bounds
+        bucket_offs[s] (n_b + 1 offsets relative to the scan) / time offsets bucket_dts[s] (n_b) and start time t_begins[s]."""
+        n_scans = len(bucket_dts)
+        so = np.ascontiguousarray(scan_off, dtype=np.uint64)
+        assert len(so) == n_scans + 1 and len(bucket_offs) == n_scans and len(t_begins) == n_scans
+        nb = np.array([len(d) for d in bucket_dts], dtype=np.uint32)
+        off = np.ascontiguousarray(np.concatenate([np.asarray(o, dtype=np.uint32) for o in bucket_offs]))
+        dt = _f64(np.concatenate([np.asarray(d, dtype=np.float64) for d in bucket_dts]))
+        assert len(off) == int(nb.sum()) + n_scans
+        tb = _f64(t_begins)
+        poses = (abi.lk_pose * n_scans)() if want_poses else None
+        self._chk(self.L.lk_batch_replay_ragged_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(so), _p(nb), _p(off), _p(dt),
+                                                    _p(tb), poses))
+        return poses
+
+    def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None):
+        """Convenience: host scans (lists of lk_point arrays, time-sorted) -> HBM, buckets = runs of equal curvature
+        (KILO.cc:375-378), optional priors, ragged replay.  Returns the poses."""
+        from . import synth
+
+        if xs is not None:
+            self.batch_set_priors(np.asarray(xs), np.asarray(Ps))
+        allpts = np.ascontiguousarray(np.concatenate(scans))
+        scan_off = np.r_[0, np.cumsum([len(sc) for sc in scans])]
+        tabs = [synth.buckets_of(sc) for sc in scans]
+        d = self.device_malloc(allpts.nbytes)
+        try:
+            self.h2d(d, allpts)
+            return self.batch_replay_ragged_dev(d, scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins)
+        finally:
+            self.device_free(d)
 
     # ---- measurement / memory hooks ----
     def profile_enable(self, on):

@@ -52,6 +52,8 @@ struct lk_handle {
     unsigned char* d_valid = nullptr;
     double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
     lk_pose* d_poses = nullptr;
+    void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev
+    size_t rag_cap = 0;
     double acc_norm = 1.0;
     // grow-only scratch of lk_preprocess_scan
     size_t pre_cap = 0, pre_tmp_bytes = 0;
@@ -237,7 +239,7 @@ void lk_destroy(lk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
-                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses};
+                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -1312,6 +1314,95 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
         rc = fetch_poses(h, tmp.data(), S);
         if (rc) return rc;
         memcpy(out, tmp.data(), sizeof(lk_pose) * n_scans);
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return LK_OK;
+}
+
+// Ragged batch replay: the scans of a recorded run differ in size, in their time buckets and in their start time.  One
+// launch per bucket INDEX over all scans (grid sized by the largest bucket of that index; scans that have run out of
+// buckets leave at once), every scan reading its own tables (LkRagged).  Same kernels' arithmetic as the uniform entry:
+// a ragged batch of equally shaped scans gives the same bits.  Synchronous; priors as for lk_batch_replay_dev.
+int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                               const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                               const double* t_begin, lk_pose* out) {
+    CHECK_H(h);
+    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
+    if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
+    const size_t S = n_scans;
+    // compact away empty buckets (as the uniform entry does) and find the table pitch
+    std::vector<std::vector<unsigned long long>> po(S);
+    std::vector<std::vector<double>> tt(S);
+    size_t row_o = 0, row_t = 0, ldb = 0;
+    for (size_t s = 0; s < S; ++s) {
+        const uint32_t* bo = bucket_off + row_o;
+        const double* bd = bucket_dt + row_t;
+        const size_t nbs = n_buckets[s];
+        if (nbs == 0) return fail(h, LK_ERR_INVALID, "a scan has no buckets");
+        if (bo[0] != 0 || scan_off[s] + bo[nbs] != scan_off[s + 1]) return fail(h, LK_ERR_INVALID, "bucket offsets do not tile the scan");
+        for (size_t b = 0; b < nbs; ++b) {
+            if (bo[b + 1] < bo[b]) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing");
+            if (bo[b + 1] == bo[b]) continue;
+            if ((size_t)(bo[b + 1] - bo[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+            po[s].push_back(scan_off[s] + bo[b]);
+            tt[s].push_back(t_begin[s] + bd[b]);
+        }
+        if (po[s].empty()) return fail(h, LK_ERR_INVALID, "empty scan");
+        po[s].push_back(scan_off[s + 1]);
+        ldb = std::max(ldb, tt[s].size());
+        row_o += nbs + 1, row_t += nbs;
+    }
+    // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32
+    const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_nb = o_tb + 8 * S, bytes = o_nb + 4 * S;
+    std::vector<unsigned char> stage(bytes, 0);
+    auto* hpo = reinterpret_cast<unsigned long long*>(stage.data() + o_po);
+    auto* ht = reinterpret_cast<double*>(stage.data() + o_t);
+    auto* htb = reinterpret_cast<double*>(stage.data() + o_tb);
+    auto* hnb = reinterpret_cast<unsigned int*>(stage.data() + o_nb);
+    std::vector<int> max_n(ldb, 0);
+    for (size_t s = 0; s < S; ++s) {
+        const size_t nbs = tt[s].size();
+        for (size_t b = 0; b <= nbs; ++b) hpo[s * (ldb + 1) + b] = po[s][b];
+        for (size_t b = nbs + 1; b <= ldb; ++b) hpo[s * (ldb + 1) + b] = po[s][nbs];
+        for (size_t b = 0; b < nbs; ++b) {
+            ht[s * ldb + b] = tt[s][b];
+            max_n[b] = std::max(max_n[b], (int)(po[s][b + 1] - po[s][b]));
+        }
+        htb[s] = t_begin[s];
+        hnb[s] = (unsigned int)nbs;
+    }
+    if (bytes > h->rag_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_rag) hipFree(h->d_rag), h->d_rag = nullptr, h->rag_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_rag, bytes + bytes / 2));
+        h->rag_cap = bytes + bytes / 2;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_rag, stage.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `stage` is pageable host memory
+    unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
+    LkRagged rg;
+    rg.pt_off = reinterpret_cast<const unsigned long long*>(dr + o_po);
+    rg.t = reinterpret_cast<const double*>(dr + o_t);
+    rg.nb = reinterpret_cast<const unsigned int*>(dr + o_nb);
+    rg.ldb = (int)ldb;
+    int rc = zero_scan_counters(h, 0, (uint32_t)S);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    LkFilter* fl = h->d_filters;
+    hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, reinterpret_cast<const double*>(dr + o_tb));
+    hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
+    for (size_t b = 0; b < ldb; ++b) {
+        const int nblk = (max_n[b] + LK_RB - 1) / LK_RB;
+        hipLaunchKernelGGL(lk_residual_ragged_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts, rg, (int)b,
+                           h->d_partials, h->part_stride);
+        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg,
+                           (int)b);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (out) {
+        rc = fetch_poses(h, out, (int)S);
+        if (rc) return rc;
     } else {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }

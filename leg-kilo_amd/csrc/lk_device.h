@@ -118,6 +118,15 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;
 };
 
+// Device tables of a RAGGED batch (lk_batch_replay_ragged_dev): every scan has its own number of points, its own
+// time buckets and its own start time.  Passed by value.
+struct LkRagged {
+    const unsigned long long* pt_off;  // [S][ldb + 1]: index into the point array of the first point of bucket b of scan s
+    const double* t;                   // [S][ldb]: absolute time of bucket b of scan s (t_begin + curvature, KILO.cc:376)
+    const unsigned int* nb;            // [S]: number of buckets of scan s
+    int ldb;                           // row pitch of t; pt_off rows have ldb + 1 entries
+};
+
 // ---------------------------------------------------------------- small fp64 helpers
 struct V3 {
     double x, y, z;

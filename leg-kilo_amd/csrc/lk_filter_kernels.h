@@ -362,11 +362,8 @@ __device__ __forceinline__ int tri6(int i, int j) {  // index of (i,j) in the pa
     return r * 6 - r * (r - 1) / 2 + (c - r);
 }
 
-__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
-    lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
-                          const double* __restrict__ Q, double t_next, int mode) {
-    __shared__ WaveSmem sm;
-    LkFilter* f = &filters[blockIdx.x];
+__device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const double* __restrict__ part, int nblk, double t,
+                                                const double* __restrict__ Q, double t_next, int mode) {
     const int lane = threadIdx.x;
     for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
     if (lane < 36) sm.x[lane] = f->x[lane];
@@ -376,7 +373,6 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
 
     if (mode & 1) {
         // -- totals: lane (j, hh) carries the groups g = hh, hh+2, hh+4, hh+6 of lk_update_kernel, four accumulators each
-        const double* part = partials + (size_t)blockIdx.x * slot_stride;
         const int j = lane & 31, hh = lane >> 5;
         double acc[4][4];
 #pragma unroll
@@ -623,6 +619,39 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
         for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
         if (lane < 36) f->x[lane] = sm.x[lane];
     }
+}
+
+__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+    lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
+                          const double* __restrict__ Q, double t_next, int mode) {
+    __shared__ WaveSmem sm;
+    dev_update_wave(&filters[blockIdx.x], sm, partials + (size_t)blockIdx.x * slot_stride, nblk, t, Q, t_next, mode);
+}
+
+// Ragged batch: bucket b of every scan that has one (b == -1: the predict to each scan's first bucket); times, bucket
+// sizes and "is there a next bucket" come from the scan's own tables.
+__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+    lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
+                                 const double* __restrict__ Q, LkRagged rg, int b) {
+    __shared__ WaveSmem sm;
+    const int slot = blockIdx.x;
+    const int nbk = (int)rg.nb[slot];
+    if (b >= nbk) return;
+    const double* T = rg.t + (size_t)slot * rg.ldb;
+    const double* part = partials + (size_t)slot * slot_stride;
+    if (b < 0) {
+        dev_update_wave(&filters[slot], sm, part, 0, 0.0, Q, T[0], 2);
+        return;
+    }
+    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    const int n = (int)(po[b + 1] - po[b]);
+    const bool has_next = b + 1 < nbk;
+    dev_update_wave(&filters[slot], sm, part, (n + LK_WAVE - 1) / LK_WAVE, T[b], Q, has_next ? T[b + 1] : 0.0, has_next ? 3 : 1);
+}
+
+__global__ void lk_set_times_ragged_kernel(LkFilter* filters, int n, const double* __restrict__ t_begin) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) filters[s].last_predict_t = t_begin[s], filters[s].last_update_t = t_begin[s];
 }
 
 // updateByPoints(ObsShared&) on caller rows (class-surface call): one block accumulates A, b

@@ -289,6 +289,32 @@ __global__ void LK_RES_BOUNDS
     }
 }
 
+// Ragged batch: bucket b of every scan that has one.  grid = (waves of the LARGEST bucket b, scans); a workgroup beyond
+// its scan's bucket leaves at once (two scalar loads).
+__global__ void LK_RES_BOUNDS
+    lk_residual_ragged_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                              LkRagged rg, int b, double* __restrict__ partials, size_t part_slot_stride) {
+    __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
+    const int slot = blockIdx.y;
+    if ((unsigned int)b >= rg.nb[slot]) return;
+    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    const unsigned long long base = po[b];
+    const int n = (int)(po[b + 1] - base);
+    if ((int)(blockIdx.x * LK_RB) >= n) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    BucketConst bc;
+    load_bucket_const<false>(&filters[slot], pr, bc);
+    ResidualOut out;
+    out.h6 = nullptr, out.z = nullptr, out.R = nullptr, out.valid = nullptr, out.world = nullptr;
+    const double acc = residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), blockIdx.x * LK_RB + tid, n,
+                                            &stage[wv][0], lane, out, (size_t)0);
+    if (lane < LK_NPART) {
+        const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
+        partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
+    }
+}
+
 // ---------------------------------------------------------------- find-or-create a root voxel
 // voxel_map.cc:345-357.  Lock-free for readers; a creator claims the slot (EMPTY -> LOCKED), writes
 // the key and the root node, then publishes the node id.  A thread that meets a LOCKED slot retries

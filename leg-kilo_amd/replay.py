@@ -110,3 +110,19 @@ def pose_rows(poses):
     a = poses if isinstance(poses, np.ndarray) and poses.dtype == abi.pose_dtype() else np.frombuffer(poses, dtype=abi.pose_dtype())
     return np.concatenate([a["pos"], a["vel"], a["rot"], a["n_effect"].astype(np.float64)[:, None],
                            a["n_buckets"].astype(np.float64)[:, None], a["n_updates"].astype(np.float64)[:, None]], axis=1)
+
+
+def replay_recorded_run(engine, dist, rank, world, device, scans, t_begins, xs, Ps, max_batch):
+    """Batch replay of a recorded run against the engine's (already distributed, frozen) map: scans i in [0, n) are
+    block-partitioned over the ranks (shard_range), every rank replays its block in ragged batches of at most
+    `max_batch` scans (= the engine's filter slots; lk_batch_replay_ragged_dev: every scan keeps its own size, time
+    buckets and start time), and the per-scan result rows (pose_rows) are all-gathered in scan order.
+    `scans` / `t_begins` / `xs` / `Ps` are the full lists on every rank (only the rank's block is touched)."""
+    start, stop = shard_range(len(scans), rank, world)
+    rows = []
+    for a in range(start, stop, max_batch):
+        b = min(a + max_batch, stop)
+        poses = engine.batch_replay_ragged(scans[a:b], t_begins[a:b], xs[a:b], Ps[a:b])
+        rows.append(pose_rows(poses))
+    local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 18))
+    return gather_results(dist, local, world, device) if world > 1 else local

@@ -531,6 +531,67 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     o.close()
 
 
+def test_batch_replay_ragged(scene, oracle_lib, hip_lib):
+    """lk_batch_replay_ragged_dev: scans of different sizes, bucket tables and start times in one batch (what a recorded
+    run looks like) - each must come out as the oracle's own bucket loop over that scan alone; on equally shaped scans the
+    ragged entry reproduces the uniform one bit for bit."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    o.set_map_insert(False)
+    rng = np.random.default_rng(8118)
+    shapes = [(8000, 5), (3000, 3), None, (65, 1), (5000, 7), (1, 1)]   # None: a config-1 scan (VLP-16, ~370 two-ms buckets)
+    scans, tbs, xs, Ps = [], [], [], []
+    for s, shp in enumerate(shapes):
+        tb = t0 + 1.1 + 0.23 * s
+        if shp is None:
+            sc = scenes.vlp_scan_input(scene, tb, 40 + s)
+        else:
+            sc = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=shp[0], n_buckets=shp[1], seed_scan=8200 + s, seed_noise=8300 + s)
+        scans.append(sc)
+        tbs.append(tb)
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+    S = len(scans)
+    nbs = [len(synth.buckets_of(sc)[1]) for sc in scans]
+    assert max(nbs) > 100 and min(nbs) == 1, nbs
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    g.map_import(blob)
+    g.init_process_cov_q()
+    poses = g.batch_replay_ragged(scans, tbs, xs, Ps)
+    for s in range(S):
+        o.set_state(xs[s], Ps[s])
+        o.set_times(tbs[s], tbs[s])
+        po, _ = o.process_scan(scans[s], tbs[s])
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), (s, nbs[s])
+        assert po.n_buckets == nbs[s]
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+        assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+    # equally shaped scans: ragged == uniform, bit for bit
+    uni = [synth.dense_scan(scene.world, scene.traj, t0 + 2.0 + 0.1 * s, scene.P, n=4000, n_buckets=5, seed_scan=8400 + s, seed_noise=8500 + s)
+           for s in range(3)]
+    off, dt = synth.buckets_of(uni[0])
+    allpts = np.concatenate(uni)
+    d_pts = g.device_malloc(allpts.nbytes)
+    g.h2d(d_pts, allpts)
+    g.batch_set_priors(np.array(xs[:3]), np.array(Ps[:3]))
+    g.batch_replay_dev(d_pts, 3, 4000, 0.0, off, dt)
+    ref = [g.get_state(slot=s) for s in range(3)]
+    g.batch_set_priors(np.array(xs[:3]), np.array(Ps[:3]))
+    g.batch_replay_ragged_dev(d_pts, [0, 4000, 8000, 12000], [off] * 3, [dt] * 3, [0.0] * 3)
+    for s in range(3):
+        xr, Pr = g.get_state(slot=s)
+        assert np.array_equal(xr, ref[s][0]) and np.array_equal(Pr, ref[s][1]), s
+    # malformed tables are refused
+    with pytest.raises(hip_lib.LegKiloError):
+        g.batch_replay_ragged_dev(d_pts, [0, 4000, 8000, 12001], [off] * 3, [dt] * 3, [0.0] * 3)
+    g.device_free(d_pts)
+    g.close()
+    o.close()
+
+
 def test_batch_update_kernels_agree_on_edge_buckets(scene, oracle_lib, hip_lib, monkeypatch):
     """Batch replay has two implementations of update(k) + predict(k+1): the single-wave kernel (default) and the
     256-thread one (LEGKILO_UPDATE_CLASSIC=1).  They must agree BIT FOR BIT, also on buckets that match nothing (no

@@ -42,6 +42,55 @@ class StubEngine:
         self.imported = np.array(b, copy=True)
 
 
+class StubReplayEngine:
+    """Answers batch_replay_ragged with poses that encode what it was asked to replay."""
+
+    def __init__(self):
+        self.calls = []
+
+    def batch_replay_ragged(self, scans, t_begins, xs, Ps):
+        from legkilo_amd import abi
+
+        self.calls.append(len(scans))
+        out = np.zeros(len(scans), dtype=abi.pose_dtype())
+        for i, (sc, tb, x) in enumerate(zip(scans, t_begins, xs)):
+            out["pos"][i] = (tb, float(len(sc)), x[9])
+            out["n_buckets"][i] = len(sc) % 7
+        return out
+
+
+def _worker_run(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 11
+    scans = [np.zeros(10 + 3 * i) for i in range(n)]
+    tbs = [0.1 * i for i in range(n)]
+    xs = [np.full(36, float(i)) for i in range(n)]
+    Ps = [np.eye(30)] * n
+    eng = StubReplayEngine()
+    rows = replay.replay_recorded_run(eng, dist, rank, world, torch.device("cpu"), scans, tbs, xs, Ps, max_batch=4)
+    ok = rows.shape == (n, 18) and np.allclose(rows[:, 0], tbs) and np.array_equal(rows[:, 1], [10.0 + 3 * i for i in range(n)]) \
+        and np.array_equal(rows[:, 2], np.arange(float(n))) and np.array_equal(rows[:, 16], [(10 + 3 * i) % 7 for i in range(n)])
+    a, b = replay.shard_range(n, rank, world)
+    ok_calls = sum(eng.calls) == b - a and max(eng.calls) <= 4
+    q.put((rank, bool(ok), bool(ok_calls)))
+    dist.destroy_process_group()
+
+
+def test_replay_recorded_run_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True), (1, True, True)], res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
