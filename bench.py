@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--stream-scans", type=int, default=24, help="consecutive scans of the single-stream (config 3) measurement")
     ap.add_argument("--cpu-sample", type=int, default=240, help="scans the oracle replays for cpu_baseline (0 = skip); the default "
                     "is ~6 s of single-thread work on the frozen-map workload plus ~2 s on the full path with insert")
+    ap.add_argument("--config1-scans", type=int, default=2048, help="scans of the ragged config-1 batch measured as an extra (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     args = ap.parse_args()
@@ -311,6 +312,51 @@ def main():
             del h_batch, bufs
         except Exception as e:   # host memory for the pinned copy may be short on some boxes
             extra["pcie_inclusive_error"] = str(e)[:120]
+    # ---- extra: a recorded-run shaped batch - the reference's own configuration (config 1: VLP-16 scans, voxel-grid
+    # filtered to a few thousand points, 2 ms time bins -> hundreds of small buckets per scan, every scan with its own
+    # tables and start time) through the ragged entry, all 2 x S filter slots in one batch, frozen map
+    c1 = None
+    if rank == 0 and world_size == 1 and args.config1_scans > 0:
+        U1 = 8
+        c1_scans, c1_tb = [], []
+        for k in range(U1):
+            tb = t_after + 0.1 * k
+            raw = synth.vlp16_scan(world, traj, tb, P, seed_noise=7007 + k)
+            pre = synth.preprocess_velodyne(raw, P["filter_num"], P["blind"])
+            c1_scans.append(synth.sort_by_time(synth.voxel_grid_centroid(pre, P["voxel_grid_resolution"])))
+            c1_tb.append(tb)
+        S1 = min(args.config1_scans, 2 * S)
+        tile1 = np.arange(S1) % U1
+        rng1 = np.random.default_rng(7107)
+        xs1 = np.stack([synth.initial_state(traj, c1_tb[u], P) for u in tile1])
+        xs1[:, 9:12] += rng1.normal(0, 0.005, (S1, 3))
+        Ps1 = np.tile((1e-4 * np.eye(30)).reshape(1, 900), (S1, 1))
+        tabs = [synth.buckets_of(sc_) for sc_ in c1_scans]
+        scan_off = np.r_[0, np.cumsum([len(c1_scans[u]) for u in tile1])]
+        allp = np.ascontiguousarray(np.concatenate([c1_scans[u] for u in tile1]))
+        d_c1 = torch.empty(allp.nbytes, dtype=torch.uint8, device=dev)
+        g.h2d(d_c1.data_ptr(), allp)
+        d_x1, d_P1 = torch.from_numpy(xs1).to(dev), torch.from_numpy(Ps1).to(dev)
+        offs, dts, tbs1 = [tabs[u][0] for u in tile1], [tabs[u][1] for u in tile1], [c1_tb[u] for u in tile1]
+
+        def run_c1():
+            g.batch_set_priors_dev(d_x1.data_ptr(), d_P1.data_ptr(), S1)
+            return g.batch_replay_ragged_dev(d_c1.data_ptr(), scan_off, offs, dts, tbs1)
+
+        run_c1()
+        tc = time.perf_counter()
+        for _ in range(3):
+            poses1 = run_c1()
+        el1 = (time.perf_counter() - tc) / 3
+        p1 = np.frombuffer(poses1, dtype=_abi.pose_dtype())
+        extra["config1_ragged_scans_per_s"] = round(S1 / el1, 1)
+        extra["config1_ragged_ms_per_batch"] = round(el1 * 1e3, 2)
+        extra["config1_batch"] = int(S1)
+        extra["config1_points_per_scan"] = round(float(len(allp)) / S1, 1)
+        extra["config1_buckets_per_scan"] = round(float(p1["n_buckets"].mean()), 1)
+        extra["config1_mean_n_effect"] = round(float(p1["n_effect"].astype(np.float64).mean()), 1)
+        c1 = (c1_scans, c1_tb, xs1, Ps1, tile1)
+        del d_c1, d_x1, d_P1
     cpu_baseline = None
     sscans = []
     if rank == 0 and args.stream_scans >= 2:
@@ -374,6 +420,18 @@ def main():
                 tc = time.perf_counter()
                 o.process_scan(scans[tile[s]], 0.0, with_sort=True)
                 tcs.append(time.perf_counter() - tc)
+            if c1 is not None:   # the same config-1 scans on the CPU port, one at a time (frozen map)
+                c1_scans, c1_tb, xs1, Ps1, tile1 = c1
+                t1s = []
+                for s in range(min(16, len(tile1))):
+                    u = tile1[s]
+                    o.set_state(xs1[s], Ps1[s].reshape(30, 30))
+                    o.set_times(c1_tb[u], c1_tb[u])
+                    tc = time.perf_counter()
+                    o.process_scan(c1_scans[u], c1_tb[u], with_sort=True)
+                    t1s.append(time.perf_counter() - tc)
+                extra["config1_cpu_port_scans_per_s"] = round(1.0 / float(np.median(t1s)), 1)
+                extra["config1_speedup_vs_cpu_port"] = round(extra["config1_ragged_scans_per_s"] / extra["config1_cpu_port_scans_per_s"], 1)
             # and the full config-3 path with insert (the reference's own timed lambda, KILO.cc:367-396)
             o.set_map_insert(True)
             o.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30))
