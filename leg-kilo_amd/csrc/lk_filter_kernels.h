@@ -1,6 +1,7 @@
 // lk_filter_kernels.h — single-workgroup ESKF kernels (one 256-thread block per filter slot).
 //   lk_predict_kernel     ESKF::predict x2 as issued by KILO.cc:111-115              (eskf.cc:64-89)
 //   lk_update_kernel      reduce block partials -> 6x6 information-form update       (eskf.cc:91-113)
+//   lk_update_wave_kernel (+ _ragged)  the same + the next bucket's predict as ONE WAVE per slot, for batch replay
 //   lk_imu_kernel         predictUpdateImu  (KILO.cc:235-258, eskf.cc:125-135)
 //   lk_kin_kernel         predictUpdateKinImu (KILO.cc:260-314, eskf.cc:137-145)
 //   lk_obs_update_kernel  updateByPoints / updateByKinImu on caller-supplied rows (class-surface calls)
