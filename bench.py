@@ -104,8 +104,8 @@ def make_batch(world, traj, P, t_start, n_scans, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scans-per-gpu", type=int, default=1024, help="BASELINE config 5: a batch of 1024 scans (fits one GPU)")
     ap.add_argument("--unique-scans", type=int, default=16, help="distinct synthetic scans generated per GPU (tiled to the batch)")
     ap.add_argument("--map-warm", type=int, default=6)
