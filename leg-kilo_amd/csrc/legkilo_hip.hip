@@ -446,6 +446,79 @@ __global__ void __launch_bounds__(LK_FB)
     dev_update_from_totals(f, sm, tot, t);
 }
 
+// Ragged batch of SMALL buckets (a real scan: 2 ms time bins of tens of points): the whole bucket chain of a scan - predict,
+// residual tiles, update, predict, ... - as ONE WAVE in one launch.  State and covariance stay in LDS from the first
+// predict to the last update (WaveSmem), the bucket totals never leave the registers, and there is no launch boundary
+// or partial-record round trip per bucket: the batch costs one scan's dependent chain, whatever the number of scans
+// (up to the GPU's resident waves).  Arithmetic = residual_tile + wave_update_core + wave_predict_core, i.e. what the
+// per-bucket launches of lk_batch_replay_ragged_dev compute; a bucket's tile totals are added in tile order, which is
+// the order lk_update_wave_kernel uses for up to 8 tiles (one per group) - the host takes this path only when every bucket
+// has <= LK_SCAN_WAVE_MAX points, so both paths give the same bits.
+#define LK_SCAN_WAVE_MAX 512
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
+                        const double* __restrict__ Q) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    LkFilter* f = &filters[slot];
+    const int nbk = (int)rg.nb[slot];
+    if (nbk == 0) return;
+    const double* T = rg.t + (size_t)slot * rg.ldb;
+    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+    if (lane < 36) sm.x[lane] = f->x[lane];
+    double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    unsigned long long n_effect = f->n_effect;
+    unsigned int n_updates = f->n_updates, n_buckets = f->n_buckets;
+    int last_N = f->last_N, updated = f->updated;
+    __syncthreads();
+    wave_predict_core(sm, Q, T[0] - t_upd, T[0] - t_pred, lane);
+    t_pred = T[0];
+    ResidualOut ro;
+    ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = nullptr;
+    for (int b = 0; b < nbk; ++b) {
+        const double t = T[b];
+        const unsigned long long base = po[b];
+        const int n = (int)(po[b + 1] - base);
+        BucketConst bc;   // load_bucket_const<false> from the LDS-resident state
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bc.R[i] = sm.x[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bc.p[i] = sm.x[9 + i];
+        {
+            const double* P = sm.P;
+            bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
+            bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
+        }
+        double totv = 0.0;  // tot[j] in lanes 0..31
+        for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
+            __builtin_amdgcn_wave_barrier();  // the previous tile's reads of the rows are complete
+            const double a = residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
+            totv += (lane < 29) ? a : 0.0;
+        }
+        const int N = (int)(__shfl(totv, 28, LK_WAVE) + 0.5);
+        n_buckets += 1, last_N = N, updated = N > 0;
+        if (N > 0) {
+            n_updates += 1, n_effect += (unsigned long long)N;
+            t_upd = t;  // KILO.cc:212
+            wave_update_core(sm, totv, N, lane);
+        }
+        __syncthreads();
+        if (b + 1 < nbk) {
+            wave_predict_core(sm, Q, T[b + 1] - t_upd, T[b + 1] - t_pred, lane);
+            t_pred = T[b + 1];
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+    if (lane < 36) f->x[lane] = sm.x[lane];
+    if (lane == 0) {
+        f->last_update_t = t_upd, f->last_predict_t = t_pred;
+        f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
+    }
+}
+
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
@@ -1391,7 +1464,14 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
     hipStream_t st = h->stream;
     LkFilter* fl = h->d_filters;
     hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, reinterpret_cast<const double*>(dr + o_tb));
-    hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
+    const int biggest = *std::max_element(max_n.begin(), max_n.end());
+    if (biggest <= LK_SCAN_WAVE_MAX && !getenv("LEGKILO_RAGGED_LEVELS")) {
+        // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
+        hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+        ldb = 0;
+    } else {
+        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
+    }
     for (size_t b = 0; b < ldb; ++b) {
         const int nblk = (max_n[b] + LK_RB - 1) / LK_RB;
         hipLaunchKernelGGL(lk_residual_ragged_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts, rg, (int)b,

@@ -363,6 +363,204 @@ __device__ __forceinline__ int tri6(int i, int j) {  // index of (i,j) in the pa
     return r * 6 - r * (r - 1) / 2 + (c - r);
 }
 
+// The N > 0 branch of updateByPoints on LDS-resident state: tot[j] in lanes 0..31 of totv (see dev_update_wave).
+__device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int N, int lane) {
+    if (N == 1) {  // eskf.cc:98-104
+        double r = __shfl(totv, 27, LK_WAVE);
+        double sc = r / (r + 0.0001);
+        if (lane < 27) totv *= sc;
+    }
+    __syncthreads();  // sm.P, sm.x loaded
+    // -- augmented column of this lane: lanes 0..5 S[:,lane] = I + (A P)[:,lane]; lanes 6..35 G[:,lane-6]; lane 36 b
+    const int pc = lane < 6 ? lane : (lane < 36 ? lane - 6 : 29);
+    double col[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += __shfl(totv, tri6(i, k), LK_WAVE) * sm.P[k * 30 + pc];
+        double bi = __shfl(totv, 21 + i, LK_WAVE);
+        col[i] = lane == 36 ? bi : (lane < 6 ? ((i == lane) ? 1.0 : 0.0) + s : s);
+    }
+    // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double best = fabs(col[k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            double v = fabs(col[i]);
+            if (v > best) best = v, p = i;
+        }
+        p = __shfl(p, k, LK_WAVE);  // the pivot search belongs to column k
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (i == p) {
+                double tmp = col[k];
+                col[k] = col[i];
+                col[i] = tmp;
+            }
+        const double piv = __shfl(col[k], k, LK_WAVE);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i == k) continue;
+            double fi = __shfl(col[i], k, LK_WAVE) / piv;
+            col[i] -= fi * col[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);  // X = G / diag(S)
+    // -- dx = P[:,0:6] X[:,30]
+    double dxv = 0.0;
+    {
+        const int i = lane < 30 ? lane : 29;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) dxv += sm.P[i * 30 + m] * __shfl(col[m], 36, LK_WAVE);
+        asm volatile("" : "+v"(dxv));  // finished here: keeps its six operands from living across the loop below
+    }
+    // -- P -= P[:,0:6] X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...  A row's new values depend on
+    // that row only, so five rows at a time are read, then written.
+    {
+        const int jc = lane % 30, i0 = lane < 60 ? 15 * (lane / 30) : 15;
+        double X[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) X[m] = __shfl(col[m], 6 + jc, LK_WAVE);
+#pragma unroll 1
+        for (int r0 = 0; r0 < 15; r0 += 5) {
+            double nv[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int i = i0 + r0 + r;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) s += sm.P[i * 30 + m] * X[m];
+                nv[r] = sm.P[i * 30 + jc] - s;
+            }
+            __syncthreads();
+            if (lane < 60) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) sm.P[(i0 + r0 + r) * 30 + jc] = nv[r];
+            }
+            __syncthreads();
+        }
+    }
+    // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
+    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    if (lane == 0) {
+        double E[9], Rn[9];
+        exp3_1e5(d0, d1, d2, E);
+        mat3_mul(sm.x, E, Rn);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
+    }
+    if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+}
+
+// ESKF::predict(dt_cov, false, true) then predict(dt, true, false) (KILO.cc:111-115) on LDS-resident state.
+__device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane) {
+    if (lane == 0) {  // getFx, eskf.cc:72-81
+        const double* x = sm.x;
+        V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
+        double E[9], K[9], mR[9], B60[9];
+        expv_1e7(V3{(-dt_cov) * w.x, (-dt_cov) * w.y, (-dt_cov) * w.z}, E);
+        skew3(a, K);
+        for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
+        mat3_mul(mR, K, B60);
+        for (int i = 0; i < 9; ++i) sm.fx[i] = E[i], sm.fx[9 + i] = B60[i];
+    }
+    __syncthreads();
+    const double* E = sm.fx;
+    const double* B60 = sm.fx + 9;
+    {  // rows 0..8 of B = Fx * P, in place (rows >= 9 of B are rows of P)
+        double nb[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = lane + 64 * q;
+            const int i = e < 270 ? e / 30 : 0, c = e % 30;
+            double s = 0.0;
+            if (i < 3) {
+                s += E[3 * i + 0] * sm.P[0 * 30 + c];
+                s += E[3 * i + 1] * sm.P[1 * 30 + c];
+                s += E[3 * i + 2] * sm.P[2 * 30 + c];
+                s += dt_cov * sm.P[(21 + i) * 30 + c];
+            } else if (i < 6) {
+                s += 1.0 * sm.P[i * 30 + c];
+                s += dt_cov * sm.P[(3 + i) * 30 + c];
+            } else {
+                const int ii = i - 6;
+                s += B60[3 * ii + 0] * sm.P[0 * 30 + c];
+                s += B60[3 * ii + 1] * sm.P[1 * 30 + c];
+                s += B60[3 * ii + 2] * sm.P[2 * 30 + c];
+                s += 1.0 * sm.P[i * 30 + c];
+                s += dt_cov * sm.P[(15 + ii) * 30 + c];
+                s += (dt_cov * sm.x[3 * ii + 0]) * sm.P[18 * 30 + c];
+                s += (dt_cov * sm.x[3 * ii + 1]) * sm.P[19 * 30 + c];
+                s += (dt_cov * sm.x[3 * ii + 2]) * sm.P[20 * 30 + c];
+            }
+            nb[q] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 270) sm.P[e] = nb[q];
+        }
+    }
+    __syncthreads();
+    {  // columns 0..8 of B * Fx^T, in place
+        double nc[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = lane + 64 * q;
+            const int i = e < 270 ? e / 9 : 0, c = e % 9;
+            const double* Bi = &sm.P[i * 30];
+            double s = 0.0;
+            if (c < 3) {
+                s += Bi[0] * E[3 * c + 0];
+                s += Bi[1] * E[3 * c + 1];
+                s += Bi[2] * E[3 * c + 2];
+                s += Bi[21 + c] * dt_cov;
+            } else if (c < 6) {
+                s += Bi[c] * 1.0;
+                s += Bi[3 + c] * dt_cov;
+            } else {
+                const int cc = c - 6;
+                s += Bi[0] * B60[3 * cc + 0];
+                s += Bi[1] * B60[3 * cc + 1];
+                s += Bi[2] * B60[3 * cc + 2];
+                s += Bi[c] * 1.0;
+                s += Bi[15 + cc] * dt_cov;
+                s += Bi[18] * (dt_cov * sm.x[3 * cc + 0]);
+                s += Bi[19] * (dt_cov * sm.x[3 * cc + 1]);
+                s += Bi[20] * (dt_cov * sm.x[3 * cc + 2]);
+            }
+            nc[q] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 270) sm.P[(e / 9) * 30 + (e % 9)] = nc[q];
+        }
+    }
+    __syncthreads();
+    const double dt2 = dt_cov * dt_cov;
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = sm.P[e] + dt2 * Q[e];
+    if (lane == 0) {  // getFunctionf + operator+=, eskf.cc:64-70,18-29
+        double* x = sm.x;
+        double d[9];
+        V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
+        for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
+        d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
+        double E[9], Rn[9];  // state_boxplus with d[9..29] = 0
+        exp3_1e5(d[0], d[1], d[2], E);
+        mat3_mul(x, E, Rn);
+        for (int i = 0; i < 9; ++i) x[i] = Rn[i];
+        for (int i = 0; i < 6; ++i) x[9 + i] += d[3 + i];
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const double* __restrict__ part, int nblk, double t,
                                                 const double* __restrict__ Q, double t_next, int mode) {
     const int lane = threadIdx.x;
@@ -416,95 +614,7 @@ __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const
         if (N > 0) {
             t_upd = t;
             dirty = true;
-            if (N == 1) {  // eskf.cc:98-104
-                double r = __shfl(totv, 27, LK_WAVE);
-                double sc = r / (r + 0.0001);
-                if (lane < 27) totv *= sc;
-            }
-            __syncthreads();  // sm.P, sm.x loaded
-            // -- augmented column of this lane: lanes 0..5 S[:,lane] = I + (A P)[:,lane]; lanes 6..35 G[:,lane-6]; lane 36 b
-            const int pc = lane < 6 ? lane : (lane < 36 ? lane - 6 : 29);
-            double col[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s += __shfl(totv, tri6(i, k), LK_WAVE) * sm.P[k * 30 + pc];
-                double bi = __shfl(totv, 21 + i, LK_WAVE);
-                col[i] = lane == 36 ? bi : (lane < 6 ? ((i == lane) ? 1.0 : 0.0) + s : s);
-            }
-            // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int p = k;
-                double best = fabs(col[k]);
-#pragma unroll
-                for (int i = k + 1; i < 6; ++i) {
-                    double v = fabs(col[i]);
-                    if (v > best) best = v, p = i;
-                }
-                p = __shfl(p, k, LK_WAVE);  // the pivot search belongs to column k
-#pragma unroll
-                for (int i = k + 1; i < 6; ++i)
-                    if (i == p) {
-                        double tmp = col[k];
-                        col[k] = col[i];
-                        col[i] = tmp;
-                    }
-                const double piv = __shfl(col[k], k, LK_WAVE);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    if (i == k) continue;
-                    double fi = __shfl(col[i], k, LK_WAVE) / piv;
-                    col[i] -= fi * col[k];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);  // X = G / diag(S)
-            // -- dx = P[:,0:6] X[:,30]
-            double dxv = 0.0;
-            {
-                const int i = lane < 30 ? lane : 29;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) dxv += sm.P[i * 30 + m] * __shfl(col[m], 36, LK_WAVE);
-                asm volatile("" : "+v"(dxv));  // finished here: keeps its six operands from living across the loop below
-            }
-            // -- P -= P[:,0:6] X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...  A row's new values depend on
-            // that row only, so five rows at a time are read, then written.
-            {
-                const int jc = lane % 30, i0 = lane < 60 ? 15 * (lane / 30) : 15;
-                double X[6];
-#pragma unroll
-                for (int m = 0; m < 6; ++m) X[m] = __shfl(col[m], 6 + jc, LK_WAVE);
-#pragma unroll 1
-                for (int r0 = 0; r0 < 15; r0 += 5) {
-                    double nv[5];
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) {
-                        const int i = i0 + r0 + r;
-                        double s = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) s += sm.P[i * 30 + m] * X[m];
-                        nv[r] = sm.P[i * 30 + jc] - s;
-                    }
-                    __syncthreads();
-                    if (lane < 60) {
-#pragma unroll
-                        for (int r = 0; r < 5; ++r) sm.P[(i0 + r0 + r) * 30 + jc] = nv[r];
-                    }
-                    __syncthreads();
-                }
-            }
-            // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
-            const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
-            if (lane == 0) {
-                double E[9], Rn[9];
-                exp3_1e5(d0, d1, d2, E);
-                mat3_mul(sm.x, E, Rn);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
-            }
-            if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+            wave_update_core(sm, totv, N, lane);
         }
     }
     __syncthreads();
@@ -513,108 +623,8 @@ __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const
         const double dt_cov = t_next - t_upd;
         const double dt = t_next - t_pred;
         dirty = true;
-        if (lane == 0) {  // getFx, eskf.cc:72-81
-            const double* x = sm.x;
-            V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
-            double E[9], K[9], mR[9], B60[9];
-            expv_1e7(V3{(-dt_cov) * w.x, (-dt_cov) * w.y, (-dt_cov) * w.z}, E);
-            skew3(a, K);
-            for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
-            mat3_mul(mR, K, B60);
-            for (int i = 0; i < 9; ++i) sm.fx[i] = E[i], sm.fx[9 + i] = B60[i];
-        }
-        __syncthreads();
-        const double* E = sm.fx;
-        const double* B60 = sm.fx + 9;
-        {  // rows 0..8 of B = Fx * P, in place (rows >= 9 of B are rows of P)
-            double nb[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int e = lane + 64 * q;
-                const int i = e < 270 ? e / 30 : 0, c = e % 30;
-                double s = 0.0;
-                if (i < 3) {
-                    s += E[3 * i + 0] * sm.P[0 * 30 + c];
-                    s += E[3 * i + 1] * sm.P[1 * 30 + c];
-                    s += E[3 * i + 2] * sm.P[2 * 30 + c];
-                    s += dt_cov * sm.P[(21 + i) * 30 + c];
-                } else if (i < 6) {
-                    s += 1.0 * sm.P[i * 30 + c];
-                    s += dt_cov * sm.P[(3 + i) * 30 + c];
-                } else {
-                    const int ii = i - 6;
-                    s += B60[3 * ii + 0] * sm.P[0 * 30 + c];
-                    s += B60[3 * ii + 1] * sm.P[1 * 30 + c];
-                    s += B60[3 * ii + 2] * sm.P[2 * 30 + c];
-                    s += 1.0 * sm.P[i * 30 + c];
-                    s += dt_cov * sm.P[(15 + ii) * 30 + c];
-                    s += (dt_cov * sm.x[3 * ii + 0]) * sm.P[18 * 30 + c];
-                    s += (dt_cov * sm.x[3 * ii + 1]) * sm.P[19 * 30 + c];
-                    s += (dt_cov * sm.x[3 * ii + 2]) * sm.P[20 * 30 + c];
-                }
-                nb[q] = s;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int e = lane + 64 * q;
-                if (e < 270) sm.P[e] = nb[q];
-            }
-        }
-        __syncthreads();
-        {  // columns 0..8 of B * Fx^T, in place
-            double nc[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int e = lane + 64 * q;
-                const int i = e < 270 ? e / 9 : 0, c = e % 9;
-                const double* Bi = &sm.P[i * 30];
-                double s = 0.0;
-                if (c < 3) {
-                    s += Bi[0] * E[3 * c + 0];
-                    s += Bi[1] * E[3 * c + 1];
-                    s += Bi[2] * E[3 * c + 2];
-                    s += Bi[21 + c] * dt_cov;
-                } else if (c < 6) {
-                    s += Bi[c] * 1.0;
-                    s += Bi[3 + c] * dt_cov;
-                } else {
-                    const int cc = c - 6;
-                    s += Bi[0] * B60[3 * cc + 0];
-                    s += Bi[1] * B60[3 * cc + 1];
-                    s += Bi[2] * B60[3 * cc + 2];
-                    s += Bi[c] * 1.0;
-                    s += Bi[15 + cc] * dt_cov;
-                    s += Bi[18] * (dt_cov * sm.x[3 * cc + 0]);
-                    s += Bi[19] * (dt_cov * sm.x[3 * cc + 1]);
-                    s += Bi[20] * (dt_cov * sm.x[3 * cc + 2]);
-                }
-                nc[q] = s;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int e = lane + 64 * q;
-                if (e < 270) sm.P[(e / 9) * 30 + (e % 9)] = nc[q];
-            }
-        }
-        __syncthreads();
-        const double dt2 = dt_cov * dt_cov;
-        for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = sm.P[e] + dt2 * Q[e];
-        if (lane == 0) {  // getFunctionf + operator+=, eskf.cc:64-70,18-29
-            double* x = sm.x;
-            double d[9];
-            V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
-            for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
-            d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
-            double E[9], Rn[9];  // state_boxplus with d[9..29] = 0
-            exp3_1e5(d[0], d[1], d[2], E);
-            mat3_mul(x, E, Rn);
-            for (int i = 0; i < 9; ++i) x[i] = Rn[i];
-            for (int i = 0; i < 6; ++i) x[9 + i] += d[3 + i];
-            f->last_predict_t = t_next;
-        }
-        __syncthreads();
+        wave_predict_core(sm, Q, dt_cov, dt, lane);
+        if (lane == 0) f->last_predict_t = t_next;
     }
     if (dirty) {
         for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];

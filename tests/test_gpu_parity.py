@@ -531,7 +531,7 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     o.close()
 
 
-def test_batch_replay_ragged(scene, oracle_lib, hip_lib):
+def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     """lk_batch_replay_ragged_dev: scans of different sizes, bucket tables and start times in one batch (what a recorded
     run looks like) - each must come out as the oracle's own bucket loop over that scan alone; on equally shaped scans the
     ragged entry reproduces the uniform one bit for bit."""
@@ -569,6 +569,32 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib):
         assert po.n_buckets == nbs[s]
         assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
         assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+    # small buckets only (<= 512 points each): the entry runs each scan's whole bucket chain as ONE wave in one launch
+    # (lk_scan_wave_kernel); it must equal the per-bucket launches (LEGKILO_RAGGED_LEVELS=1) bit for bit, and the oracle
+    small = [i for i, sc in enumerate(scans) if np.diff(synth.buckets_of(sc)[0].astype(np.int64)).max() <= 512]
+    small_scans = [scans[i] for i in small] + [scenes.vlp_scan_input(scene, t0 + 3.0 + 0.1 * k, 60 + k) for k in range(2)]
+    small_tb = [tbs[i] for i in small] + [t0 + 3.0 + 0.1 * k for k in range(2)]
+    small_x = [xs[i] for i in small] + [synth.initial_state(scene.traj, t0 + 3.0 + 0.1 * k, scene.P, rng, 0.02, 0.5) for k in range(2)]
+    small_P = [1e-4 * np.eye(30)] * len(small_scans)
+    assert len(small_scans) >= 4 and sum(len(synth.buckets_of(sc)[1]) > 100 for sc in small_scans) >= 3
+    res = []
+    for levels in (False, True):
+        if levels:
+            monkeypatch.setenv("LEGKILO_RAGGED_LEVELS", "1")
+        ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P)
+        res.append(([g.get_state(slot=s) for s in range(len(small_scans))], [(p.n_buckets, p.n_updates, p.n_effect) for p in ps]))
+        if levels:
+            monkeypatch.delenv("LEGKILO_RAGGED_LEVELS")
+    assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+    for s in range(len(small_scans)):
+        assert np.array_equal(res[0][0][s][0], res[1][0][s][0]) and np.array_equal(res[0][0][s][1], res[1][0][s][1]), s
+        o.set_state(small_x[s], small_P[s])
+        o.set_times(small_tb[s], small_tb[s])
+        po, _ = o.process_scan(small_scans[s], small_tb[s])
+        xo, Po = o.get_state()
+        assert (po.n_buckets, po.n_updates, po.n_effect) == res[0][1][s], (s, res[0][1][s])
+        assert np.allclose(xo, res[0][0][s][0], rtol=1e-8, atol=1e-9), (s, np.abs(xo - res[0][0][s][0]).max())
+        assert np.allclose(Po, res[0][0][s][1], rtol=1e-6, atol=1e-11), s
     # equally shaped scans: ragged == uniform, bit for bit
     uni = [synth.dense_scan(scene.world, scene.traj, t0 + 2.0 + 0.1 * s, scene.P, n=4000, n_buckets=5, seed_scan=8400 + s, seed_noise=8500 + s)
            for s in range(3)]
