@@ -324,20 +324,27 @@ class LegKiloHip:
                                                    C.c_void_p(d_x36) if d_x36 else None, C.c_void_p(d_P900) if d_P900 else None,
                                                    C.c_void_p(host_out_ptr) if host_out_ptr else None))
 
-    def batch_replay_ragged_dev(self, d_pts, scan_off, bucket_offs, bucket_dts, t_begins, want_poses=True):
-        """Ragged batch on slots [0, n_scans): scan s = d_pts[scan_off[s]:scan_off[s+1]] with its own bucket bounds
-        bucket_offs[s] (n_b + 1 offsets relative to the scan) / time offsets bucket_dts[s] (n_b) and start time t_begins[s]."""
+    @staticmethod
+    def ragged_tables(scan_off, bucket_offs, bucket_dts, t_begins):
+        """Flatten per-scan bucket tables into the arrays lk_batch_replay_ragged_dev takes (do this once per recorded run,
+        not per replay): scan s = points [scan_off[s], scan_off[s+1]) with bucket bounds bucket_offs[s] (n_b + 1 offsets
+        relative to the scan), time offsets bucket_dts[s] (n_b) and start time t_begins[s]."""
         n_scans = len(bucket_dts)
         so = np.ascontiguousarray(scan_off, dtype=np.uint64)
         assert len(so) == n_scans + 1 and len(bucket_offs) == n_scans and len(t_begins) == n_scans
-        nb = np.array([len(d) for d in bucket_dts], dtype=np.uint32)
-        off = np.ascontiguousarray(np.concatenate([np.asarray(o, dtype=np.uint32) for o in bucket_offs]))
-        dt = _f64(np.concatenate([np.asarray(d, dtype=np.float64) for d in bucket_dts]))
-        assert len(off) == int(nb.sum()) + n_scans
-        tb = _f64(t_begins)
+        nb = np.fromiter((len(d) for d in bucket_dts), dtype=np.uint32, count=n_scans)
+        off = np.ascontiguousarray(np.concatenate(bucket_offs), dtype=np.uint32)
+        dt = np.ascontiguousarray(np.concatenate(bucket_dts), dtype=np.float64)
+        assert len(off) == int(nb.sum()) + n_scans and len(dt) == int(nb.sum())
+        return dict(n_scans=n_scans, scan_off=so, n_buckets=nb, bucket_off=off, bucket_dt=dt, t_begin=_f64(t_begins))
+
+    def batch_replay_ragged_dev(self, d_pts, tables, want_poses=True):
+        """Ragged batch on slots [0, n_scans): `tables` from ragged_tables()."""
+        t = tables
+        n_scans = t["n_scans"]
         poses = (abi.lk_pose * n_scans)() if want_poses else None
-        self._chk(self.L.lk_batch_replay_ragged_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(so), _p(nb), _p(off), _p(dt),
-                                                    _p(tb), poses))
+        self._chk(self.L.lk_batch_replay_ragged_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(t["scan_off"]), _p(t["n_buckets"]),
+                                                    _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]), poses))
         return poses
 
     def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None):
@@ -353,7 +360,7 @@ class LegKiloHip:
         d = self.device_malloc(allpts.nbytes)
         try:
             self.h2d(d, allpts)
-            return self.batch_replay_ragged_dev(d, scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins)
+            return self.batch_replay_ragged_dev(d, self.ragged_tables(scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins))
         finally:
             self.device_free(d)
 

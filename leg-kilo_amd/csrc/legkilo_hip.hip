@@ -52,7 +52,8 @@ struct lk_handle {
     unsigned char* d_valid = nullptr;
     double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
     lk_pose* d_poses = nullptr;
-    void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev
+    void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev (device copy, pinned staging copy)
+    void* h_rag = nullptr;
     size_t rag_cap = 0;
     double acc_norm = 1.0;
     // grow-only scratch of lk_preprocess_scan
@@ -246,6 +247,7 @@ void lk_destroy(lk_handle* h) {
                    h->pre_v0, h->pre_v1, h->pre_starts, h->pre_tmp};
     for (void* p : pre)
         if (p) hipFree(p);
+    if (h->h_rag) hipHostFree(h->h_rag);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1404,55 +1406,66 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
     const size_t S = n_scans;
-    // compact away empty buckets (as the uniform entry does) and find the table pitch
-    std::vector<std::vector<unsigned long long>> po(S);
-    std::vector<std::vector<double>> tt(S);
+    // pass 1: validate, count the non-empty buckets of every scan (empty ones are skipped, as in the uniform entry), pitch
+    std::vector<uint32_t> cnt(S);
     size_t row_o = 0, row_t = 0, ldb = 0;
     for (size_t s = 0; s < S; ++s) {
         const uint32_t* bo = bucket_off + row_o;
-        const double* bd = bucket_dt + row_t;
         const size_t nbs = n_buckets[s];
         if (nbs == 0) return fail(h, LK_ERR_INVALID, "a scan has no buckets");
         if (bo[0] != 0 || scan_off[s] + bo[nbs] != scan_off[s + 1]) return fail(h, LK_ERR_INVALID, "bucket offsets do not tile the scan");
+        uint32_t c = 0;
         for (size_t b = 0; b < nbs; ++b) {
             if (bo[b + 1] < bo[b]) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing");
-            if (bo[b + 1] == bo[b]) continue;
             if ((size_t)(bo[b + 1] - bo[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
-            po[s].push_back(scan_off[s] + bo[b]);
-            tt[s].push_back(t_begin[s] + bd[b]);
+            c += bo[b + 1] > bo[b];
         }
-        if (po[s].empty()) return fail(h, LK_ERR_INVALID, "empty scan");
-        po[s].push_back(scan_off[s + 1]);
-        ldb = std::max(ldb, tt[s].size());
+        if (c == 0) return fail(h, LK_ERR_INVALID, "empty scan");
+        cnt[s] = c;
+        ldb = std::max(ldb, (size_t)c);
         row_o += nbs + 1, row_t += nbs;
     }
-    // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32
+    // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32, staged in pinned host memory
     const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_nb = o_tb + 8 * S, bytes = o_nb + 4 * S;
-    std::vector<unsigned char> stage(bytes, 0);
-    auto* hpo = reinterpret_cast<unsigned long long*>(stage.data() + o_po);
-    auto* ht = reinterpret_cast<double*>(stage.data() + o_t);
-    auto* htb = reinterpret_cast<double*>(stage.data() + o_tb);
-    auto* hnb = reinterpret_cast<unsigned int*>(stage.data() + o_nb);
-    std::vector<int> max_n(ldb, 0);
-    for (size_t s = 0; s < S; ++s) {
-        const size_t nbs = tt[s].size();
-        for (size_t b = 0; b <= nbs; ++b) hpo[s * (ldb + 1) + b] = po[s][b];
-        for (size_t b = nbs + 1; b <= ldb; ++b) hpo[s * (ldb + 1) + b] = po[s][nbs];
-        for (size_t b = 0; b < nbs; ++b) {
-            ht[s * ldb + b] = tt[s][b];
-            max_n[b] = std::max(max_n[b], (int)(po[s][b + 1] - po[s][b]));
-        }
-        htb[s] = t_begin[s];
-        hnb[s] = (unsigned int)nbs;
-    }
     if (bytes > h->rag_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->d_rag) hipFree(h->d_rag), h->d_rag = nullptr, h->rag_cap = 0;
+        if (h->d_rag) hipFree(h->d_rag), h->d_rag = nullptr;
+        if (h->h_rag) hipHostFree(h->h_rag), h->h_rag = nullptr;
+        h->rag_cap = 0;
         HIPCHK(h, hipMalloc(&h->d_rag, bytes + bytes / 2));
+        HIPCHK(h, hipHostMalloc(&h->h_rag, bytes + bytes / 2, hipHostMallocDefault));
         h->rag_cap = bytes + bytes / 2;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // a previous call's upload from the staging buffer has completed
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_rag, stage.data(), bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // `stage` is pageable host memory
+    unsigned char* stage = static_cast<unsigned char*>(h->h_rag);
+    auto* hpo = reinterpret_cast<unsigned long long*>(stage + o_po);
+    auto* ht = reinterpret_cast<double*>(stage + o_t);
+    auto* htb = reinterpret_cast<double*>(stage + o_tb);
+    auto* hnb = reinterpret_cast<unsigned int*>(stage + o_nb);
+    std::vector<int> max_n(ldb, 0);
+    row_o = 0, row_t = 0;
+    for (size_t s = 0; s < S; ++s) {   // pass 2: fill
+        const uint32_t* bo = bucket_off + row_o;
+        const double* bd = bucket_dt + row_t;
+        const size_t nbs = n_buckets[s];
+        unsigned long long* po = hpo + s * (ldb + 1);
+        double* tr = ht + s * ldb;
+        size_t k = 0;
+        for (size_t b = 0; b < nbs; ++b) {
+            if (bo[b + 1] == bo[b]) continue;
+            po[k] = scan_off[s] + bo[b];
+            tr[k] = t_begin[s] + bd[b];
+            max_n[k] = std::max(max_n[k], (int)(bo[b + 1] - bo[b]));
+            ++k;
+        }
+        for (size_t b = k; b <= ldb; ++b) po[b] = scan_off[s + 1];
+        for (size_t b = k; b < ldb; ++b) tr[b] = 0.0;
+        htb[s] = t_begin[s];
+        hnb[s] = cnt[s];
+        row_o += nbs + 1, row_t += nbs;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
     unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
     LkRagged rg;
     rg.pt_off = reinterpret_cast<const unsigned long long*>(dr + o_po);

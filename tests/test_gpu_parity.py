@@ -606,13 +606,13 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     g.batch_replay_dev(d_pts, 3, 4000, 0.0, off, dt)
     ref = [g.get_state(slot=s) for s in range(3)]
     g.batch_set_priors(np.array(xs[:3]), np.array(Ps[:3]))
-    g.batch_replay_ragged_dev(d_pts, [0, 4000, 8000, 12000], [off] * 3, [dt] * 3, [0.0] * 3)
+    g.batch_replay_ragged_dev(d_pts, g.ragged_tables([0, 4000, 8000, 12000], [off] * 3, [dt] * 3, [0.0] * 3))
     for s in range(3):
         xr, Pr = g.get_state(slot=s)
         assert np.array_equal(xr, ref[s][0]) and np.array_equal(Pr, ref[s][1]), s
     # malformed tables are refused
     with pytest.raises(hip_lib.LegKiloError):
-        g.batch_replay_ragged_dev(d_pts, [0, 4000, 8000, 12001], [off] * 3, [dt] * 3, [0.0] * 3)
+        g.batch_replay_ragged_dev(d_pts, g.ragged_tables([0, 4000, 8000, 12001], [off] * 3, [dt] * 3, [0.0] * 3))
     g.device_free(d_pts)
     g.close()
     o.close()
