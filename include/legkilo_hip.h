@@ -319,6 +319,14 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
                                const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
                                const double* t_begin, lk_pose* out);
 
+/* The same with the IMU messages of each scan (only_imu_use mode): n_imu[s] messages of scan s, rows concatenated in `imus`,
+ * time-sorted per scan; every message stamped before a bucket's time is applied (predictUpdateImu, KILO.cc:235-258) before
+ * that bucket, as the loop at KILO.cc:379-383 does.  Requires every bucket to hold <= 512 points (what a recorded scan's
+ * 2 ms bins hold); LK_ERR_INVALID otherwise. */
+int lk_batch_replay_ragged_imu_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                                   const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                                   const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out);
+
 /* ---- measurement hooks ---- */
 int lk_profile_enable(lk_handle* h, int on);                           /* HIP-event timing around each kernel */
 int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms);

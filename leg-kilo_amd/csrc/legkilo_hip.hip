@@ -457,11 +457,8 @@ __global__ void __launch_bounds__(LK_FB)
 // the order lk_update_wave_kernel uses for up to 8 tiles (one per group) - the host takes this path only when every bucket
 // has <= LK_SCAN_WAVE_MAX points, so both paths give the same bits.
 #define LK_SCAN_WAVE_MAX 512
-__global__ void __launch_bounds__(LK_WAVE, 2)
-    lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
-                        const double* __restrict__ Q) {
-    __shared__ WaveSmem sm;
-    __shared__ double rows[64 * LK_ROW2];
+__device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& pr, LkFilter* filters, const lk_point* __restrict__ pts,
+                                              const LkRagged& rg, const double* __restrict__ Q, WaveSmem& sm, double* rows, const bool WITH_IMU) {
     const int slot = blockIdx.x, lane = threadIdx.x;
     LkFilter* f = &filters[slot];
     const int nbk = (int)rg.nb[slot];
@@ -475,12 +472,24 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
     unsigned int n_updates = f->n_updates, n_buckets = f->n_buckets;
     int last_N = f->last_N, updated = f->updated;
     __syncthreads();
-    wave_predict_core(sm, Q, T[0] - t_upd, T[0] - t_pred, lane);
-    t_pred = T[0];
+    unsigned int qi = 0, qn = 0;   // this scan's IMU messages (KILO.cc:379-383: those stamped before the bucket come first)
+    if (WITH_IMU) qi = rg.imu_off[slot], qn = rg.imu_off[slot + 1];
     ResidualOut ro;
     ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = nullptr;
-    for (int b = 0; b < nbk; ++b) {
-        const double t = T[b];
+    for (int b = 0; b < nbk;) {
+        // next event of the scan: an IMU message stamped before the bucket's time (KILO.cc:379-383), else the bucket
+        const double tb_ = T[b];
+        const bool is_imu = WITH_IMU && qi < qn && rg.imu[7 * (size_t)qi] < tb_;
+        const double t = is_imu ? rg.imu[7 * (size_t)qi] : tb_;
+        wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane);   // KILO.cc:111-115 / :240-244
+        t_pred = t;
+        if (is_imu) {   // predictUpdateImu, KILO.cc:235-258
+            const double* m = rg.imu + 7 * (size_t)qi;
+            wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
+            t_upd = t;  // KILO.cc:256
+            ++qi;
+            continue;
+        }
         const unsigned long long base = po[b];
         const int n = (int)(po[b + 1] - base);
         BucketConst bc;   // load_bucket_const<false> from the LDS-resident state
@@ -507,10 +516,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
             wave_update_core(sm, totv, N, lane);
         }
         __syncthreads();
-        if (b + 1 < nbk) {
-            wave_predict_core(sm, Q, T[b + 1] - t_upd, T[b + 1] - t_pred, lane);
-            t_pred = T[b + 1];
-        }
+        ++b;
     }
     __syncthreads();
     for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
@@ -519,6 +525,20 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
         f->last_update_t = t_upd, f->last_predict_t = t_pred;
         f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
     }
+}
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
+                        const double* __restrict__ Q) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, false);
+}
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_scan_wave_imu_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
+                            const double* __restrict__ Q) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, true);
 }
 
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
@@ -1399,9 +1419,9 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
 // launch per bucket INDEX over all scans (grid sized by the largest bucket of that index; scans that have run out of
 // buckets leave at once), every scan reading its own tables (LkRagged).  Same kernels' arithmetic as the uniform entry:
 // a ragged batch of equally shaped scans gives the same bits.  Synchronous; priors as for lk_batch_replay_dev.
-int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
-                               const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
-                               const double* t_begin, lk_pose* out) {
+static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                         const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                         const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out) {
     CHECK_H(h);
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
@@ -1426,7 +1446,13 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
         row_o += nbs + 1, row_t += nbs;
     }
     // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32, staged in pinned host memory
-    const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_nb = o_tb + 8 * S, bytes = o_nb + 4 * S;
+    size_t n_imu_total = 0;
+    if (n_imu)
+        for (size_t s = 0; s < S; ++s) n_imu_total += n_imu[s];
+    if (n_imu_total && !imus) return fail(h, LK_ERR_INVALID, "null IMU array");
+    // ... | imu [n][7] f64 | nb [S] u32 | imu_off [S+1] u32
+    const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_im = o_tb + 8 * S, o_nb = o_im + 56 * n_imu_total,
+                 o_io = o_nb + 4 * S, bytes = o_io + 4 * (S + 1);
     if (bytes > h->rag_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_rag) hipFree(h->d_rag), h->d_rag = nullptr;
@@ -1465,6 +1491,12 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
         hnb[s] = cnt[s];
         row_o += nbs + 1, row_t += nbs;
     }
+    if (n_imu) {
+        memcpy(stage + o_im, imus, 56 * n_imu_total);
+        auto* hio = reinterpret_cast<unsigned int*>(stage + o_io);
+        hio[0] = 0;
+        for (size_t s = 0; s < S; ++s) hio[s + 1] = hio[s] + n_imu[s];
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
     unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
     LkRagged rg;
@@ -1472,15 +1504,24 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
     rg.t = reinterpret_cast<const double*>(dr + o_t);
     rg.nb = reinterpret_cast<const unsigned int*>(dr + o_nb);
     rg.ldb = (int)ldb;
+    rg.imu_off = n_imu ? reinterpret_cast<const unsigned int*>(dr + o_io) : nullptr;
+    rg.imu = reinterpret_cast<const double*>(dr + o_im);
+    rg.acc_scale = h->cfg.gravity / h->acc_norm;
+    imu_noise(h->cfg, rg.Rn);
     int rc = zero_scan_counters(h, 0, (uint32_t)S);
     if (rc) return rc;
     hipStream_t st = h->stream;
     LkFilter* fl = h->d_filters;
     hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, reinterpret_cast<const double*>(dr + o_tb));
     const int biggest = *std::max_element(max_n.begin(), max_n.end());
-    if (biggest <= LK_SCAN_WAVE_MAX && !getenv("LEGKILO_RAGGED_LEVELS")) {
+    if (n_imu && biggest > LK_SCAN_WAVE_MAX)
+        return fail(h, LK_ERR_INVALID, "IMU messages between buckets are only replayed for scans whose buckets hold <= 512 points");
+    if (biggest <= LK_SCAN_WAVE_MAX && (n_imu || !getenv("LEGKILO_RAGGED_LEVELS"))) {
         // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
-        hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+        if (n_imu)
+            hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+        else
+            hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
         ldb = 0;
     } else {
         hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
@@ -1500,6 +1541,22 @@ int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_sca
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return LK_OK;
+}
+
+int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                               const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                               const double* t_begin, lk_pose* out) {
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, nullptr, nullptr, out);
+}
+// The same with each scan's IMU messages (only_imu_use mode, KILO.cc:379-383): n_imu[s] messages of scan s, concatenated in
+// `imus`, time-sorted per scan; a message stamped before a bucket's time is applied before that bucket, the rest of the
+// scan's messages are left unused exactly as the bucket loop of KILO::process leaves them.
+int lk_batch_replay_ragged_imu_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                                   const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                                   const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out) {
+    CHECK_H(h);
+    if (!n_imu) return fail(h, LK_ERR_INVALID, "null argument");
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, n_imu, imus, out);
 }
 
 // Asynchronous, double-buffered batch replay.  The batch uses filter slots [first_slot, first_slot + n_scans); calls whose

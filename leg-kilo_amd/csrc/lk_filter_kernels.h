@@ -456,6 +456,98 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
     if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
 }
 
+// updateByImu (eskf.cc:125-135) with the rows of KILO.cc:246-253 on LDS-resident, already propagated state: H selects
+// (ba + imu_a) and (bw + imu_w), i.e. P H^T = P[:,9:15] + P[:,18:24].  Same one-column-per-lane Gauss-Jordan as
+// wave_update_core (kept as a separate copy: that one is register-tuned for lk_update_wave_kernel's 96-VGPR budget);
+// sums in the order lk_imu_kernel takes them.  acc / gyr / Rn6 are wave-uniform.
+__device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double* acc, const double* gyr, double acc_scale,
+                                                     const double* Rn6, int lane) {
+    const double* x = sm.x;
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        z[i] = acc_scale * acc[i] - x[24 + i] - x[15 + i];  // (g/|a|) a - imu_a - ba
+        z[3 + i] = gyr[i] - x[27 + i] - x[18 + i];          // w - imu_w - bw
+    }
+    auto pht = [&](int i, int m) { return sm.P[i * 30 + 9 + m] + sm.P[i * 30 + 18 + m]; };
+    double col[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c6 = lane < 6 ? lane : 0, j = (lane >= 6 && lane < 36) ? lane - 6 : 0;
+        const double sv = (pht(9 + i, c6) + pht(18 + i, c6)) + ((i == c6) ? Rn6[i] : 0.0);
+        const double gv = sm.P[(9 + i) * 30 + j] + sm.P[(18 + i) * 30 + j];
+        col[i] = lane == 36 ? z[i] : (lane < 6 ? sv : gv);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double best = fabs(col[k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            double v = fabs(col[i]);
+            if (v > best) best = v, p = i;
+        }
+        p = __shfl(p, k, LK_WAVE);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (i == p) {
+                double tmp = col[k];
+                col[k] = col[i];
+                col[i] = tmp;
+            }
+        const double piv = __shfl(col[k], k, LK_WAVE);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i == k) continue;
+            double fi = __shfl(col[i], k, LK_WAVE) / piv;
+            col[i] -= fi * col[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);
+    double dxv = 0.0;
+    {
+        const int i = lane < 30 ? lane : 29;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) dxv += pht(i, m) * __shfl(col[m], 36, LK_WAVE);
+        asm volatile("" : "+v"(dxv));
+    }
+    {
+        const int jc = lane % 30, i0 = lane < 60 ? 15 * (lane / 30) : 15;
+        double X[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) X[m] = __shfl(col[m], 6 + jc, LK_WAVE);
+#pragma unroll 1
+        for (int r0 = 0; r0 < 15; r0 += 5) {
+            double nv[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int i = i0 + r0 + r;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) s += pht(i, m) * X[m];
+                nv[r] = sm.P[i * 30 + jc] - s;
+            }
+            __syncthreads();
+            if (lane < 60) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) sm.P[(i0 + r0 + r) * 30 + jc] = nv[r];
+            }
+            __syncthreads();
+        }
+    }
+    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    if (lane == 0) {
+        double E[9], Rn[9];
+        exp3_1e5(d0, d1, d2, E);
+        mat3_mul(sm.x, E, Rn);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
+    }
+    if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+    __syncthreads();
+}
+
 // ESKF::predict(dt_cov, false, true) then predict(dt, true, false) (KILO.cc:111-115) on LDS-resident state.
 __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane) {
     if (lane == 0) {  // getFx, eskf.cc:72-81

@@ -595,6 +595,22 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
         assert (po.n_buckets, po.n_updates, po.n_effect) == res[0][1][s], (s, res[0][1][s])
         assert np.allclose(xo, res[0][0][s][0], rtol=1e-8, atol=1e-9), (s, np.abs(xo - res[0][0][s][0]).max())
         assert np.allclose(Po, res[0][0][s][1], rtol=1e-6, atol=1e-11), s
+    # the same scans with their IMU messages applied between the buckets (only_imu_use mode, KILO.cc:379-383)
+    g.set_acc_norm(9.81)
+    o.set_acc_norm(9.81)
+    small_imus = [synth.imu_stream(scene.traj, tb_, tb_ + 0.1, seed=8600 + s) for s, tb_ in enumerate(small_tb)]
+    ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P, imus=small_imus)
+    for s in range(len(small_scans)):
+        o.set_state(small_x[s], small_P[s])
+        o.set_times(small_tb[s], small_tb[s])
+        po, _ = o.process_scan(small_scans[s], small_tb[s], imus=small_imus[s])
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (ps[s].n_buckets, ps[s].n_updates, ps[s].n_effect), s
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+        assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+        if po.n_buckets > 100:
+            assert not np.array_equal(xg, res[0][0][s][0])   # the IMU updates did change the outcome
     # equally shaped scans: ragged == uniform, bit for bit
     uni = [synth.dense_scan(scene.world, scene.traj, t0 + 2.0 + 0.1 * s, scene.P, n=4000, n_buckets=5, seed_scan=8400 + s, seed_noise=8500 + s)
            for s in range(3)]

@@ -4,7 +4,7 @@
     updates and map insert (KILO.cc:367-396), one scan after the other, trajectory written as a TUM file
     (trajectory_saver.hpp:43-50);
 (2) replayed as ONE ragged batch against the final map, frozen: every scan re-localised from its live prior, with its own
-    size / 2 ms buckets / start time (lk_batch_replay_ragged_dev).
+    size / 2 ms buckets / start time / IMU messages (lk_batch_replay_ragged_imu_dev).
 Prints rates and the ATE of both trajectories against the synthetic ground truth.   Usage: replay_recorded_run.py [N_SCANS]"""
 import os
 import sys
@@ -64,9 +64,9 @@ gt = np.array([traj.pos(t) for t in stamps]).reshape(-1, 3)
 tmp = tempfile.mkdtemp()
 tum.write_tum(os.path.join(tmp, "live.txt"), stamps, rots, poss)
 
-# ---- (2) the same scans as one ragged batch against the final map (no IMU, no insert: pure re-localisation)
+# ---- (2) the same scans, with their IMU messages, as one ragged batch against the final map (frozen: no insert)
 t_b = time.perf_counter()
-poses = g.batch_replay_ragged(live_scans, live_tb, priors_x, priors_P)
+poses = g.batch_replay_ragged(live_scans, live_tb, priors_x, priors_P, imus=imu_q)
 t_b = time.perf_counter() - t_b
 pb = np.array([np.array(p.pos) for p in poses])
 tum.write_tum(os.path.join(tmp, "batch.txt"), stamps, [np.array(p.rot).reshape(3, 3) for p in poses], pb)
