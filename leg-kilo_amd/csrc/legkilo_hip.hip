@@ -1492,7 +1492,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
         row_o += nbs + 1, row_t += nbs;
     }
     if (n_imu) {
-        memcpy(stage + o_im, imus, 56 * n_imu_total);
+        if (n_imu_total) memcpy(stage + o_im, imus, 56 * n_imu_total);
         auto* hio = reinterpret_cast<unsigned int*>(stage + o_io);
         hio[0] = 0;
         for (size_t s = 0; s < S; ++s) hio[s + 1] = hio[s] + n_imu[s];

@@ -83,3 +83,26 @@ def test_host_mirror_compiles_against_the_c_abi():
                         src, "-o", exe, "-L", os.path.join(ROOT, "leg-kilo_amd"), "-llegkilo_hip",
                         "-Wl,-rpath," + os.path.join(ROOT, "leg-kilo_amd")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_ragged_tables_layout():
+    """binding.ragged_tables flattens per-scan bucket tables into exactly what lk_batch_replay_ragged(_imu)_dev takes."""
+    import lk_pkg
+
+    lk_pkg.load()
+    import numpy as np
+    from legkilo_amd import binding, synth
+
+    offs = [np.array([0, 3, 7], dtype=np.uint32), np.array([0, 5], dtype=np.uint32)]
+    dts = [np.array([0.0, 0.002]), np.array([0.004])]
+    t = binding.LegKiloHip.ragged_tables([0, 7, 12], offs, dts, [1.0, 1.1])
+    assert t["n_scans"] == 2 and t["scan_off"].dtype == np.uint64 and list(t["scan_off"]) == [0, 7, 12]
+    assert t["n_buckets"].dtype == np.uint32 and list(t["n_buckets"]) == [2, 1]
+    assert t["bucket_off"].dtype == np.uint32 and list(t["bucket_off"]) == [0, 3, 7, 0, 5]
+    assert t["bucket_dt"].dtype == np.float64 and list(t["bucket_dt"]) == [0.0, 0.002, 0.004]
+    assert list(t["t_begin"]) == [1.0, 1.1] and "n_imu" not in t
+    imus = [np.zeros(3, dtype=synth.IMU_DTYPE), np.zeros(0, dtype=synth.IMU_DTYPE)]
+    t = binding.LegKiloHip.ragged_tables([0, 7, 12], offs, dts, [1.0, 1.1], imus=imus)
+    assert list(t["n_imu"]) == [3, 0] and t["imus"].nbytes == 3 * 56
+    with pytest.raises(AssertionError):
+        binding.LegKiloHip.ragged_tables([0, 7], offs, dts, [1.0, 1.1])
