@@ -1,5 +1,5 @@
 // Minimal use of the C++ mirror, written the way KILO.cc drives the reference classes: first-frame
-// BuildVoxelMap on a synthetic floor + wall, then one predictUpdatePoint bucket.  Needs a gfx950 device
+// BuildVoxelMap on a synthetic floor + wall, one predictUpdatePoint bucket, then a two-scan recorded-run replay.  Needs a gfx950 device
 // to RUN (exit code 3 otherwise); tests/test_abi_and_host.py only checks that it compiles and links.
 #include <cmath>
 #include <cstdio>
@@ -13,6 +13,7 @@ int main() {
     ESKF::Config ec{20, 500, 1000, 20, 0.001, 0.001, 0.001, 0.1, 1.0, 0.01, 0.1, 0.1, 0.001, 10};
     VoxelMapConfig vc;
     DeviceCaps caps;
+    caps.n_slots = 2;   // replayRecordedRun below replays two scans at once
     caps.max_roots = 1u << 14, caps.max_nodes = 1u << 15, caps.max_point_blocks = 1u << 14, caps.max_scan_points = 1u << 15;
     std::unique_ptr<KiloPath> kilo;
     try {
@@ -50,5 +51,12 @@ int main() {
     bool updated = kilo->predictUpdatePoint(0.01, 0, bucket.size(), bucket, bucket_world, n_success);
     Vec3D p = kilo->eskf().getPos();
     std::printf("updated=%d matched=%zu pos=(%.4f %.4f %.4f)\n", (int)updated, n_success, p[0], p[1], p[2]);
-    return (updated && n_success > 500 && std::fabs(p[2] - 0.5) < 0.05) ? 0 : 1;
+    // the same bucket twice more as a two-scan "recorded run", each from its own prior, against the (now frozen) map
+    PointCloudType scan(bucket.begin(), bucket.end());
+    for (size_t i = 0; i < scan.size(); ++i) scan[i].curvature = (i < scan.size() / 2) ? 0.f : 0.002f;   // two time buckets
+    std::vector<lk_pose> poses = kilo->replayRecordedRun({scan, scan}, {0.02, 0.05}, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
+    std::printf("replay: %u / %u buckets, matched %llu / %llu\n", poses[0].n_buckets, poses[1].n_buckets,
+                (unsigned long long)poses[0].n_effect, (unsigned long long)poses[1].n_effect);
+    const bool replay_ok = poses.size() == 2 && poses[0].n_buckets == 2 && poses[1].n_buckets == 2 && poses[1].n_effect > 500;
+    return (updated && n_success > 500 && std::fabs(p[2] - 0.5) < 0.05 && replay_ok) ? 0 : 1;
 }

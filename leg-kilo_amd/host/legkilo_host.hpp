@@ -11,6 +11,7 @@
 // build_single_residual is not a per-point host call — BuildResidualList() runs the whole bucket on the GPU.
 // Configuration errors throw std::runtime_error like YamlHelper does (yaml_helper.hpp:42,50).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstddef>
 #include <cstring>
@@ -325,6 +326,58 @@ class KiloPath {
             for (size_t i = 0; i < pts.size(); ++i) (*world_out)[i].x = w[3 * i], (*world_out)[i].y = w[3 * i + 1], (*world_out)[i].z = w[3 * i + 2];
         }
         return true;
+    }
+
+    // Many recorded scans at once against the CURRENT map, frozen (lk_batch_replay_ragged(_imu)_dev): scan s runs the bucket
+    // loop of KILO::process (KILO.cc:375-395) on filter slot s from its own prior; buckets are the runs of equal curvature
+    // of each time-sorted scan (KILO.cc:376-378), t_begin[s] its start time; `imus` (optional, one time-sorted vector per
+    // scan) are applied between the buckets as in only_imu_use mode.  n scans need DeviceCaps::n_slots >= n.
+    std::vector<lk_pose> replayRecordedRun(const std::vector<PointCloudType>& sorted_scans, const std::vector<double>& t_begin,
+                                           const std::vector<State>& prior_states, const std::vector<StateCov>& prior_covs,
+                                           const std::vector<std::vector<lk_imu>>* imus = nullptr) {
+        const size_t S = sorted_scans.size();
+        if (t_begin.size() != S || prior_states.size() != S || prior_covs.size() != S || (imus && imus->size() != S))
+            throw std::runtime_error("replayRecordedRun: one start time, prior state and prior covariance per scan");
+        std::vector<lk_point> pts;
+        std::vector<uint64_t> scan_off(1, 0);
+        std::vector<uint32_t> n_buckets, bucket_off, n_imu;
+        std::vector<double> bucket_dt, x36(S * LK_STATE_DOUBLES), P900(S * DIM_STATE * DIM_STATE);
+        std::vector<lk_imu> imu_flat;
+        for (size_t s = 0; s < S; ++s) {
+            const PointCloudType& sc = sorted_scans[s];
+            uint32_t nb = 0;
+            for (size_t i = 0; i < sc.size(); ++i) {
+                if (i == 0 || sc[i].curvature != sc[i - 1].curvature) {
+                    bucket_off.push_back((uint32_t)i);
+                    bucket_dt.push_back((double)sc[i].curvature);
+                    ++nb;
+                }
+                pts.push_back(lk_point{sc[i].x, sc[i].y, sc[i].z, sc[i].curvature});
+            }
+            bucket_off.push_back((uint32_t)sc.size());
+            n_buckets.push_back(nb);
+            scan_off.push_back(pts.size());
+            prior_states[s].to_x36(&x36[s * LK_STATE_DOUBLES]);
+            std::memcpy(&P900[s * DIM_STATE * DIM_STATE], prior_covs[s].d.data(), sizeof(double) * DIM_STATE * DIM_STATE);
+            if (imus) {
+                n_imu.push_back((uint32_t)(*imus)[s].size());
+                imu_flat.insert(imu_flat.end(), (*imus)[s].begin(), (*imus)[s].end());
+            }
+        }
+        void* d_pts = nullptr;
+        dev_->check(lk_device_malloc(dev_->h(), &d_pts, sizeof(lk_point) * std::max<size_t>(pts.size(), 1)));
+        std::vector<lk_pose> out(S);
+        int rc = lk_memcpy_h2d(dev_->h(), d_pts, pts.data(), sizeof(lk_point) * pts.size());
+        if (!rc) rc = lk_batch_set_priors(dev_->h(), x36.data(), P900.data(), S);
+        if (!rc)
+            rc = imus ? lk_batch_replay_ragged_imu_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
+                                                       bucket_off.data(), bucket_dt.data(), t_begin.data(), n_imu.data(), imu_flat.data(),
+                                                       out.data())
+                      : lk_batch_replay_ragged_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
+                                                   bucket_off.data(), bucket_dt.data(), t_begin.data(), out.data());
+        lk_device_free(dev_->h(), d_pts);
+        dev_->check(rc);
+        return out;
     }
 
    private:
