@@ -205,6 +205,7 @@ int lk_init_process_cov_q(lk_handle* h);                               /* initPr
 int lk_set_times(lk_handle* h, uint32_t slot, double last_predict_t, double last_update_t); /* KILO.cc:350-351 */
 int lk_get_times(lk_handle* h, uint32_t slot, double* last_predict_t, double* last_update_t);
 int lk_set_acc_norm(lk_handle* h, double acc_norm);                    /* KILO.cc:349 */
+int lk_get_acc_norm(lk_handle* h, double* acc_norm);                   /* acc_norm_ (KILO.h:60): part of a checkpoint */
 int lk_get_fx(lk_handle* h, uint32_t slot, double dt, double* Fx900);   /* getFx, eskf.cc:72-81 */
 int lk_get_function_f(lk_handle* h, uint32_t slot, double dt, double* f30); /* getFunctionf, eskf.cc:64-70 */
 int lk_predict(lk_handle* h, uint32_t slot, double dt, int prop_state, int prop_cov);   /* predict, eskf.cc:83-89 */

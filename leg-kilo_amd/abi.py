@@ -108,6 +108,16 @@ class lk_blob_header(C.Structure):
     ]
 
 
+def blob_header_dtype():
+    """numpy view of lk_blob_header (48 B)."""
+    import numpy as np
+
+    dt = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_roots", "<u4"), ("n_nodes", "<u4"), ("n_blocks", "<u4"), ("block_pts", "<u4"),
+                   ("voxel_size", "<f8"), ("max_layer", "<i4"), ("max_points_num", "<i4"), ("bytes", "<u8")])
+    assert dt.itemsize == C.sizeof(lk_blob_header)
+    return dt
+
+
 # numpy dtypes of the blob records (for parsing exports in tests / tools)
 def blob_dtypes():
     import numpy as np

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LEGKILO_HIP_LIB", os.path.join(_HERE, "liblegkilo_hip
 
 EXPORTS = [
     "lk_abi_version", "lk_create", "lk_destroy", "lk_last_error", "lk_set_state", "lk_get_state", "lk_set_Q", "lk_get_Q",
-    "lk_init_process_cov_q", "lk_set_times", "lk_get_times", "lk_set_acc_norm", "lk_get_fx", "lk_get_function_f",
+    "lk_init_process_cov_q", "lk_set_times", "lk_get_times", "lk_set_acc_norm", "lk_get_acc_norm", "lk_get_fx", "lk_get_function_f",
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
@@ -123,6 +123,11 @@ class LegKiloHip:
 
     def set_acc_norm(self, a):
         self._chk(self.L.lk_set_acc_norm(self.h, C.c_double(a)))
+
+    def get_acc_norm(self):
+        a = C.c_double()
+        self._chk(self.L.lk_get_acc_norm(self.h, C.byref(a)))
+        return a.value
 
     def get_fx(self, dt, slot=0):
         F = np.zeros(900)

@@ -1,6 +1,6 @@
 """Checkpoint / resume of one handle (the reference has none; 8f rank 4: the map blob is the format).
 
-A checkpoint = filter state (x, P, Q, the two time stamps) + the voxel-map blob of lk_map_export + the map's
+A checkpoint = filter state (x, P, Q, the two time stamps, acc_norm_ of KILO.cc:349 read back from the handle) + the voxel-map blob of lk_map_export + the map's
 last_slide_position (voxel_map.h:201).  Restoring it into a
 fresh handle with the same configuration continues bit-identically: node / block ids may differ after the
 re-import, results do not depend on them.
@@ -8,10 +8,10 @@ re-import, results do not depend on them.
 import numpy as np
 
 
-def save(path, handle, acc_norm=9.81):
+def save(path, handle):
     x, P = handle.get_state()
     tp, tu = handle.get_times()
-    np.savez_compressed(path, x=x, P=P, Q=handle.get_Q(), times=np.array([tp, tu]), acc_norm=acc_norm,
+    np.savez_compressed(path, x=x, P=P, Q=handle.get_Q(), times=np.array([tp, tu]), acc_norm=handle.get_acc_norm(),
                         last_slide_position=handle.get_last_slide_position(), blob=np.asarray(handle.map_export(), dtype=np.uint8))
 
 

@@ -106,6 +106,23 @@ static int launch(lk_handle* h, const char* name, F&& f) {
         if (rc_ != LK_OK) return rc_;                          \
     } while (0)
 
+// device temporaries of one call: freed on every return path
+struct DevTemps {
+    std::vector<void*> ptrs;
+    ~DevTemps() {
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+    }
+    template <typename T>
+    hipError_t alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T*)p;
+        return e;
+    }
+};
+
 static unsigned int next_pow2(unsigned int v) {
     unsigned int p = 1;
     while (p < v) p <<= 1;
@@ -124,6 +141,8 @@ static int check_map_errors(lk_handle* h) {
     }
     return LK_OK;
 }
+
+static int create_pools(lk_handle* h, const lk_config* cfg);
 
 extern "C" {
 
@@ -154,6 +173,17 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
         return fail(nullptr, LK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     lk_handle* h = new lk_handle;
     h->cfg = *cfg;
+    const int rc = create_pools(h, cfg);
+    if (rc != LK_OK) {  // release whatever was allocated before the failure (lk_destroy is null-safe per field)
+        const std::string why = h->err;
+        lk_destroy(h);
+        return fail(nullptr, rc, why);
+    }
+    *out = h;
+    return LK_OK;
+}
+
+static int create_pools(lk_handle* h, const lk_config* cfg) {
     HIPCHK(h, hipSetDevice(cfg->device_id));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -230,7 +260,6 @@ int lk_create(const lk_config* cfg, lk_handle** out) {
     hipLaunchKernelGGL(lk_pool_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, h->stream, m, h->hash_cap);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    *out = h;
     return LK_OK;
 }
 
@@ -337,6 +366,12 @@ int lk_get_times(lk_handle* h, uint32_t slot, double* last_predict_t, double* la
 int lk_set_acc_norm(lk_handle* h, double acc_norm) {
     CHECK_H(h);
     h->acc_norm = acc_norm;
+    return LK_OK;
+}
+int lk_get_acc_norm(lk_handle* h, double* acc_norm) {
+    CHECK_H(h);
+    if (!acc_norm) return fail(h, LK_ERR_INVALID, "acc_norm is null");
+    *acc_norm = h->acc_norm;
     return LK_OK;
 }
 int lk_get_fx(lk_handle* h, uint32_t slot, double dt, double* Fx900) {
@@ -622,13 +657,14 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     int *d_i0 = nullptr, *d_i1 = nullptr;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
-    HIPCHK(h, hipMalloc(&d_w, sizeof(float) * 3 * n));
-    HIPCHK(h, hipMalloc(&d_b, sizeof(float) * 3 * n));
-    HIPCHK(h, hipMalloc(&d_bpts, sizeof(lk_pt_rec) * n));
-    HIPCHK(h, hipMalloc(&d_k0, sizeof(unsigned int) * n));
-    HIPCHK(h, hipMalloc(&d_k1, sizeof(unsigned int) * n));
-    HIPCHK(h, hipMalloc(&d_i0, sizeof(int) * n));
-    HIPCHK(h, hipMalloc(&d_i1, sizeof(int) * n));
+    DevTemps tmp;
+    HIPCHK(h, tmp.alloc(&d_w, sizeof(float) * 3 * n));
+    HIPCHK(h, tmp.alloc(&d_b, sizeof(float) * 3 * n));
+    HIPCHK(h, tmp.alloc(&d_bpts, sizeof(lk_pt_rec) * n));
+    HIPCHK(h, tmp.alloc(&d_k0, sizeof(unsigned int) * n));
+    HIPCHK(h, tmp.alloc(&d_k1, sizeof(unsigned int) * n));
+    HIPCHK(h, tmp.alloc(&d_i0, sizeof(int) * n));
+    HIPCHK(h, tmp.alloc(&d_i1, sizeof(int) * n));
     HIPCHK(h, hipMemcpyAsync(d_w, xyz_world, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_b, xyz_body, sizeof(float) * 3 * n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->map);
@@ -637,16 +673,14 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
                                                  h->d_filters, d_w, d_b, (int)n, d_bpts, d_k0, d_i0));
     // stable sort by root id: groups each root's points, preserving input order (voxel_map.cc:313-332)
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
-    HIPCHK(h, hipMalloc(&d_tmp, tmp_bytes));
+    HIPCHK(h, tmp.alloc(&d_tmp, tmp_bytes));
     HIPCHK(h, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
     LAUNCH(h, "build_segments",
            hipLaunchKernelGGL(lk_build_segments_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, d_k1, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
     LAUNCH(h, "build_tree", hipLaunchKernelGGL(lk_build_tree_kernel, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                d_bpts, d_i1, d_i0));
-    int rc = check_map_errors(h);
-    hipFree(d_w), hipFree(d_b), hipFree(d_bpts), hipFree(d_k0), hipFree(d_k1), hipFree(d_i0), hipFree(d_i1), hipFree(d_tmp);
-    return rc;
+    return check_map_errors(h);  // synchronises the stream; `tmp` frees the temporaries
 }
 
 int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) {
@@ -660,7 +694,8 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
         st[i].var[0] = v[0], st[i].var[1] = v[1], st[i].var[2] = v[2], st[i].var[3] = v[4], st[i].var[4] = v[5], st[i].var[5] = v[8];
     }
     lk_pt_rec* d_pv = nullptr;
-    HIPCHK(h, hipMalloc(&d_pv, sizeof(lk_pt_rec) * n));
+    DevTemps tmp;
+    HIPCHK(h, tmp.alloc(&d_pv, sizeof(lk_pt_rec) * n));
     HIPCHK(h, hipMemcpyAsync(d_pv, st.data(), sizeof(lk_pt_rec) * n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->map);
     const int nb = (int)((n + 255) / 256);
@@ -672,9 +707,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
                                               h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     LAUNCH(h, "insert_pv_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<true>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
                                                        h->map, h->pr, h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
-    int rc = check_map_errors(h);
-    hipFree(d_pv);
-    return rc;
+    return check_map_errors(h);  // synchronises the stream; `tmp` frees d_pv
 }
 
 static int upload_xyz_as_points(lk_handle* h, const float* xyz, size_t n) {
@@ -887,6 +920,37 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
     return LK_OK;
 }
 
+// A blob is only usable by a handle configured like the one that wrote it: the voxel size defines the keys, max_layer
+// and max_points_num the insert state machine.
+static int check_blob_config(lk_handle* h, const lk_blob_header& hd) {
+    if (hd.voxel_size != h->cfg.max_voxel_size || hd.max_layer != h->cfg.max_layer || hd.max_points_num != h->cfg.max_points_num) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "blob was written with voxel_size %.9g / max_layer %d / max_points_num %d, the handle has %.9g / %d / %d",
+                 hd.voxel_size, hd.max_layer, hd.max_points_num, h->cfg.max_voxel_size, h->cfg.max_layer, h->cfg.max_points_num);
+        return fail(h, LK_ERR_INVALID, buf);
+    }
+    return LK_OK;
+}
+
+// child / block / root-node ids of an imported map must index the imported pools (device-resident blobs are checked
+// where they are; a host blob is checked on the host before anything is copied)
+__global__ void lk_validate_ids_kernel(LkMap map, unsigned int n_nodes, unsigned int n_blocks, unsigned int hash_cap) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n_nodes) {
+        const lk_node_rec* nd = &map.nodes[i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bad |= nd->child[c] < -1 || nd->child[c] >= (int)n_nodes;
+        bad |= nd->block < -1 || nd->block >= (int)n_blocks;
+        bad |= nd->npts < 0 || (nd->block >= 0 && nd->npts > LK_BLOCK_PTS);
+    }
+    if (i < hash_cap) {
+        const int4 e = map.hash[i];
+        bad |= e.w >= (int)n_nodes || e.w < LK_LOCKED;
+    }
+    if (bad) atomicOr(&map.counters[LK_CTR_ERR], LK_E_BAD_BLOB);
+}
+
 static int reset_pools(lk_handle* h) {
     unsigned int ninit = std::max(h->hash_cap, h->map.max_nodes);
     hipLaunchKernelGGL(lk_pool_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, h->stream, h->map, h->hash_cap);
@@ -901,14 +965,37 @@ int lk_map_import(lk_handle* h, const void* blob, size_t bytes) {
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != LK_BLOB_MAGIC || hd.version != LK_ABI_VERSION || hd.block_pts != LK_BLOCK_PTS || hd.bytes > bytes)
         return fail(h, LK_ERR_INVALID, "bad blob header");
+    {   // the counts must account for every byte: a truncated or corrupt blob must not make the copies read past `blob`
+        const size_t expect = sizeof(hd) + (size_t)hd.n_roots * sizeof(lk_root_rec) +
+                              (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) + (size_t)hd.n_blocks * sizeof(lk_block_rec);
+        if (expect != hd.bytes) return fail(h, LK_ERR_INVALID, "blob size does not match its record counts (truncated or corrupt)");
+    }
+    int rc = check_blob_config(h, hd);
+    if (rc) return rc;
     if (hd.n_nodes > h->map.max_nodes || hd.n_blocks > h->map.max_blocks || 2 * (size_t)hd.n_roots > h->hash_cap)
         return fail(h, LK_ERR_CAPACITY, "blob exceeds pool capacities");
-    int rc = reset_pools(h);
+    {   // ids are range-checked here, on the host copy, before the device sees them
+        const char* q = (const char*)blob + sizeof(hd);
+        const lk_root_rec* rr = (const lk_root_rec*)q;
+        for (uint32_t i = 0; i < hd.n_roots; ++i)
+            if (rr[i].node < 0 || (uint32_t)rr[i].node >= hd.n_nodes) return fail(h, LK_ERR_INVALID, "blob: root node id out of range");
+        const lk_node_rec* nn = (const lk_node_rec*)(q + (size_t)hd.n_roots * sizeof(lk_root_rec));
+        for (uint32_t i = 0; i < hd.n_nodes; ++i) {
+            lk_node_rec nd;
+            memcpy(&nd, &nn[i], sizeof(nd));
+            for (int c = 0; c < 8; ++c)
+                if (nd.child[c] < -1 || nd.child[c] >= (int)hd.n_nodes) return fail(h, LK_ERR_INVALID, "blob: child id out of range");
+            if (nd.block < -1 || nd.block >= (int)hd.n_blocks || nd.npts < 0 || (nd.block >= 0 && nd.npts > LK_BLOCK_PTS))
+                return fail(h, LK_ERR_INVALID, "blob: point block id / count out of range");
+        }
+    }
+    rc = reset_pools(h);
     if (rc) return rc;
     const char* p = (const char*)blob + sizeof(hd);
     lk_root_rec* d_roots = nullptr;
+    DevTemps tmp;
     if (hd.n_roots) {
-        HIPCHK(h, hipMalloc(&d_roots, sizeof(lk_root_rec) * hd.n_roots));
+        HIPCHK(h, tmp.alloc(&d_roots, sizeof(lk_root_rec) * hd.n_roots));
         HIPCHK(h, hipMemcpyAsync(d_roots, p, sizeof(lk_root_rec) * hd.n_roots, hipMemcpyHostToDevice, h->stream));
     }
     p += (size_t)hd.n_roots * sizeof(lk_root_rec);
@@ -926,9 +1013,7 @@ int lk_map_import(lk_handle* h, const void* blob, size_t bytes) {
     ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
     // only the first three counters: the hash-insert kernel may raise the error word concurrently
     HIPCHK(h, hipMemcpyAsync(h->map.counters, ctr, 3 * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
-    rc = check_map_errors(h);
-    if (d_roots) hipFree(d_roots);
-    return rc;
+    return check_map_errors(h);
 }
 
 // Device-resident blob for the RCCL broadcast: header | hash table (full) | nodes | planes | blocks (used prefixes).
@@ -972,13 +1057,15 @@ int lk_map_import_dev(lk_handle* h, const void* d_blob, size_t bytes) {
     HIPCHK(h, hipMemcpy(&hd, d_blob, sizeof(hd), hipMemcpyDeviceToHost));
     if (hd.magic != LK_BLOB_MAGIC || hd.version != (LK_ABI_VERSION | 0x100u) || hd.bytes > bytes)
         return fail(h, LK_ERR_INVALID, "bad device blob header");
+    int rc = check_blob_config(h, hd);
+    if (rc) return rc;
     if (hd.n_nodes > h->map.max_nodes || hd.n_blocks > h->map.max_blocks)
         return fail(h, LK_ERR_CAPACITY, "device blob exceeds pool capacities");
     size_t expect = sizeof(hd) + sizeof(int4) * (size_t)h->hash_cap + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
                     (size_t)hd.n_blocks * sizeof(lk_block_rec);
     if (((expect + 255) & ~(size_t)255) != hd.bytes)
         return fail(h, LK_ERR_INVALID, "device blob was exported with different capacities (max_roots must match)");
-    int rc = reset_pools(h);
+    rc = reset_pools(h);
     if (rc) return rc;
     const char* p = (const char*)d_blob + sizeof(hd);
     HIPCHK(h, hipMemcpyAsync(h->map.hash, p, sizeof(int4) * (size_t)h->hash_cap, hipMemcpyDeviceToDevice, h->stream));
@@ -993,7 +1080,17 @@ int lk_map_import_dev(lk_handle* h, const void* d_blob, size_t bytes) {
     unsigned int ctr[LK_CTR_COUNT] = {0};
     ctr[LK_CTR_NODES] = hd.n_nodes, ctr[LK_CTR_BLOCKS] = hd.n_blocks, ctr[LK_CTR_ROOTS] = hd.n_roots;
     HIPCHK(h, hipMemcpyAsync(h->map.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        const unsigned int nv = std::max(hd.n_nodes, h->hash_cap);
+        hipLaunchKernelGGL(lk_validate_ids_kernel, dim3((nv + 255) / 256), dim3(256), 0, h->stream, h->map, hd.n_nodes, hd.n_blocks, h->hash_cap);
+        HIPCHK(h, hipGetLastError());
+    }
+    rc = check_map_errors(h);
+    if (rc) {  // a map with dangling ids must not stay loaded
+        reset_pools(h);
+        hipStreamSynchronize(h->stream);
+        return fail(h, LK_ERR_INVALID, "device blob: node / block ids out of range");
+    }
     return LK_OK;
 }
 
@@ -1429,6 +1526,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     // pass 1: validate, count the non-empty buckets of every scan (empty ones are skipped, as in the uniform entry), pitch
     std::vector<uint32_t> cnt(S);
     size_t row_o = 0, row_t = 0, ldb = 0;
+    uint32_t biggest_bucket = 0;
     for (size_t s = 0; s < S; ++s) {
         const uint32_t* bo = bucket_off + row_o;
         const size_t nbs = n_buckets[s];
@@ -1439,12 +1537,16 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
             if (bo[b + 1] < bo[b]) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing");
             if ((size_t)(bo[b + 1] - bo[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
             c += bo[b + 1] > bo[b];
+            biggest_bucket = std::max(biggest_bucket, bo[b + 1] - bo[b]);
         }
         if (c == 0) return fail(h, LK_ERR_INVALID, "empty scan");
         cnt[s] = c;
         ldb = std::max(ldb, (size_t)c);
         row_o += nbs + 1, row_t += nbs;
     }
+    // every check comes before the first memset / upload / launch: a refused call leaves the filter slots untouched
+    if (n_imu && biggest_bucket > (uint32_t)LK_SCAN_WAVE_MAX)
+        return fail(h, LK_ERR_INVALID, "IMU messages between buckets are only replayed for scans whose buckets hold <= 512 points");
     // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32, staged in pinned host memory
     size_t n_imu_total = 0;
     if (n_imu)
@@ -1513,9 +1615,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     hipStream_t st = h->stream;
     LkFilter* fl = h->d_filters;
     hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, reinterpret_cast<const double*>(dr + o_tb));
-    const int biggest = *std::max_element(max_n.begin(), max_n.end());
-    if (n_imu && biggest > LK_SCAN_WAVE_MAX)
-        return fail(h, LK_ERR_INVALID, "IMU messages between buckets are only replayed for scans whose buckets hold <= 512 points");
+    const int biggest = (int)biggest_bucket;
     if (biggest <= LK_SCAN_WAVE_MAX && (n_imu || !getenv("LEGKILO_RAGGED_LEVELS"))) {
         // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
         if (n_imu)
@@ -1573,9 +1673,19 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
     if ((d_x36 == nullptr) != (d_P900 == nullptr)) return fail(h, LK_ERR_INVALID, "give both prior buffers or neither");
     const int S = (int)n_scans;
+    for (size_t b = 0; b < n_buckets; ++b)   // all checks before the first enqueue
+        if (bucket_off[b + 1] > bucket_off[b] && (size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan)
+            return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
     hipStream_t st = ((first_slot / (uint32_t)n_scans) & 1u) ? h->side[0] : h->stream;
     LkFilter* fl = h->d_filters + first_slot;
     double* parts = h->d_partials + (size_t)first_slot * h->part_stride;
+    if (st != h->stream && !d_x36) {
+        // the slots' state was armed elsewhere (lk_batch_set_priors_dev is asynchronous on the MAIN stream): order this batch
+        // after it.  With d_x36 / d_P900 the batch arms its own slots on its own stream and needs no such edge - which is
+        // what keeps two batches in flight.
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_fork, 0));
+    }
     if (d_x36) {
         HIPCHK(h, hipMemcpy2DAsync(fl[0].x, sizeof(LkFilter), d_x36, sizeof(double) * 36, sizeof(double) * 36, n_scans, hipMemcpyDeviceToDevice, st));
         HIPCHK(h, hipMemcpy2DAsync(fl[0].P, sizeof(LkFilter), d_P900, sizeof(double) * 900, sizeof(double) * 900, n_scans, hipMemcpyDeviceToDevice, st));
@@ -1588,7 +1698,6 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     for (size_t b = 0; b < n_buckets; ++b) {
         if (bucket_off[b + 1] <= bucket_off[b]) continue;
         const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
-        if ((size_t)nb > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
         size_t nx = b + 1;
         while (nx < n_buckets && bucket_off[nx + 1] <= bucket_off[nx]) ++nx;
         const bool has_next = nx < n_buckets;

@@ -34,6 +34,7 @@
 #define LK_E_NODES_FULL 2u
 #define LK_E_BLOCKS_FULL 4u
 #define LK_E_SCRATCH_FULL 8u
+#define LK_E_BAD_BLOB 16u
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,
        LK_CTR_HEAVY = 6, LK_CTR_FREE = 7 /* signed: blocks poppable this bucket */, LK_CTR_FREED = 8 /* blocks retired

@@ -1,6 +1,8 @@
 // Minimal use of the C++ mirror, written the way KILO.cc drives the reference classes: first-frame
 // BuildVoxelMap on a synthetic floor + wall, one predictUpdatePoint bucket, then a two-scan recorded-run replay.  Needs a gfx950 device
-// to RUN (exit code 3 otherwise); tests/test_abi_and_host.py only checks that it compiles and links.
+// to RUN (exit code 3 otherwise); tests/test_abi_and_host.py only checks that it compiles and links.  With a path as argv[1] it
+// dumps its inputs and results (a flat binary: counts, the two clouds, x36 after the bucket, the match count, the replay poses) so
+// that tests/test_golden.py can replay the SAME inputs through the oracle and compare state and counts, not just sanity.
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -9,7 +11,7 @@
 
 using namespace legkilo;
 
-int main() {
+int main(int argc, char** argv) {
     ESKF::Config ec{20, 500, 1000, 20, 0.001, 0.001, 0.001, 0.1, 1.0, 0.01, 0.1, 0.1, 0.001, 10};
     VoxelMapConfig vc;
     DeviceCaps caps;
@@ -57,6 +59,22 @@ int main() {
     std::vector<lk_pose> poses = kilo->replayRecordedRun({scan, scan}, {0.02, 0.05}, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
     std::printf("replay: %u / %u buckets, matched %llu / %llu\n", poses[0].n_buckets, poses[1].n_buckets,
                 (unsigned long long)poses[0].n_effect, (unsigned long long)poses[1].n_effect);
+    if (argc > 1) {
+        FILE* f = std::fopen(argv[1], "wb");
+        if (!f) return 4;
+        const unsigned int hdr[4] = {(unsigned int)body->size(), (unsigned int)bucket.size(), (unsigned int)n_success, (unsigned int)poses.size()};
+        std::fwrite(hdr, sizeof(hdr), 1, f);
+        for (const auto* c : {world.get(), body.get()})
+            for (const PointType& q : *c) {
+                const float xyz[3] = {q.x, q.y, q.z};
+                std::fwrite(xyz, sizeof(xyz), 1, f);
+            }
+        double x36[36];
+        kilo->eskf().state().to_x36(x36);
+        std::fwrite(x36, sizeof(x36), 1, f);
+        std::fwrite(poses.data(), sizeof(lk_pose), poses.size(), f);
+        std::fclose(f);
+    }
     const bool replay_ok = poses.size() == 2 && poses[0].n_buckets == 2 && poses[1].n_buckets == 2 && poses[1].n_effect > 500;
     return (updated && n_success > 500 && std::fabs(p[2] - 0.5) < 0.05 && replay_ok) ? 0 : 1;
 }

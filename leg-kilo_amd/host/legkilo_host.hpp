@@ -290,6 +290,11 @@ class KiloPath {
     VoxelMapManager& map_manager() { return *map_manager_; }
     void setTimes(double last_predict, double last_update) { dev_->check(lk_set_times(dev_->h(), 0, last_predict, last_update)); }
     void setAccNorm(double a) { dev_->check(lk_set_acc_norm(dev_->h(), a)); }
+    double accNorm() const {
+        double a = 0.0;
+        dev_->check(lk_get_acc_norm(dev_->h(), &a));
+        return a;
+    }
 
     // KILO.cc:108-233
     bool predictUpdatePoint(double current_time, size_t idx_i, size_t idx_j, const PointCloudType& cloud_down_body,

@@ -199,6 +199,13 @@ class Oracle:
         assert rc == 0
         return buf
 
+    def map_import(self, blob):
+        """Rebuild the octrees from a blob of include/legkilo_hip.h (e.g. LegKiloHip.map_export()): the checker then
+        replays against exactly the map the device handle holds."""
+        buf = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        rc = self.L.lko_map_import(self.h, _p(buf), C.c_size_t(buf.nbytes))
+        assert rc == 0, "lko_map_import: malformed blob"
+
     def map_stats(self):
         n = C.c_uint32()
         self.L.lko_map_stats(self.h, C.byref(n))

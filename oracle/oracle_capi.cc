@@ -236,6 +236,79 @@ int lko_map_export(lko_handle* h, void* blob, size_t* bytes) {
                                                                    m.config_setting_.max_points_num_, blob, bytes);
 }
 
+// ---- blob import (the inverse of export_blob.hpp): rebuild the octrees from a blob of include/legkilo_hip.h, so that a
+// checker can replay scans against EXACTLY the map a device handle holds (bench.py's in-line parity check of the timed loop,
+// tests).  What the blob does not carry is not restored: points of first-frame leaves with more than LK_BLOCK_PTS points
+// (LK_NODE_PTS_DROPPED - such leaves are frozen, voxel_map.cc:199) and points of inner non-plane nodes (never read again).
+static VoxelOctoTree* import_node(const lk_config& cfg, const lk_node_rec* nodes, const lk_plane_rec* planes,
+                                  const lk_block_rec* blocks, uint32_t n_nodes, uint32_t n_blocks, int id, int depth) {
+    if (id < 0 || (uint32_t)id >= n_nodes || depth > 8) return nullptr;
+    const lk_node_rec& n = nodes[id];
+    const lk_plane_rec& p = planes[id];
+    const int layer = n.layer;
+    const int lin = (layer >= 0 && layer < 5) ? cfg.layer_init_num[layer] : cfg.layer_init_num[4];
+    VoxelOctoTree* t = new VoxelOctoTree(cfg.max_layer, layer, lin, cfg.max_points_num, (float)cfg.planner_threshold);
+    for (int c = 0; c < 3; ++c) t->voxel_center_[c] = n.voxel_center[c];
+    t->quater_length_ = n.quater_length;
+    t->new_points_ = n.new_points;
+    t->init_octo_ = (n.state & LK_NODE_INIT_OCTO) != 0;
+    t->update_enable_ = (n.state & LK_NODE_UPDATE_ENABLE) != 0;
+    t->octo_state_ = (n.state & LK_NODE_OCTO_STATE) ? 1 : 0;
+    t->layer_init_num_.assign(cfg.layer_init_num, cfg.layer_init_num + 5);
+    if (n.block >= 0 && (uint32_t)n.block < n_blocks && n.npts > 0 && n.npts <= LK_BLOCK_PTS) {
+        const lk_block_rec& b = blocks[n.block];
+        t->temp_points_.resize(n.npts);
+        for (int i = 0; i < n.npts; ++i) {
+            pointWithVar& pv = t->temp_points_[i];
+            for (int c = 0; c < 3; ++c) pv.point_w[c] = b.pts[i].pw[c];
+            const double* v = b.pts[i].var;
+            pv.var(0, 0) = v[0], pv.var(0, 1) = v[1], pv.var(0, 2) = v[2], pv.var(1, 0) = v[1], pv.var(1, 1) = v[3];
+            pv.var(1, 2) = v[4], pv.var(2, 0) = v[2], pv.var(2, 1) = v[4], pv.var(2, 2) = v[5];
+        }
+    }
+    VoxelPlane& pl = *t->plane_ptr_;
+    for (int c = 0; c < 3; ++c) pl.center_[c] = p.center[c], pl.normal_[c] = p.normal[c];
+    pl.d_ = p.d;
+    pl.radius_ = p.radius;
+    pl.is_plane_ = (p.flags & LK_PLANE_IS_PLANE) != 0;
+    pl.is_init_ = (p.flags & LK_PLANE_IS_INIT) != 0;
+    pl.points_size_ = p.points_size;
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) pl.plane_var_(r, c) = pl.plane_var_(c, r) = p.plane_var[k++];
+    pl.min_eigen_value_ = p.min_eigen_value;
+    pl.mid_eigen_value_ = p.mid_eigen_value;
+    pl.max_eigen_value_ = p.max_eigen_value;
+    for (int l = 0; l < 8; ++l)
+        if (n.child[l] >= 0) t->leaves_[l] = import_node(cfg, nodes, planes, blocks, n_nodes, n_blocks, n.child[l], depth + 1);
+    return t;
+}
+int lko_map_import(lko_handle* h, const void* blob, size_t bytes) {
+    if (!blob || bytes < sizeof(lk_blob_header)) return -1;
+    lk_blob_header hd;
+    std::memcpy(&hd, blob, sizeof(hd));
+    const size_t want = sizeof(hd) + (size_t)hd.n_roots * sizeof(lk_root_rec) + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
+                        (size_t)hd.n_blocks * sizeof(lk_block_rec);
+    if (hd.magic != LK_BLOB_MAGIC || hd.block_pts != LK_BLOCK_PTS || hd.bytes != want || want > bytes) return -1;
+    const char* p = (const char*)blob + sizeof(hd);
+    const lk_root_rec* roots = (const lk_root_rec*)p;
+    p += (size_t)hd.n_roots * sizeof(lk_root_rec);
+    const lk_node_rec* nodes = (const lk_node_rec*)p;
+    p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
+    const lk_plane_rec* planes = (const lk_plane_rec*)p;
+    p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
+    const lk_block_rec* blocks = (const lk_block_rec*)p;
+    auto& m = *h->kilo->map_manager_;
+    for (auto& kv : m.voxel_map_) delete kv.second;
+    m.voxel_map_.clear();
+    for (uint32_t r = 0; r < hd.n_roots; ++r) {
+        VoxelOctoTree* t = import_node(h->cfg, nodes, planes, blocks, hd.n_nodes, hd.n_blocks, roots[r].node, 0);
+        if (!t) return -1;
+        m.voxel_map_[Vec3i{roots[r].key[0], roots[r].key[1], roots[r].key[2]}] = t;
+    }
+    return 0;
+}
+
 // VoxelMapManager::mapSliding with the caller-set position_last_ and the two parameters of voxel_map.h:54,56
 int lko_map_slide(lko_handle* h, const double* position3, double sliding_thresh, int half_map_size, int* slid, uint32_t* n_removed) {
     auto* m = h->kilo->map_manager_.get();

@@ -75,8 +75,10 @@ def test_hip_reproduces_golden(hip_lib):
 
 
 @pytest.mark.gpu
-def test_host_mirror_example_runs(hip_lib):
-    """The C++ mirror of the reference classes (leg-kilo_amd/host) drives the same library end to end."""
+def test_host_mirror_example_runs(hip_lib, oracle_lib):
+    """The C++ mirror of the reference classes (leg-kilo_amd/host) drives the same library end to end, and what it computes -
+    BuildVoxelMap, one predictUpdatePoint bucket, a two-scan recorded-run replay - equals the oracle on the SAME inputs (the
+    example dumps its clouds and results): match count exact, state to 1e-7, replay poses to 1e-7."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,8 +87,53 @@ def test_host_mirror_example_runs(hip_lib):
                         os.path.join(root, "leg-kilo_amd", "host", "example_kilo_path.cc"), "-o", exe, "-L", os.path.join(root, "leg-kilo_amd"),
                         "-llegkilo_hip", "-Wl,-rpath," + os.path.join(root, "leg-kilo_amd")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    dump = "/tmp/lk_host_example_dump.bin"
+    r = subprocess.run([exe, dump], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1500:])
+    from legkilo_amd import abi, config
+
+    raw = open(dump, "rb").read()
+    n, nb, n_succ, n_poses = np.frombuffer(raw, dtype=np.uint32, count=4)
+    o_ = 16
+    world = np.frombuffer(raw, dtype=np.float32, count=3 * n, offset=o_).reshape(n, 3)
+    o_ += 12 * n
+    body = np.frombuffer(raw, dtype=np.float32, count=3 * n, offset=o_).reshape(n, 3)
+    o_ += 12 * n
+    x_hip = np.frombuffer(raw, dtype=np.float64, count=36, offset=o_)
+    o_ += 288
+    poses = np.frombuffer(raw, dtype=abi.pose_dtype(), count=n_poses, offset=o_)
+    P = dict(config.LEG_FUSION)     # the example's ESKF::Config / VoxelMapConfig literals are leg_fusion.yaml's; extrinsic T = (0,0,0.2)
+    o = oracle_lib.Oracle(config.make_config(P), imu_mode_only=True)
+    x0 = np.zeros(36)
+    x0[:9] = np.eye(3).reshape(9)
+    x0[9:12] = [0, 0, 0.5]
+    x0[21:24] = [0, 0, -9.81]
+    o.set_state(x0, 1e-6 * np.eye(30))
+    o.init_process_cov_q()
+    o.set_times(0.0, 0.0)
+    o.map_build(world, body)
+    _, _, ne = o.update_points(0.01, body[:nb])
+    xo, Po = o.get_state()
+    assert int(ne) == int(n_succ) > 500, (ne, n_succ)
+    assert np.abs(xo - x_hip).max() < 1e-7, np.abs(xo - x_hip).max()
+    # the two-scan recorded-run replay: same bucket as two 2-ms buckets, from (posterior, P_post) and from (x0, P0), frozen map
+    pts = np.zeros(nb, dtype=synth_point_dtype())
+    pts["x"], pts["y"], pts["z"] = body[:nb, 0], body[:nb, 1], body[:nb, 2]
+    pts["curvature"] = np.where(np.arange(nb) < nb // 2, 0.0, 0.002).astype(np.float32)
+    o.set_map_insert(False)
+    for k, (xs, Ps, tb) in enumerate([(xo, Po, 0.02), (x0, 1e-6 * np.eye(30), 0.05)]):
+        o.set_state(xs, Ps)
+        o.set_times(tb, tb)
+        po, _ = o.process_scan(pts, tb)
+        assert (int(po.n_buckets), int(po.n_effect)) == (int(poses[k]["n_buckets"]), int(poses[k]["n_effect"])), k
+        assert np.abs(np.array(po.pos) - poses[k]["pos"]).max() < 1e-7 and np.abs(np.array(po.rot) - poses[k]["rot"]).max() < 1e-7, k
+    o.close()
+
+
+def synth_point_dtype():
+    from legkilo_amd import synth
+
+    return synth.POINT_DTYPE
 
 
 # ----------------------------------------------------------------------------- golden vectors made BY THE REFERENCE

@@ -64,6 +64,43 @@ def test_eskf_predict_and_fx(pair, scene):
         assert rel_err(Pg, Po) < 1e-12
 
 
+def test_device_exp_on_both_sides_of_the_thresholds(scene, oracle_lib, hip_lib):
+    """math_utils.hpp:19-32 (Exp(vec&&), identity below 1e-7: the (0,0) block of Fx, eskf.cc:74) and :54-68 (Exp(v1,v2,v3),
+    identity below 1e-5: the rotation part of x (+) dx, eskf.cc:19) ON THE DEVICE (expv_1e7 / exp3_1e5, lk_device.h), against the
+    reference's own two functions (oracle/_ref) - or the oracle's pinned restatement where _ref is not built."""
+    which = "ref" if oracle_lib.ref_lib() is not None else "oracle"
+    g = hip_lib.LegKiloHip(scene.cfg())
+    rng = np.random.default_rng(5)
+    R0 = oracle_lib.exp_log(np.array([0.3, -0.5, 0.8]))[0]
+    dirs = [np.array([1.0, 0, 0]), np.array([0.6, -0.8, 0.0]), rng.normal(size=3)]
+    mags = [0.0, 5e-8, 9.9e-8, 1.01e-7, 3e-6, 9.9e-6, 1.01e-5, 2e-5, 1e-3, 0.3, 3.0]
+    for d in dirs:
+        d = d / np.linalg.norm(d)
+        for m in mags:
+            v = m * d
+            x = np.zeros(36)
+            x[:9] = R0.reshape(9)
+            x[9:12] = [1.0, 2.0, 3.0]
+            x[27:30] = v                      # imu_w; dt = 1 -> f[0:3] = v, Fx(0:3,0:3) = Exp(-v)
+            g.set_state(x, 1e-4 * np.eye(30))
+            Fx = g.get_fx(1.0)
+            want_fx = oracle_lib.exp_log(-v, which)[1]
+            assert np.allclose(Fx[:3, :3], want_fx, rtol=0, atol=4e-16), (v, np.abs(Fx[:3, :3] - want_fx).max())
+            if np.linalg.norm(-v) <= 1e-7:
+                assert np.array_equal(Fx[:3, :3], np.eye(3)), v
+            elif m >= 1.01e-7:
+                assert not np.array_equal(Fx[:3, :3], np.eye(3)), v
+            g.predict(1.0, True, False)
+            xn, _ = g.get_state()
+            want_R = R0 @ oracle_lib.exp_log(v, which)[0]
+            assert np.allclose(xn[:9].reshape(3, 3), want_R, rtol=0, atol=1e-15), (v, np.abs(xn[:9].reshape(3, 3) - want_R).max())
+            if np.linalg.norm(v) <= 1e-5:
+                assert np.array_equal(xn[:9], x[:9]), v       # below the threshold Exp is exactly I: the rotation keeps its bits
+            elif m >= 1.01e-5:
+                assert not np.array_equal(xn[:9], x[:9]), v
+    g.close()
+
+
 @pytest.mark.parametrize("N", [1, 2, 7, 300, 5000])
 def test_update_by_points(pair, scene, N):
     o, g = pair
@@ -389,6 +426,32 @@ def test_config3_full_size(big):
     so = scenes.canon_map(o.map_export())
     sg = scenes.canon_map(g.map_export())
     assert set(so) == set(sg)
+
+
+def test_config3_51_buckets_full_size(big):
+    """SURVEY 8(d) config 3, the reference's own time quantisation: a 100 000-point scan in 51 two-ms bins (lidar_processing.cc:48)
+    = 51 predict / residual / update / re-project / insert cycles of ~2 000 points each (the variant bench.py times as
+    extra.stream51_*), against the oracle's bucket loop: identical bucket / update counts, match counts within 2, pose to 1e-6,
+    the same set of voxels afterwards."""
+    scene, o, g, t0 = big
+    for k in range(2):
+        tb = t0 + 0.3 + 0.1 * k
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=51, seed_scan=8208 + k, seed_noise=8308 + k)
+        off, _ = synth.buckets_of(pts)
+        assert len(off) - 1 == 51
+        for obj in (o, g):
+            obj.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30))
+            obj.set_times(tb, tb)
+        po, _ = o.process_scan(pts, tb)
+        pg, _ = g.process_scan(pts, tb)
+        assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (51, 51), (po.n_buckets, po.n_updates, pg.n_buckets, pg.n_updates)
+        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (po.n_effect, pg.n_effect)
+        assert po.n_effect > 30000
+        xo, _ = o.get_state()
+        xg, _ = g.get_state()
+        assert np.abs(xo[:12] - xg[:12]).max() < 1e-6, np.abs(xo[:12] - xg[:12]).max()
+        assert np.allclose(xo, xg, rtol=1e-4, atol=1e-4), np.abs(xo - xg).max()
+    assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
 
 
 def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
@@ -742,11 +805,15 @@ def test_checkpoint_resume_is_bit_identical(scene, hip_lib, tmp_path):
     a = hip_lib.LegKiloHip(scene.cfg())
     t0 = 1.0
     x0 = scenes.init_filter(a, scene, t0)
+    # acc_norm_ is |mean acc| of the initialisation window in a real run (KILO.cc:349), not 9.81: the checkpoint has to
+    # carry what the HANDLE holds (the IMU rows are scaled by gravity / acc_norm, KILO.cc:246)
+    a.set_acc_norm(9.6317)
     scenes.first_frame(a, scene, t0, x0)
     scenes.replay_vlp(a, scene, t0, 4)
     checkpoint.save(tmp_path / "ck.npz", a)
     b = hip_lib.LegKiloHip(scene.cfg())
     checkpoint.restore(tmp_path / "ck.npz", b)
+    assert b.get_acc_norm() == 9.6317
     ra = scenes.replay_vlp(a, scene, t0, 4, start=4)
     rb = scenes.replay_vlp(b, scene, t0, 4, start=4)
     for k, ((pa, xa), (pb, xb)) in enumerate(zip(ra, rb)):
@@ -758,6 +825,53 @@ def test_checkpoint_resume_is_bit_identical(scene, hip_lib, tmp_path):
     scenes.compare_maps(a.map_export(), b.map_export(), rtol=0.0, ptol=0.0)
     a.close()
     b.close()
+
+
+def test_map_import_rejects_malformed_blobs(scene, hip_lib):
+    """lk_map_import / lk_map_import_dev: a truncated blob, counts that do not add up to the size, ids that point outside the
+    pools and a blob written with another voxel size are refused with LK_ERR_INVALID before anything is used."""
+    import torch
+
+    a = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 1.0
+    x0 = scenes.init_filter(a, scene, t0)
+    scenes.first_frame(a, scene, t0, x0)
+    blob = np.asarray(a.map_export(), dtype=np.uint8).copy()
+    hd = blob[: abi.blob_header_dtype().itemsize].view(abi.blob_header_dtype())[0]
+    b = hip_lib.LegKiloHip(scene.cfg())
+    with pytest.raises(hip_lib.LegKiloError):
+        b.map_import(blob[:-64])                      # truncated
+    bad = blob.copy()
+    bad[: abi.blob_header_dtype().itemsize].view(abi.blob_header_dtype())["n_nodes"] += 3   # counts exceed the bytes
+    with pytest.raises(hip_lib.LegKiloError, match="size does not match"):
+        b.map_import(bad)
+    bad = blob.copy()
+    off_nodes = abi.blob_header_dtype().itemsize + int(hd["n_roots"]) * 16
+    bad[off_nodes: off_nodes + 4].view(np.int32)[0] = int(hd["n_nodes"]) + 7          # child[0] of node 0 out of range
+    with pytest.raises(hip_lib.LegKiloError, match="child id"):
+        b.map_import(bad)
+    P2 = dict(scene.P)
+    P2["voxel_size"] = 0.25
+    c = hip_lib.LegKiloHip(config.make_config(P2, **CAPS))
+    with pytest.raises(hip_lib.LegKiloError, match="voxel_size"):
+        c.map_import(blob)
+    # device-resident blob: same configuration check, ids validated on the device
+    nbytes = a.map_export_dev_size()
+    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.map_export_dev(d.data_ptr(), nbytes)
+    with pytest.raises(hip_lib.LegKiloError, match="voxel_size"):
+        c.map_import_dev(d.data_ptr(), nbytes)
+    b.map_import_dev(d.data_ptr(), nbytes)            # the intact blob loads
+    assert b.map_stats() == a.map_stats()
+    hsz = abi.blob_header_dtype().itemsize
+    # corrupt a child id inside the node pool of the device blob: header | hash table (8 x max_roots slots of 16 B) | nodes ...
+    node0 = hsz + 16 * (1 << int(np.ceil(np.log2(8 * int(scene.cfg().max_roots)))))
+    d[node0: node0 + 4] = torch.from_numpy(np.array([2 ** 30], dtype=np.int32).view(np.uint8)).cuda()
+    with pytest.raises(hip_lib.LegKiloError, match="out of range"):
+        b.map_import_dev(d.data_ptr(), nbytes)
+    assert b.map_stats() == (0, 0, 0)
+    for hnd in (a, b, c):
+        hnd.close()
 
 
 def count_tree(blob_bytes):

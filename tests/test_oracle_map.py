@@ -234,3 +234,35 @@ def test_map_sliding_semantics(o):
     # a surviving voxel keeps accepting points (the tree object was not touched)
     o.map_update((np.array([0.25, 0.25, 0.25]))[None, :], var)
     assert node_of(o, (0, 0, 0))["npts"] == 2
+
+
+def test_blob_import_round_trip_and_continuation():
+    """lko_map_import (oracle_capi.cc) rebuilds the octrees of an exported blob: the re-export is byte-identical, and two
+    more scans WITH insert through the rebuilt map give the same poses and the same map as the original handle.  This is
+    what lets bench.py's checker replay against exactly the map the device holds."""
+    sc = scenes.Scene()
+    t0 = 5.0
+    a = ob.Oracle(sc.cfg(), imu_mode_only=True)
+    x0 = scenes.init_filter(a, sc, t0)
+    scenes.first_frame(a, sc, t0, x0)
+    scenes.replay_vlp(a, sc, t0, 2)
+    blob = a.map_export()
+    xa, Pa = a.get_state()
+    b = ob.Oracle(sc.cfg(), imu_mode_only=True)
+    b.init_process_cov_q()
+    b.set_acc_norm(9.81)
+    b.map_import(blob)
+    assert np.array_equal(b.map_export(), blob)
+    b.set_state(xa, Pa)
+    b.set_times(*a.get_times())
+    ra = scenes.replay_vlp(a, sc, t0, 2, start=2)
+    rb = scenes.replay_vlp(b, sc, t0, 2, start=2)
+    for (pa, xa_), (pb, xb_) in zip(ra, rb):
+        assert (pa.n_effect, pa.n_buckets, pa.n_updates) == (pb.n_effect, pb.n_buckets, pb.n_updates)
+        # the blob keeps the upper triangles of plane_var / var only: the rebuilt matrices are exactly symmetric where the
+        # original accumulations are symmetric to rounding, hence last-bit differences
+        assert np.abs(xa_ - xb_).max() < 1e-9, np.abs(xa_ - xb_).max()
+    scenes.compare_maps(a.map_export(), b.map_export(), rtol=1e-6, ptol=1e-9)
+    with pytest.raises(AssertionError):
+        b.map_import(blob[:-8])
+    a.close(), b.close()

@@ -129,3 +129,78 @@ def test_map_transport_and_gather_world2(algo):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, True), (1, True, True)], res
+
+
+class OracleReplayEngine:
+    """TEST-ONLY engine: answers batch_replay_ragged by running the oracle's bucket loop scan by scan on a frozen map (the
+    product has no CPU engine).  Lets the CPU suite check that the SHARDED run (world 2, gloo) gathers exactly the rows of the
+    unsharded one (world 1) for the same scans - shard boundaries, ragged batches of max_batch, gather order."""
+
+    def __init__(self):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import oracle_binding as ob
+        import scenes
+
+        self.sc = scenes.Scene()
+        self.o = ob.Oracle(self.sc.cfg(), imu_mode_only=True)
+        t0 = 1.0
+        x0 = scenes.init_filter(self.o, self.sc, t0)
+        scenes.first_frame(self.o, self.sc, t0, x0)
+        self.o.set_map_insert(False)
+        self.scenes = scenes
+
+    def inputs(self, n):
+        from legkilo_amd import synth
+
+        scans, tbs, xs, Ps = [], [], [], []
+        for k in range(n):
+            tb = 1.0 + 0.1 * k
+            scans.append(self.scenes.vlp_scan_input(self.sc, tb, k)[: 600 + 50 * k])
+            tbs.append(tb)
+            xs.append(synth.initial_state(self.sc.traj, tb, self.sc.P, np.random.default_rng(k), 0.02, 0.5))
+            Ps.append(1e-4 * np.eye(30))
+        return scans, tbs, xs, Ps
+
+    def batch_replay_ragged(self, scans, t_begins, xs, Ps):
+        from legkilo_amd import abi
+
+        out = np.zeros(len(scans), dtype=abi.pose_dtype())
+        for i, (sc, tb, x, P) in enumerate(zip(scans, t_begins, xs, Ps)):
+            self.o.set_state(x, P)
+            self.o.set_times(tb, tb)
+            pose, _ = self.o.process_scan(sc, tb)
+            out["pos"][i], out["vel"][i], out["rot"][i] = pose.pos, pose.vel, pose.rot
+            out["n_effect"][i], out["n_buckets"][i], out["n_updates"][i] = pose.n_effect, pose.n_buckets, pose.n_updates
+        return out
+
+
+def _worker_same_rows(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = OracleReplayEngine()
+    scans, tbs, xs, Ps = eng.inputs(8)
+    rows = replay.replay_recorded_run(eng, dist, rank, world, torch.device("cpu"), scans, tbs, xs, Ps, max_batch=3)
+    q.put((rank, rows))
+    dist.destroy_process_group()
+
+
+def test_world1_and_world2_gather_identical_rows():
+    """The same 8 scans replayed unsharded (N = 1) and sharded over 2 ranks (gloo): every rank ends up with the SAME 8 rows,
+    bit for bit, in scan order - the property the multi-GPU bench relies on."""
+    eng = OracleReplayEngine()
+    scans, tbs, xs, Ps = eng.inputs(8)
+    solo = replay.replay_recorded_run(eng, None, 0, 1, torch.device("cpu"), scans, tbs, xs, Ps, max_batch=3)
+    assert solo.shape == (8, 18) and (solo[:, 15] > 100).all()     # every scan matched points
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_same_rows, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert np.array_equal(res[r], solo), (r, np.abs(res[r] - solo).max())
