@@ -18,7 +18,7 @@ config 3's per-scan semantics:
 The line is self-checking: the cpu_baseline leg replays a sample of the batch through the oracle ON THE MAP THE DEVICE
 HOLDS and compares counts and poses with what the TIMED loop delivered for the same scans (`parity_check`; a violation
 exits non-zero).  `roofline` describes lk_residual_kernel with counter-derived bounds (profiles/latest_pmc.json, made
-by tools/gpu_pmc_r02.sh from rocprofv3 --pmc passes of this very command): HBM fraction from FETCH_SIZE/WRITE_SIZE,
+by tools/gpu_prof_r02.sh + tools/collect_r02.py from rocprofv3 --pmc passes of this very command): HBM fraction from FETCH_SIZE/WRITE_SIZE,
 L2 fraction from TCC_REQ, VALU-issue fraction from SQ_INSTS_VALU, launch time from the timed region.
 `cpu_baseline` = the oracle (kind "port") on one pinned host thread, plus the reference's own build (oracle/_ref,
 literal N x N update) timed on the config-1 scans for the record.
@@ -197,16 +197,18 @@ def main():
     jobs += [("dense", (t_after + 0.1 * k, N_BUCKETS, 8008 + k, 8108 + k)) for k in range(ns)]
     jobs += [("dense", (t_after + 0.1 * (ns + k), 51, 8208 + k, 8308 + k)) for k in range(n51)]
     jobs += [("vlp", (t_after + 0.1 * k, 7007 + k)) for k in range(U1)]
-    cache = os.path.join(args.cache_dir, f"lkbench_r{rank}_{world_size}_{S}_{U}_{args.map_warm}_{ns}_{U1}.npy") if args.cache_dir else ""
-    if cache and os.path.exists(cache):
-        gen = list(np.load(cache, allow_pickle=True))
+    # optional per-job cache (profiling passes of one session re-run this command many times)
+    def cpath(j):
+        return os.path.join(args.cache_dir, "lk_" + j[0] + "_" + "_".join(repr(v) for v in j[1]) + ".npy")
+
+    if args.cache_dir:
+        os.makedirs(args.cache_dir, exist_ok=True)
+        missing = [j for j in jobs if not os.path.exists(cpath(j))]
+        for j, arr in zip(missing, generate(missing, workers)):
+            np.save(cpath(j), arr)
+        gen = [np.load(cpath(j)) for j in jobs]
     else:
         gen = generate(jobs, workers)
-        if cache:
-            os.makedirs(args.cache_dir, exist_ok=True)
-            arr = np.empty(len(gen), dtype=object)
-            arr[:] = gen
-            np.save(cache, arr, allow_pickle=True)
     it = iter(gen)
     scans = [next(it) for _ in range(n_batch_jobs)]
     first = warm = None
