@@ -270,6 +270,8 @@ def main():
             warnings.append(f"scatter_allgather map broadcast FAILED on this backend: {type(e).__name__}: {str(e)[:160]}")
     n_roots, n_nodes, n_blocks = g.map_stats()
     map_build_s = time.time() - t_map0
+    # the checker replays against EXACTLY this snapshot: exported now, before the stream extras (which insert) touch the map
+    map_blob_for_oracle = g.map_export() if (rank == 0 and world_size == 1 and args.cpu_sample > 0) else None
 
     # ---- resident batch
     host_batch = np.stack([np.ascontiguousarray(sc).view(np.uint8).reshape(-1) for sc in scans])      # U x 1.6 MB
@@ -469,7 +471,6 @@ def main():
             tl.append(time.perf_counter() - tc)
         extra["config1_live_stream_ms_per_scan"] = round(float(np.median(tl[1:])) * 1e3, 3)
         del d_c1, d_x1, d_P1
-    map_blob_for_oracle = g.map_export() if (rank == 0 and world_size == 1 and args.cpu_sample > 0) else None
     cpu_baseline = None
     parity = None
     if rank == 0 and ns >= 2:

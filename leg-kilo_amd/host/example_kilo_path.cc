@@ -53,6 +53,8 @@ int main(int argc, char** argv) {
     bool updated = kilo->predictUpdatePoint(0.01, 0, bucket.size(), bucket, bucket_world, n_success);
     Vec3D p = kilo->eskf().getPos();
     std::printf("updated=%d matched=%zu pos=(%.4f %.4f %.4f)\n", (int)updated, n_success, p[0], p[1], p[2]);
+    double x36[36];   // the bucket's posterior (slot 0 is re-used by the replay below)
+    kilo->eskf().state().to_x36(x36);
     // the same bucket twice more as a two-scan "recorded run", each from its own prior, against the (now frozen) map
     PointCloudType scan(bucket.begin(), bucket.end());
     for (size_t i = 0; i < scan.size(); ++i) scan[i].curvature = (i < scan.size() / 2) ? 0.f : 0.002f;   // two time buckets
@@ -69,8 +71,6 @@ int main(int argc, char** argv) {
                 const float xyz[3] = {q.x, q.y, q.z};
                 std::fwrite(xyz, sizeof(xyz), 1, f);
             }
-        double x36[36];
-        kilo->eskf().state().to_x36(x36);
         std::fwrite(x36, sizeof(x36), 1, f);
         std::fwrite(poses.data(), sizeof(lk_pose), poses.size(), f);
         std::fclose(f);

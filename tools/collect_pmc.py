@@ -16,6 +16,6 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*"))):
             a[0] += 1; a[1] += val; a[2] += dur
     for cn, (n, v, du) in acc.items():
         out[cn] = {"launches": n, "avg": v / n, "avg_dur_us_profiled": du / n / 1e3}
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_attrib.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.environ.get("LK_PROFILES_DIR", os.path.join(ROOT, "profiles")), f"{tag}_pmc_attrib.json"), "w"), indent=1)
 for k, v in out.items():
     print(f"{k:45s} {v['avg']:16.1f}   (n={v['launches']}, dur {v['avg_dur_us_profiled']:.1f} us)")

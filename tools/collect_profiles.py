@@ -20,7 +20,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 G = os.path.join(ROOT, "gpurun_out")
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("LK_PROFILES_DIR", os.path.join(ROOT, "profiles"))
 os.makedirs(P, exist_ok=True)
 
 

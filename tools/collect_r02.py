@@ -12,7 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02a"
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("LK_PROFILES_DIR", os.path.join(ROOT, "profiles"))
+os.makedirs(P, exist_ok=True)
 for tool in ("collect_profiles.py", "collect_pmc.py"):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), tag], check=False, stdout=subprocess.DEVNULL)
 res = json.load(open(os.path.join(P, f"{tag}_pmc_residual.json")))

@@ -27,6 +27,11 @@ for p in $PASSES; do
     tcc)   run pmc_${TAG}_3 "--steps 2 --warmup 0 --stream-scans 0" --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum ;;
   esac
 done
-find $OUT -name '*.csv' -size +20M -delete
-find $OUT -name '*.db' -size +40M -delete
+# condense ON the box (the rocpd databases are tens of MB each; gpurun_out/ merges back only below 64 MiB), keep the summaries
+export LK_PROFILES_DIR=$OUT/profiles_$TAG
+mkdir -p $LK_PROFILES_DIR
+python $REPO/tools/collect_r02.py $TAG > $OUT/collect_$TAG.log 2>&1
+tail -n 40 $OUT/collect_$TAG.log
+rm -rf $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_[0-9]
+find $OUT -name '*.log' -size +2M -delete
 du -sh $OUT 2>/dev/null
