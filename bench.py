@@ -623,28 +623,36 @@ def reference_literal(ob, cfg, P, traj, c1, blob, tcs_port):
 
         c1_scans, c1_tb = c1[0], c1[1]
         yml = os.path.join(tempfile.mkdtemp(prefix="lkref"), "ref.yaml")
-        ob.write_reference_yaml(yml, P, True)
-        r = ob.ReferenceKilo(P, True, yml)
         world = synth.World()
         t00 = c1_tb[0] - 0.1
         x0 = synth.initial_state(traj, t00, P)
-        r.set_state(x0, 1e-6 * np.eye(30))
-        r.init_process_cov_q()
-        r.set_acc_norm(9.81)
-        r.set_times(t00, t00)
         raw = synth.vlp16_scan(world, Frozen(traj, t00), t00, P)
         xb = xyz_of(raw)
-        r.map_build(world_of(x0, xb, P), xb)
-        ts, neff, nb = [], [], []
-        for k in range(len(c1_scans)):
-            r.set_state(synth.initial_state(traj, c1_tb[k], P), 1e-6 * np.eye(30))
-            r.set_times(c1_tb[k], c1_tb[k])
-            tc = time.perf_counter()
-            pose, _ = r.process_scan(c1_scans[k], c1_tb[k], with_sort=True)
-            ts.append(time.perf_counter() - tc)
-            neff.append(int(pose.n_effect))
-            nb.append(int(pose.n_buckets))
-        r.close()
+        res = {}
+        # the reference's own process() needs the scan's IMU packet (KILO.cc:326): the real config-1 mode, IMU updates between the
+        # buckets (only_imu_use); the port runs the identical call sequence beside it
+        for name, mk in (("reference", lambda: ob.ReferenceKilo(P, True, yml)), ("port", lambda: ob.Oracle(cfg, imu_mode_only=True))):
+            r = mk()
+            r.set_state(x0, 1e-6 * np.eye(30))
+            r.init_process_cov_q()
+            r.set_acc_norm(9.81)
+            r.set_times(t00, t00)
+            r.map_build(world_of(x0, xb, P), xb)
+            ts, neff = [], []
+            for k in range(len(c1_scans)):
+                imus = synth.imu_stream(traj, c1_tb[k], c1_tb[k] + 0.1, seed=3003 + k)
+                r.set_state(synth.initial_state(traj, c1_tb[k], P), 1e-6 * np.eye(30))
+                r.set_times(c1_tb[k], c1_tb[k])
+                tc = time.perf_counter()
+                pose, _ = r.process_scan(c1_scans[k], c1_tb[k], imus=imus, with_sort=True)
+                ts.append(time.perf_counter() - tc)
+                neff.append(int(pose.n_effect))
+            r.close()
+            res[name] = (ts, neff)
+        ts, neff = res["reference"]
+        if min(neff) <= 0:
+            out["why"] = "the reference build did not process the scans (n_effect = 0)"
+            return out
         # literal-form cost model: the N x N inverse dominates, ~ (2/3 + 2) N^3 flop for LU + solve against I; calibrate the
         # per-flop time on a dense N = 600 inverse with numpy (LAPACK, one thread is what Eigen's would be at best)
         Ncal = 600
@@ -659,7 +667,8 @@ def reference_literal(ob, cfg, P, traj, c1, blob, tcs_port):
             "available": True, "what": "oracle/_ref = the reference's KILO.cc/eskf.cc/voxel_map.cc compiled unmodified (mini-Eigen stand-in: "
                                        "naive dense kernels, so this is an upper bound on the reference's time, not its best)",
             "config1_scans_per_s": round(1.0 / float(np.median(ts)), 2), "config1_scans": len(ts), "config1_mean_n_effect": float(np.mean(neff)),
-            "config1_buckets_per_scan": float(np.mean(nb)),
+            "config1_port_same_calls_scans_per_s": round(1.0 / float(np.median(res["port"][0])), 2),
+            "config1_counts_equal_reference_vs_port": bool(neff == res["port"][1]),
             "literal_100k_extrapolated_s_per_scan": round(lit_s, 1),
             "literal_100k_extrapolation": f"5 buckets x 2 N^3 flop at N = {int(Nb)} matched rows, {per_flop * 1e12:.2f} ps/flop from a LAPACK "
                                           f"{Ncal} x {Ncal} inverse on this host; memory N^2 x 8 B = {Nb * Nb * 8 / 1e9:.1f} GB per bucket",

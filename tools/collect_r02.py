@@ -39,7 +39,8 @@ out = {
     "profiled_dur_us": att["SQ_INSTS_VALU"]["avg_dur_us_profiled"],
 }
 if out["gui_active_cycles"]:
-    out["clock_GHz_under_profiler"] = out["gui_active_cycles"] / (out["profiled_dur_us"] * 1e3)
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    out["clock_GHz_under_profiler"] = out["gui_active_cycles"] / 8.0 / (out["profiled_dur_us"] * 1e3)
 json.dump(out, open(os.path.join(P, "latest_pmc.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
