@@ -328,6 +328,13 @@ int lk_batch_replay_ragged_imu_dev(lk_handle* h, const lk_point* d_pts, size_t n
                                    const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
                                    const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out);
 
+/* Leg-fusion mode (only_imu_use: false): the same with each scan's kinematic + IMU messages (common::KinImuMeas): every message
+ * stamped before a bucket's time is applied (predictUpdateKinImu, KILO.cc:260-314; updateByKinImu, eskf.cc:137-145) before
+ * that bucket, as the loop at KILO.cc:384-390 does.  Same <= 512 points-per-bucket requirement. */
+int lk_batch_replay_ragged_kin_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                                   const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                                   const double* t_begin, const uint32_t* n_kin, const lk_kin_imu* kins, lk_pose* out);
+
 /* ---- measurement hooks ---- */
 int lk_profile_enable(lk_handle* h, int on);                           /* HIP-event timing around each kernel */
 int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms);

@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -330,7 +330,7 @@ class LegKiloHip:
                                                    C.c_void_p(host_out_ptr) if host_out_ptr else None))
 
     @staticmethod
-    def ragged_tables(scan_off, bucket_offs, bucket_dts, t_begins, imus=None):
+    def ragged_tables(scan_off, bucket_offs, bucket_dts, t_begins, imus=None, kins=None):
         """Flatten per-scan bucket tables into the arrays lk_batch_replay_ragged_dev takes (do this once per recorded run,
         not per replay): scan s = points [scan_off[s], scan_off[s+1]) with bucket bounds bucket_offs[s] (n_b + 1 offsets
         relative to the scan), time offsets bucket_dts[s] (n_b) and start time t_begins[s]."""
@@ -347,6 +347,11 @@ class LegKiloHip:
             tab["n_imu"] = np.fromiter((len(m) for m in imus), dtype=np.uint32, count=n_scans)
             tab["imus"] = np.ascontiguousarray(np.concatenate([np.asarray(m) for m in imus])) if tab["n_imu"].sum() else np.zeros(0, dtype=np.float64)
             assert tab["imus"].nbytes == 56 * int(tab["n_imu"].sum())
+        if kins is not None:   # per-scan lk_kin_imu arrays (leg-fusion mode, KILO.cc:384-390)
+            assert len(kins) == n_scans and imus is None
+            tab["n_kin"] = np.fromiter((len(m) for m in kins), dtype=np.uint32, count=n_scans)
+            tab["kins"] = np.ascontiguousarray(np.concatenate([np.asarray(m) for m in kins])) if tab["n_kin"].sum() else np.zeros(0, dtype=np.float64)
+            assert tab["kins"].nbytes == 264 * int(tab["n_kin"].sum())
         return tab
 
     def batch_replay_ragged_dev(self, d_pts, tables, want_poses=True):
@@ -354,7 +359,11 @@ class LegKiloHip:
         t = tables
         n_scans = t["n_scans"]
         poses = (abi.lk_pose * n_scans)() if want_poses else None
-        if "n_imu" in t:
+        if "n_kin" in t:
+            self._chk(self.L.lk_batch_replay_ragged_kin_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(t["scan_off"]),
+                                                            _p(t["n_buckets"]), _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]),
+                                                            _p(t["n_kin"]), _p(t["kins"]), poses))
+        elif "n_imu" in t:
             self._chk(self.L.lk_batch_replay_ragged_imu_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(t["scan_off"]),
                                                             _p(t["n_buckets"]), _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]),
                                                             _p(t["n_imu"]), _p(t["imus"]), poses))
@@ -363,7 +372,7 @@ class LegKiloHip:
                                                         _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]), poses))
         return poses
 
-    def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None, imus=None):
+    def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None, imus=None, kins=None):
         """Convenience: host scans (lists of lk_point arrays, time-sorted) -> HBM, buckets = runs of equal curvature
         (KILO.cc:375-378), optional priors, ragged replay.  Returns the poses."""
         from . import synth
@@ -376,7 +385,7 @@ class LegKiloHip:
         d = self.device_malloc(allpts.nbytes)
         try:
             self.h2d(d, allpts)
-            return self.batch_replay_ragged_dev(d, self.ragged_tables(scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins, imus))
+            return self.batch_replay_ragged_dev(d, self.ragged_tables(scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins, imus, kins))
         finally:
             self.device_free(d)
 

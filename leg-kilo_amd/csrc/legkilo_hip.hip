@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(LK_FB)
 // has <= LK_SCAN_WAVE_MAX points, so both paths give the same bits.
 #define LK_SCAN_WAVE_MAX 512
 __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& pr, LkFilter* filters, const lk_point* __restrict__ pts,
-                                              const LkRagged& rg, const double* __restrict__ Q, WaveSmem& sm, double* rows, const bool WITH_IMU) {
+                                              const LkRagged& rg, const double* __restrict__ Q, WaveSmem& sm, double* rows, const int MSG) {
+    const bool WITH_IMU = MSG != 0;   // 1: lk_imu messages (only_imu_use), 2: lk_kin_imu messages (leg fusion, KILO.cc:384-390)
     const int slot = blockIdx.x, lane = threadIdx.x;
     LkFilter* f = &filters[slot];
     const int nbk = (int)rg.nb[slot];
@@ -514,14 +515,18 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
     for (int b = 0; b < nbk;) {
         // next event of the scan: an IMU message stamped before the bucket's time (KILO.cc:379-383), else the bucket
         const double tb_ = T[b];
-        const bool is_imu = WITH_IMU && qi < qn && rg.imu[7 * (size_t)qi] < tb_;
-        const double t = is_imu ? rg.imu[7 * (size_t)qi] : tb_;
+        const size_t mstride = MSG == 2 ? 33 : 7;
+        const bool is_imu = WITH_IMU && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
+        const double t = is_imu ? rg.imu[mstride * (size_t)qi] : tb_;
         wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane);   // KILO.cc:111-115 / :240-244
         t_pred = t;
-        if (is_imu) {   // predictUpdateImu, KILO.cc:235-258
-            const double* m = rg.imu + 7 * (size_t)qi;
-            wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
-            t_upd = t;  // KILO.cc:256
+        if (is_imu) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
+            const double* m = rg.imu + mstride * (size_t)qi;
+            if (MSG == 2)
+                wave_kin_update_core(sm, rows, m, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
+            else
+                wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
+            t_upd = t;  // KILO.cc:256 / :312
             ++qi;
             continue;
         }
@@ -566,14 +571,21 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
                         const double* __restrict__ Q) {
     __shared__ WaveSmem sm;
     __shared__ double rows[64 * LK_ROW2];
-    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, false);
+    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, 0);
 }
 __global__ void __launch_bounds__(LK_WAVE, 2)
     lk_scan_wave_imu_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
                             const double* __restrict__ Q) {
     __shared__ WaveSmem sm;
     __shared__ double rows[64 * LK_ROW2];
-    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, true);
+    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, 1);
+}
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_scan_wave_kin_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
+                            const double* __restrict__ Q) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, 2);
 }
 
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
@@ -1518,7 +1530,7 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
 // a ragged batch of equally shaped scans gives the same bits.  Synchronous; priors as for lk_batch_replay_dev.
 static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
                          const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
-                         const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out) {
+                         const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out) {
     CHECK_H(h);
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
@@ -1546,14 +1558,14 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     }
     // every check comes before the first memset / upload / launch: a refused call leaves the filter slots untouched
     if (n_imu && biggest_bucket > (uint32_t)LK_SCAN_WAVE_MAX)
-        return fail(h, LK_ERR_INVALID, "IMU messages between buckets are only replayed for scans whose buckets hold <= 512 points");
+        return fail(h, LK_ERR_INVALID, "IMU / kinematic messages between buckets are only replayed for scans whose buckets hold <= 512 points");
     // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32, staged in pinned host memory
     size_t n_imu_total = 0;
     if (n_imu)
         for (size_t s = 0; s < S; ++s) n_imu_total += n_imu[s];
-    if (n_imu_total && !imus) return fail(h, LK_ERR_INVALID, "null IMU array");
+    if (n_imu_total && !imus) return fail(h, LK_ERR_INVALID, "null message array");
     // ... | imu [n][7] f64 | nb [S] u32 | imu_off [S+1] u32
-    const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_im = o_tb + 8 * S, o_nb = o_im + 56 * n_imu_total,
+    const size_t o_po = 0, o_t = o_po + 8 * S * (ldb + 1), o_tb = o_t + 8 * S * ldb, o_im = o_tb + 8 * S, o_nb = o_im + msg_bytes * n_imu_total,
                  o_io = o_nb + 4 * S, bytes = o_io + 4 * (S + 1);
     if (bytes > h->rag_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1594,7 +1606,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
         row_o += nbs + 1, row_t += nbs;
     }
     if (n_imu) {
-        if (n_imu_total) memcpy(stage + o_im, imus, 56 * n_imu_total);
+        if (n_imu_total) memcpy(stage + o_im, imus, msg_bytes * n_imu_total);
         auto* hio = reinterpret_cast<unsigned int*>(stage + o_io);
         hio[0] = 0;
         for (size_t s = 0; s < S; ++s) hio[s + 1] = hio[s] + n_imu[s];
@@ -1608,6 +1620,8 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     rg.ldb = (int)ldb;
     rg.imu_off = n_imu ? reinterpret_cast<const unsigned int*>(dr + o_io) : nullptr;
     rg.imu = reinterpret_cast<const double*>(dr + o_im);
+    rg.msg_stride = (int)(msg_bytes / sizeof(double));
+    rg.kin_noise = h->cfg.kin_meas_noise;
     rg.acc_scale = h->cfg.gravity / h->acc_norm;
     imu_noise(h->cfg, rg.Rn);
     int rc = zero_scan_counters(h, 0, (uint32_t)S);
@@ -1618,7 +1632,9 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     const int biggest = (int)biggest_bucket;
     if (biggest <= LK_SCAN_WAVE_MAX && (n_imu || !getenv("LEGKILO_RAGGED_LEVELS"))) {
         // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
-        if (n_imu)
+        if (n_imu && msg_bytes == sizeof(lk_kin_imu))
+            hipLaunchKernelGGL(lk_scan_wave_kin_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+        else if (n_imu)
             hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
         else
             hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
@@ -1646,7 +1662,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
 int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
                                const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
                                const double* t_begin, lk_pose* out) {
-    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, nullptr, nullptr, out);
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, nullptr, nullptr, sizeof(lk_imu), out);
 }
 // The same with each scan's IMU messages (only_imu_use mode, KILO.cc:379-383): n_imu[s] messages of scan s, concatenated in
 // `imus`, time-sorted per scan; a message stamped before a bucket's time is applied before that bucket, the rest of the
@@ -1656,7 +1672,18 @@ int lk_batch_replay_ragged_imu_dev(lk_handle* h, const lk_point* d_pts, size_t n
                                    const double* t_begin, const uint32_t* n_imu, const lk_imu* imus, lk_pose* out) {
     CHECK_H(h);
     if (!n_imu) return fail(h, LK_ERR_INVALID, "null argument");
-    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, n_imu, imus, out);
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, n_imu, imus, sizeof(lk_imu), out);
+}
+// Leg-fusion mode (only_imu_use: false, the reference's default): n_kin[s] kinematic + IMU messages of scan s, concatenated in
+// `kins`, time-sorted per scan; a message stamped before a bucket's time is applied (predictUpdateKinImu, KILO.cc:260-314:
+// two predicts, 6 IMU rows + 3 rows per foot in contact, updateByKinImu eskf.cc:137-145) before that bucket, as the loop at
+// KILO.cc:384-390 does.  Same bucket-size limit as the IMU entry.
+int lk_batch_replay_ragged_kin_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+                                   const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
+                                   const double* t_begin, const uint32_t* n_kin, const lk_kin_imu* kins, lk_pose* out) {
+    CHECK_H(h);
+    if (!n_kin) return fail(h, LK_ERR_INVALID, "null argument");
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, n_kin, kins, sizeof(lk_kin_imu), out);
 }
 
 // Asynchronous, double-buffered batch replay.  The batch uses filter slots [first_slot, first_slot + n_scans); calls whose

@@ -126,8 +126,10 @@ struct LkRagged {
     const double* t;                   // [S][ldb]: absolute time of bucket b of scan s (t_begin + curvature, KILO.cc:376)
     const unsigned int* nb;            // [S]: number of buckets of scan s
     int ldb;                           // row pitch of t; pt_off rows have ldb + 1 entries
-    const unsigned int* imu_off;       // optional [S + 1]: IMU messages of scan s = imu[imu_off[s] .. imu_off[s+1]), time-sorted
-    const double* imu;                 // [n][7]: stamp, acc(3), gyr(3)   (= lk_imu)
+    const unsigned int* imu_off;       // optional [S + 1]: messages of scan s = imu[imu_off[s] .. imu_off[s+1]), time-sorted
+    const double* imu;                 // [n][msg_stride]: lk_imu (7 doubles: stamp, acc, gyr) or lk_kin_imu (33 doubles, stamp first)
+    int msg_stride;                    // 7 (only_imu_use) or 33 (leg fusion: kinematic + IMU messages)
+    double kin_noise;                  // kin_meas_noise (KILO.cc:305)
     double acc_scale;                  // gravity / acc_norm (KILO.cc:246)
     double Rn[6];                      // IMU measurement noise: acc, acc, acc_z, gyr, gyr, gyr
 };

@@ -548,6 +548,200 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
     __syncthreads();
 }
 
+// updateByKinImu (eskf.cc:137-145) with the rows of predictUpdateKinImu (KILO.cc:267-309) on LDS-resident, already propagated
+// state, as ONE WAVE: the leg-fusion counterpart of wave_imu_update_core for the scan-resident replay kernel.  M = 6 + 3 c rows
+// (c = feet in contact, <= 18).  H is never stored: rows 0..5 select (ba + imu_a) and (bw + imu_w); a contact's three rows are
+// [ -R [w x p + v]x | 0 | I | ... | -R [p]x ] at columns 0..2 / 6..8 / 21..23, so H v for any column v is seven products.  P H^T
+// (30 x M) goes to the wave's scratch (the residual rows' LDS region, idle during a message update); the augmented system
+// [S | H P | z] is held one COLUMN per lane (lanes 0..17 S, 18..47 H P, 48 z) and swept by Gauss-Jordan with partial pivoting;
+// the pivot column is published through LDS so that the M row factors are computed by M lanes at once (one fp64 divide per
+// lane and step instead of M).  Every sum runs over the non-zero terms of the dense products of lk_kin_kernel /
+// dev_dense_update in the same order (zero terms cannot change a finite sum), divisions are the same divisions: the two
+// kernels agree to the last bit on finite data.  msg = one lk_kin_imu (33 doubles); Rn6 / kin_noise are wave-uniform.
+struct KinScratch {
+    double pht[30 * 18];
+    double hb[4][18];    // per contact index: b0 = -R [w x p + v]x (9), b21 = -R [p]x (9), row-major
+    double z[18], rd[18], fac[18], colk[18];
+};
+static_assert(sizeof(KinScratch) <= 64 * 15 * sizeof(double), "KinScratch must fit the residual rows' LDS region");
+
+__device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scratch, const double* __restrict__ msg, double acc_scale,
+                                                     const double* Rn6, double kin_noise, int lane) {
+    KinScratch& ks = *reinterpret_cast<KinScratch*>(scratch);
+    const double* x = sm.x;
+    const int* contact = reinterpret_cast<const int*>(msg + 25);
+    int cmask = 0;
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) cmask |= (contact[leg] != 0) ? (1 << leg) : 0;
+    const int M = 6 + 3 * __popc(cmask);
+    if (lane < 6) {   // IMU rows, KILO.cc:281-286
+        const int i = lane < 3 ? lane : lane - 3;
+        ks.z[lane] = lane < 3 ? acc_scale * msg[27 + i] - x[24 + i] - x[15 + i] : msg[30 + i] - x[27 + i] - x[18 + i];
+        ks.rd[lane] = Rn6[lane];
+    }
+    if (lane < 4 && ((cmask >> lane) & 1)) {   // one lane per foot in contact, KILO.cc:290-309
+        const int leg = lane, idx = __popc(cmask & ((1 << leg) - 1)), r0 = 6 + 3 * idx;
+        double Wk[9], mRot[9], K1[9], K2[9], b0[9], b21[9];
+        skew3(V3{x[27], x[28], x[29]}, Wk);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) mRot[i] = -x[i];
+        const V3 fp = V3{msg[1 + 3 * leg], msg[2 + 3 * leg], msg[3 + 3 * leg]};
+        const V3 fv = V3{msg[13 + 3 * leg], msg[14 + 3 * leg], msg[15 + 3 * leg]};
+        const V3 wp = mat3_mul_v(Wk, fp);
+        const V3 wpv = V3{wp.x + fv.x, wp.y + fv.y, wp.z + fv.z};
+        skew3(wpv, K1);
+        skew3(fp, K2);
+        mat3_mul(mRot, K1, b0);
+        mat3_mul(mRot, K2, b21);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ks.hb[idx][i] = b0[i], ks.hb[idx][9 + i] = b21[i];
+        const V3 Rw = mat3_mul_v(x, wpv);
+        ks.z[r0 + 0] = -x[12] - Rw.x, ks.z[r0 + 1] = -x[13] - Rw.y, ks.z[r0 + 2] = -x[14] - Rw.z;
+        ks.rd[r0 + 0] = kin_noise, ks.rd[r0 + 1] = kin_noise, ks.rd[r0 + 2] = kin_noise;
+    }
+    __syncthreads();
+    // -- P H^T, entry (i, m): dot of row i of P with row m of H over H's non-zero columns, ascending
+    for (int e = lane; e < 30 * 18; e += LK_WAVE) {
+        const int i = e / 18, m = e % 18;
+        if (m >= M) continue;
+        const double* Pi = &sm.P[i * 30];
+        double s;
+        if (m < 6) {
+            s = Pi[9 + m];
+            s += Pi[18 + m];
+        } else {
+            const int k = (m - 6) / 3, r = (m - 6) % 3;
+            const double* b0 = &ks.hb[k][3 * r];
+            const double* b21 = &ks.hb[k][9 + 3 * r];
+            s = Pi[0] * b0[0];
+            s += Pi[1] * b0[1];
+            s += Pi[2] * b0[2];
+            s += Pi[6 + r];
+            s += Pi[21] * b21[0];
+            s += Pi[22] * b21[1];
+            s += Pi[23] * b21[2];
+        }
+        ks.pht[i * 18 + m] = s;
+    }
+    __syncthreads();
+    // -- this lane's column of [S | H P | z]
+    double col[18];
+    {
+        const bool isS = lane < 18, isG = lane >= 18 && lane < 48;
+        const int c = isS ? (lane < M ? lane : 0) : 0, j = isG ? lane - 18 : 0;
+        auto v = [&](int row) { return isS ? ks.pht[row * 18 + c] : sm.P[row * 30 + j]; };
+        const double v0 = v(0), v1 = v(1), v2 = v(2), v6 = v(6), v7 = v(7), v8 = v(8), v21 = v(21), v22 = v(22), v23 = v(23);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double s = v(9 + a);
+            s += v(18 + a);
+            if (isS && a == lane) s = s + ks.rd[a];
+            col[a] = lane == 48 ? ks.z[a] : s;
+        }
+#pragma unroll
+        for (int a = 6; a < 18; ++a) {
+            col[a] = 0.0;
+            if (a < M) {
+                const int k = (a - 6) / 3, r = (a - 6) % 3;
+                const double* b0 = &ks.hb[k][3 * r];
+                const double* b21 = &ks.hb[k][9 + 3 * r];
+                const double v6r = r == 0 ? v6 : (r == 1 ? v7 : v8);
+                double s = b0[0] * v0;
+                s += b0[1] * v1;
+                s += b0[2] * v2;
+                s += v6r;
+                s += b21[0] * v21;
+                s += b21[1] * v22;
+                s += b21[2] * v23;
+                if (isS && a == lane) s = s + ks.rd[a];
+                col[a] = lane == 48 ? ks.z[a] : s;
+            }
+        }
+        if ((isS && lane >= M) || lane > 48) {
+#pragma unroll
+            for (int a = 0; a < 18; ++a) col[a] = 0.0;
+        }
+    }
+    // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane, row factors through LDS
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        if (k < M) {
+            if (lane == k) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) ks.colk[i] = col[i];
+            }
+            __syncthreads();
+            int p = k;
+            double best = fabs(ks.colk[k]);
+#pragma unroll
+            for (int i = k + 1; i < 18; ++i) {
+                if (i < M) {
+                    const double vv = fabs(ks.colk[i]);
+                    if (vv > best) best = vv, p = i;
+                }
+            }
+#pragma unroll
+            for (int i = k + 1; i < 18; ++i)
+                if (i == p) {
+                    const double tmp = col[k];
+                    col[k] = col[i];
+                    col[i] = tmp;
+                }
+            if (lane < M) {   // row `lane` after the swap: rows k and p of the published column trade places
+                const int src = lane == k ? p : (lane == p ? k : lane);
+                ks.fac[lane] = lane == k ? 0.0 : ks.colk[src] / ks.colk[p];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                if (i != k && i < M) col[i] -= ks.fac[i] * col[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i)
+        if (i < M) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);   // X = G / diag(S)
+    // -- dx = P H^T X[:,30]
+    double dxv = 0.0;
+    {
+        const int i = lane < 30 ? lane : 29;
+#pragma unroll
+        for (int m = 0; m < 18; ++m) {
+            const double xm = __shfl(col[m], 48, LK_WAVE);
+            if (m < M) dxv += ks.pht[i * 18 + m] * xm;
+        }
+    }
+    // -- P -= P H^T X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...; an entry is read and written by one lane only
+    {
+        const int jc = lane % 30, i0 = lane < 60 ? 15 * (lane / 30) : 15;
+        double X[18];
+#pragma unroll
+        for (int m = 0; m < 18; ++m) X[m] = __shfl(col[m], 18 + jc, LK_WAVE);
+        if (lane < 60) {
+#pragma unroll 1
+            for (int r = 0; r < 15; ++r) {
+                const int i = i0 + r;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < 18; ++m)
+                    if (m < M) s += ks.pht[i * 18 + m] * X[m];
+                sm.P[i * 30 + jc] = sm.P[i * 30 + jc] - s;
+            }
+        }
+    }
+    __syncthreads();
+    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    if (lane == 0) {
+        double E[9], Rn[9];
+        exp3_1e5(d0, d1, d2, E);
+        mat3_mul(sm.x, E, Rn);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
+    }
+    if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+    __syncthreads();
+}
+
 // ESKF::predict(dt_cov, false, true) then predict(dt, true, false) (KILO.cc:111-115) on LDS-resident state.
 __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane) {
     if (lane == 0) {  // getFx, eskf.cc:72-81

@@ -165,6 +165,25 @@ def vlp16_scan(world, traj, t_begin, cfg, seed_noise=3003, n_az=1800, period=0.1
     return out
 
 
+def ouster_scan(world, traj, t_begin, cfg, seed_noise=3003, n_cols=1024, n_rings=64, vfov_deg=(-22.5, 22.5), period=0.1):
+    """Config 4: an OS1-64-like scan, 64 rings x 1024 azimuth columns = 65 536 rays over `period` s, column by
+    column (all rings of one azimuth share a time stamp), cast from the moving body.  Output: raw cloud as POINT_DTYPE with
+    curvature = the column's time offset in seconds (f32) and the same offsets as integer nanoseconds (the `t` field of the
+    Ouster PointCloud2 layout, lidar_processing.cc:54-80, time_scale 1e-9)."""
+    rings = np.deg2rad(np.linspace(vfov_deg[0], vfov_deg[1], n_rings))
+    az = np.arange(n_cols) * (2 * np.pi / n_cols)
+    A, E = np.meshgrid(az, rings, indexing="ij")
+    dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
+    t_ns = np.repeat((np.arange(n_cols) * (period * 1e9 / n_cols)).astype(np.uint32), n_rings)
+    t_off = t_ns.astype(np.float64) * 1e-9
+    rngn = np.random.default_rng(seed_noise)
+    xyz, ok = cast_scan(world, traj, t_begin, dirs, t_off, cfg["extrinsic_R"], cfg["extrinsic_T"], rngn)
+    out = np.zeros(int(ok.sum()), dtype=POINT_DTYPE)
+    out["x"], out["y"], out["z"] = xyz[ok, 0], xyz[ok, 1], xyz[ok, 2]
+    out["curvature"] = t_off[ok].astype(np.float32)
+    return out, t_ns[ok]
+
+
 def dense_scan(world, traj, t_begin, cfg, n=100_000, n_buckets=5, seed_scan=2002, seed_noise=3003, period=0.1,
                blind=1.5, layout="cell"):
     """Configs 2/3/5: n points ENTERING the path (post-downsample), random ray directions

@@ -59,14 +59,60 @@ def run(mode, n_scans, tmp):
     return out
 
 
+def run_config4(n_scans, tmp):
+    """Config 4 at its stated shape: diter.yaml AS IS (voxel grid 0.5 m, time_scale 1e-9, Ouster, leg fusion), an
+    OS1-64-like 64 x 1024 scan -> Ouster PointCloud2 payload -> decode -> voxel grid -> time sort, 500 Hz kinematic + IMU
+    messages, through the reference's own KILO::process.  Stored under the mode name "c4" in the layout of run()."""
+    import preprocess_oracle as po
+
+    mode = "c4"
+    sc = scenes.Scene(params=config.DITER, **CAPS)
+    P = sc.P
+    k = ob.ReferenceKilo(P, False, os.path.join(tmp, "c4.yaml"))
+    t0 = 3.0
+    x0 = scenes.init_filter(k, sc, t0)
+    raw_static, _ = synth.ouster_scan(sc.world, scenes.Frozen(sc.traj, t0), t0, P, seed_noise=3999)
+    xb = scenes.xyz_of(raw_static[::3])
+    xw = scenes.world_of(x0, xb, P)
+    k.map_build(xw, xb)
+    out = {f"{mode}_x0": x0, f"{mode}_t0": t0, f"{mode}_build_world": xw, f"{mode}_build_body": xb}
+    pts, aux, xs, ne, tbs = [], [], [], [], []
+    for s in range(n_scans):
+        tb = t0 + 0.1 * s
+        cloud, t_ns = synth.ouster_scan(sc.world, sc.traj, tb, P, seed_noise=4000 + s)
+        raw = np.zeros(len(cloud), dtype=po.OUSTER_DTYPE)
+        raw["x"], raw["y"], raw["z"], raw["t"] = cloud["x"], cloud["y"], cloud["z"], t_ns
+        dec, b, _ = po.decode_vec(raw, 2, P["time_scale"], P["filter_num"], P["blind"], header_stamp=tb)
+        ds = po.preprocess(dec, P["voxel_grid_resolution"])
+        a = synth.kin_stream(sc.traj, tb, tb + 0.1, P, seed=5000 + s)
+        pose, _ = k.process_scan(ds, b, kins=a)
+        assert pose.n_effect > 0, "the reference did not process the scan (its voxel grid re-merged the input?)"
+        x, _ = k.get_state()
+        pts.append(ds), aux.append(a), xs.append(x.copy()), ne.append(pose.n_effect), tbs.append(b)
+    _, Pc = k.get_state()
+    out.update({
+        f"{mode}_pts": np.concatenate(pts), f"{mode}_len": np.array([len(p) for p in pts]),
+        f"{mode}_aux": np.concatenate(aux), f"{mode}_aux_len": np.array([len(a) for a in aux]),
+        f"{mode}_tb": np.array(tbs), f"{mode}_x": np.array(xs),
+        f"{mode}_n_effect": np.array(ne, dtype=np.int64), f"{mode}_P": Pc, f"{mode}_times": np.array(k.get_times()),
+    })
+    k.close()
+    return out
+
+
 def main():
     assert ob.build_ref() is not None and os.path.exists("/root/reference"), "needs the reference tree"
     with tempfile.TemporaryDirectory() as tmp:
-        d = run("imu", 3, tmp)
-        d.update(run("kin", 2, tmp))
-    path = os.path.join(HERE, "ref_kilo_small.npz")
-    np.savez_compressed(path, **d)
-    print(path, os.path.getsize(path), "bytes; n_effect imu", d["imu_n_effect"], "kin", d["kin_n_effect"])
+        if "--config4-only" not in sys.argv:
+            d = run("imu", 3, tmp)
+            d.update(run("kin", 2, tmp))
+            path = os.path.join(HERE, "ref_kilo_small.npz")
+            np.savez_compressed(path, **d)
+            print(path, os.path.getsize(path), "bytes; n_effect imu", d["imu_n_effect"], "kin", d["kin_n_effect"])
+        c4 = run_config4(3, tmp)
+    path = os.path.join(HERE, "ref_kilo_config4.npz")
+    np.savez_compressed(path, **c4)
+    print(path, os.path.getsize(path), "bytes; n_effect", c4["c4_n_effect"])
 
 
 if __name__ == "__main__":

@@ -138,6 +138,7 @@ def synth_point_dtype():
 
 # ----------------------------------------------------------------------------- golden vectors made BY THE REFERENCE
 GR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kilo_small.npz")
+GR4 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kilo_config4.npz")
 
 
 def replay_ref_golden(obj, g, mode):
@@ -152,7 +153,7 @@ def replay_ref_golden(obj, g, mode):
     ao = np.r_[0, np.cumsum(g[f"{mode}_aux_len"])]
     for k in range(len(g[f"{mode}_len"])):
         pts, aux = g[f"{mode}_pts"][po[k]:po[k + 1]], g[f"{mode}_aux"][ao[k]:ao[k + 1]]
-        kw = dict(kins=aux) if mode == "kin" else dict(imus=aux)
+        kw = dict(imus=aux) if mode == "imu" else dict(kins=aux)
         pose, _ = obj.process_scan(pts, float(g[f"{mode}_tb"][k]), **kw)
         x, _ = obj.get_state()
         yield k, pose, x
@@ -161,9 +162,11 @@ def replay_ref_golden(obj, g, mode):
 def check_ref_golden(make, tol_state, tol_cov, ptol):
     from legkilo_amd import config
 
-    g = np.load(GR)
-    for mode in ("imu", "kin"):
-        sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3) if mode == "kin" else None, **CAPS)
+    for mode in ("imu", "kin", "c4"):
+        # "c4": config 4 at its stated shape - diter.yaml as is, Ouster 64 x 1024 scans, leg fusion (make_golden_ref.py: run_config4)
+        g = np.load(GR4 if mode == "c4" else GR)
+        params = {"imu": None, "kin": dict(config.DITER, voxel_grid_resolution=0.3), "c4": config.DITER}[mode]
+        sc = scenes.Scene(params=params, **CAPS)
         obj = make(sc, mode)
         for k, pose, x in replay_ref_golden(obj, g, mode):
             assert int(pose.n_effect) == int(g[f"{mode}_n_effect"][k]), (mode, k, pose.n_effect, g[f"{mode}_n_effect"][k])

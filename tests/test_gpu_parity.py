@@ -391,6 +391,92 @@ def test_sequence_kin_mode(scene, oracle_lib, hip_lib):
     o.close()
 
 
+def ouster_message(sc, tb, k):
+    """One OS1-64-like sensor message of the config-4 run: 64 x 1024 rays, Ouster PointCloud2 point layout, `t` in ns."""
+    import preprocess_oracle as po
+
+    pts, t_ns = synth.ouster_scan(sc.world, sc.traj, tb, sc.P, seed_noise=4000 + k)
+    raw = np.zeros(len(pts), dtype=po.OUSTER_DTYPE)
+    raw["x"], raw["y"], raw["z"], raw["t"] = pts["x"], pts["y"], pts["z"], t_ns
+    raw["intensity"] = 10.0
+    dt = po.OUSTER_DTYPE
+    layout = dict(point_step=dt.itemsize, off_x=dt.fields["x"][1], off_y=dt.fields["y"][1], off_z=dt.fields["z"][1],
+                  off_time=dt.fields["t"][1], lidar_type=2)
+    return raw, layout
+
+
+N_CONFIG4_SCANS = 100
+
+
+def test_config4_ouster_leg_fusion_run(oracle_lib, hip_lib, tmp_path):
+    """Config 4 at the shape SURVEY.md 8(d) states: diter.yaml, an Ouster-like 64 x 1024 scan every 0.1 s (`t` in ns, time_scale
+    1e-9, filter_num 3, voxel grid 0.5 m), 500 Hz kinematic + IMU messages with a trot contact pattern, only_imu_use: false, a
+    10 s segment (100 scans) of the 60 s figure-eight.  GPU chain = the product's own: lk_decode_scan -> lk_process_raw_scan
+    (voxel grid + time sort + bucket loop with predictUpdateKinImu between the buckets + map insert); CPU chain = decode oracle
+    -> preprocess oracle -> the oracle's KILO::process.  Every scan: decode bit-exact, identical bucket / update / match counts;
+    trajectory: ATE delta through the TUM files < 1e-6 m (north star: < 1 mm)."""
+    import preprocess_oracle as po
+    from legkilo_amd import tum
+
+    sc = scenes.Scene(params=config.DITER, **CAPS)
+    P = sc.P
+    assert P["time_scale"] == 1e-9 and P["lidar_type"] == 2 and not P["only_imu_use"] and P["voxel_grid_resolution"] == 0.5
+    o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=False)
+    g = hip_lib.LegKiloHip(sc.cfg())
+    t0 = 3.0
+    raw0, layout = ouster_message(sc, t0, 999)
+    first, _, _ = po.decode_vec(raw0, 2, P["time_scale"], P["filter_num"], P["blind"], header_stamp=t0)
+    # first frame from a static sensor: both sides build the map from the same decoded cloud (BuildVoxelMap, KILO.cc:332-353)
+    raw_static, _ = synth.ouster_scan(sc.world, scenes.Frozen(sc.traj, t0), t0, P, seed_noise=3999)
+    xb = scenes.xyz_of(raw_static[::3])
+    for obj in (o, g):
+        x0 = scenes.init_filter(obj, sc, t0)
+        obj.map_build(scenes.world_of(x0, xb, P), xb)
+    stamps, rows_o, rows_g = [], [], []
+    n_msgs = 0
+    worst = 0.0
+    for k in range(N_CONFIG4_SCANS):
+        tb = t0 + 0.1 * k
+        raw, layout = ouster_message(sc, tb, k)
+        kins = synth.kin_stream(sc.traj, tb, tb + 0.1, P, seed=5000 + k)
+        n_msgs += len(kins)
+        dec_o, b_o, e_o = po.decode_vec(raw, 2, P["time_scale"], P["filter_num"], P["blind"], header_stamp=tb)
+        dec_g, b_g, e_g = g.decode_scan(raw.tobytes(), len(raw), layout, P["time_scale"], P["filter_num"], P["blind"], header_stamp=tb)
+        assert (b_o, e_o) == (b_g, e_g) and len(dec_o) == len(dec_g)
+        for f in dec_o.dtype.names:
+            assert np.array_equal(dec_o[f], dec_g[f]), (k, f)
+        ds = po.preprocess(dec_o, P["voxel_grid_resolution"])
+        pose_o, _ = o.process_scan(ds, b_o, kins=kins)
+        pose_g, nd = g.process_raw_scan(dec_g, P["voxel_grid_resolution"], b_g, kins=kins)
+        assert nd == len(ds), (k, nd, len(ds))
+        assert (pose_o.n_buckets, pose_o.n_updates, pose_o.n_effect) == (pose_g.n_buckets, pose_g.n_updates, pose_g.n_effect), \
+            (k, pose_o.n_buckets, pose_o.n_updates, pose_o.n_effect, pose_g.n_buckets, pose_g.n_updates, pose_g.n_effect)
+        assert pose_o.n_buckets > 300 and pose_o.n_effect > 500, (k, pose_o.n_buckets, pose_o.n_effect)
+        stamps.append(e_o)
+        rows_o.append((np.array(pose_o.rot), np.array(pose_o.pos)))
+        rows_g.append((np.array(pose_g.rot), np.array(pose_g.pos)))
+        worst = max(worst, float(np.abs(rows_o[-1][1] - rows_g[-1][1]).max()))
+    assert n_msgs == 50 * N_CONFIG4_SCANS
+    tum.write_tum(tmp_path / "cpu.txt", stamps, [r for r, _ in rows_o], [p_ for _, p_ in rows_o])
+    tum.write_tum(tmp_path / "gpu.txt", stamps, [r for r, _ in rows_g], [p_ for _, p_ in rows_g])
+    e, n = tum.ate_files(tmp_path / "cpu.txt", tmp_path / "gpu.txt")
+    assert n == N_CONFIG4_SCANS
+    ate_state = scenes.ate([p_ for _, p_ in rows_o], [p_ for _, p_ in rows_g])
+    truth = sc.traj.pos(np.array(stamps))
+    ate_truth_o = scenes.ate([p_ for _, p_ in rows_o], truth)
+    ate_truth_g = scenes.ate([p_ for _, p_ in rows_g], truth)
+    print(f"config 4: {N_CONFIG4_SCANS} scans, worst position delta {worst:.3e} m, ATE delta {ate_state:.3e} m (TUM files: {e:.3e}), "
+          f"ATE vs ground truth cpu {ate_truth_o:.4f} m / gpu {ate_truth_g:.4f} m")
+    assert ate_state < 1e-6 and e < 1e-6 + 2e-9, (ate_state, e)     # the files carry 9 decimals
+    assert abs(ate_truth_o - ate_truth_g) < 1e-6
+    (xo, _), (xg, _) = o.get_state(), g.get_state()
+    assert np.allclose(xo[:12], xg[:12], rtol=0, atol=1e-6), np.abs(xo[:12] - xg[:12]).max()
+    so, sg = scenes.canon_map(o.map_export()), scenes.canon_map(g.map_export())
+    assert set(so) == set(sg)
+    g.close()
+    o.close()
+
+
 # ----------------------------------------------------------------------------- 100k-point configs
 @pytest.fixture(scope="module")
 def big(scene, oracle_lib, hip_lib):
@@ -693,6 +779,72 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     with pytest.raises(hip_lib.LegKiloError):
         g.batch_replay_ragged_dev(d_pts, g.ragged_tables([0, 4000, 8000, 12001], [off] * 3, [dt] * 3, [0.0] * 3))
     g.device_free(d_pts)
+    g.close()
+    o.close()
+
+
+def test_batch_replay_ragged_leg_fusion(oracle_lib, hip_lib):
+    """Recorded-run replay in the reference's DEFAULT mode (only_imu_use: false, KILO.cc:384-390): every scan's 500 Hz kinematic +
+    IMU messages are applied between its time buckets (predictUpdateKinImu, KILO.cc:260-314; updateByKinImu, eskf.cc:137-145:
+    6 IMU rows + 3 rows per foot in contact, 6..18 rows) inside the one-wave-per-scan kernel (wave_kin_update_core).  diter.yaml
+    parameters.  Each scan equals the oracle's process_scan(..., kins=) on that scan alone: counts exact, x to 1e-8, P to 1e-6;
+    the message mix covers 0..4 contacts (M = 6..18)."""
+    sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3), **CAPS)
+    o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=False)
+    t0 = 2.0
+    x0 = scenes.init_filter(o, sc, t0)
+    scenes.first_frame(o, sc, t0, x0)
+    scenes.replay_vlp(o, sc, t0, 4, use_kin=True)
+    blob = o.map_export()
+    o.set_map_insert(False)
+    rng = np.random.default_rng(4242)
+    S = 6
+    scans, tbs, xs, Ps, kins = [], [], [], [], []
+    seen_m = set()
+    for s in range(S):
+        tb = t0 + 0.5 + 0.13 * s
+        scans.append(scenes.vlp_scan_input(sc, tb, 70 + s))
+        tbs.append(tb)
+        xs.append(synth.initial_state(sc.traj, tb, sc.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+        k = synth.kin_stream(sc.traj, tb, tb + 0.1, sc.P, seed=9100 + s)
+        if s == 1:
+            k["contact"][::3] = 1          # all four feet down on every third message (M = 18)
+        if s == 2:
+            k["contact"][::4] = 0          # flight phase: IMU rows only (M = 6)
+            k["contact"][1::4] = [1, 0, 0, 0]
+        seen_m |= set(int(6 + 3 * c.sum()) for c in (k["contact"] != 0))
+        kins.append(k)
+    assert seen_m >= {6, 9, 12, 18}, seen_m
+    g = hip_lib.LegKiloHip(sc.cfg(n_slots=S))
+    g.map_import(blob)
+    g.init_process_cov_q()
+    g.set_acc_norm(9.81)
+    o.set_acc_norm(9.81)
+    ps = g.batch_replay_ragged(scans, tbs, xs, Ps, kins=kins)
+    plain = None
+    for s in range(S):
+        o.set_state(xs[s], Ps[s])
+        o.set_times(tbs[s], tbs[s])
+        po, _ = o.process_scan(scans[s], tbs[s], kins=kins[s])
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (ps[s].n_buckets, ps[s].n_updates, ps[s].n_effect), s
+        assert po.n_buckets > 100 and po.n_effect > 500
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+        assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+        if s == 0:
+            plain = xg.copy()
+    # without the messages the outcome differs (they are really applied)
+    g.batch_replay_ragged(scans[:1], tbs[:1], xs[:1], Ps[:1])
+    assert not np.array_equal(g.get_state(slot=0)[0], plain)
+    # IMU and kinematic messages together are refused, and so are dense buckets with messages
+    with pytest.raises(AssertionError):
+        g.ragged_tables([0, len(scans[0])], [synth.buckets_of(scans[0])[0]], [synth.buckets_of(scans[0])[1]], [tbs[0]],
+                        imus=[synth.imu_stream(sc.traj, tbs[0], tbs[0] + 0.1)], kins=kins[:1])
+    dense = synth.dense_scan(sc.world, sc.traj, tbs[0], sc.P, n=4000, n_buckets=2, seed_scan=1)
+    with pytest.raises(hip_lib.LegKiloError, match="512"):
+        g.batch_replay_ragged([dense], tbs[:1], xs[:1], Ps[:1], kins=kins[:1])
     g.close()
     o.close()
 

@@ -135,6 +135,19 @@ def test_decode_oracle_matches_vectorised_host_version(scene):
     assert np.allclose(got["curvature"] * 500.0, np.round(got["curvature"] * 500.0), atol=1e-4)
 
 
+@pytest.mark.parametrize("lidar_type", [1, 2])
+def test_decode_vectorised_equals_the_loop(scene, lidar_type):
+    """po.decode_vec (array form, used for the 65 536-point Ouster scans of the config-4 run) == po.decode (the plain loop that is
+    pinned against the reference's handlers), field for field, incl. the begin / end stamps."""
+    raw, _, scale = raw_message(scene, 1.5, lidar_type)
+    raw = raw[:5000]
+    a, ab, ae = po.decode(raw, lidar_type, scale, 3, 1.5, header_stamp=7.0)
+    b, bb, be = po.decode_vec(raw, lidar_type, scale, 3, 1.5, header_stamp=7.0)
+    assert len(a) == len(b) > 800 and (ab, ae) == (bb, be)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("lidar_type", [1, 2, 3])
 def test_gpu_decode_bit_exact(scene, hip_lib, lidar_type):
