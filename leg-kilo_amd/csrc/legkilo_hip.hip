@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -56,6 +57,12 @@ struct lk_handle {
     void* h_rag = nullptr;
     size_t rag_cap = 0;
     double acc_norm = 1.0;
+    // frozen-map grid of batch replay (LkMap::grid): valid until the map changes
+    LkMap fmap;                // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
+    size_t grid_cap = 0;       // grid cells allocated behind the max_nodes match records of map.match
+    bool grid_valid = false;   // the grid describes the current map
+    bool grid_enable = true;   // LEGKILO_GRID=0 keeps batch replay on the hash table (A/B)
+    int* d_grid_mm = nullptr;
     // grow-only scratch of lk_preprocess_scan
     size_t pre_cap = 0, pre_tmp_bytes = 0;
     lk_point *pre_raw = nullptr, *pre_cells = nullptr, *pre_out = nullptr;
@@ -192,6 +199,8 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     if (const char* e = getenv("LEGKILO_UPDATE_CLASSIC")) h->wave_update = atoi(e) == 0;
+    if (const char* e = getenv("LEGKILO_GRID")) h->grid_enable = atoi(e) != 0;
+    HIPCHK(h, hipMalloc(&h->d_grid_mm, 6 * sizeof(int)));
     if (const char* e = getenv("LEGKILO_REPLAY_GROUPS")) h->replay_groups = std::min(std::max(atoi(e), 1), (int)lk_handle::kMaxGroups);
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -199,6 +208,10 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     LkParams& pr = h->pr;
     memcpy(pr.ext_R, cfg->ext_R, sizeof(pr.ext_R));
     memcpy(pr.ext_T, cfg->ext_T, sizeof(pr.ext_T));
+    {
+        static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        pr.ext_identity = memcmp(cfg->ext_R, I3, sizeof(I3)) == 0 ? 1 : 0;   // +0.0 only: -0.0 entries take the general path
+    }
     pr.voxel_size_d = cfg->max_voxel_size;
     pr.voxel_size_f = (float)cfg->max_voxel_size;
     pr.sigma_num = cfg->sigma_num;
@@ -269,7 +282,7 @@ void lk_destroy(lk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
-                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag};
+                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -592,6 +605,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
     const LkMap& m = h->map;
+    if (do_insert) h->grid_valid = false;   // the map changes: batch replay rebuilds its root grid
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
     if (n <= LK_SMALL_MAX) {
@@ -629,6 +643,74 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     return LK_OK;
 }
 
+// The map as the batch-replay kernels see it: with the dense root grid when it can be built (LkMap::grid).  The grid is derived
+// from the hash table + match records and rebuilt when the map has changed since (every mutating entry clears grid_valid);
+// building it is two small kernels + a memset, synchronised once - it happens per map snapshot, not per batch.
+static constexpr size_t kGridMaxCells = (size_t)1 << 24;   // 16 Mi cells x 144 B = 2.4 GB (record indices stay 32-bit byte offsets); larger boxes stay on the hash
+static int frozen_map(lk_handle* h, LkMap* out) {
+    *out = h->map;
+    out->grid_on = 0;
+    if (!h->grid_enable) return LK_OK;
+    if (!h->grid_valid) {
+        const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+        int mm[6];
+        HIPCHK(h, hipMemcpyAsync(h->d_grid_mm, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(lk_grid_bounds_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, h->map, h->hash_cap, h->d_grid_mm);
+        HIPCHK(h, hipMemcpyAsync(mm, h->d_grid_mm, sizeof(mm), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        LkMap fm = h->map;
+        fm.grid_on = 0;
+        if (mm[0] <= mm[3]) {
+            size_t dim[3], cells = 1;
+            bool ok = true;
+            for (int c = 0; c < 3; ++c) {
+                dim[c] = (size_t)((long long)mm[3 + c] - (long long)mm[c] + 1);
+                ok = ok && dim[c] <= kGridMaxCells;
+                cells = ok ? cells * dim[c] : cells;
+                ok = ok && cells <= kGridMaxCells;
+            }
+            if (ok && cells > h->grid_cap) {   // grow the match pool: [max_nodes node records | grid cells]
+                lk_match_rec* bigger = nullptr;
+                const size_t want = cells + cells / 4;
+                if (hipMalloc(&bigger, ((size_t)h->map.max_nodes + want) * sizeof(lk_match_rec)) != hipSuccess) {
+                    (void)hipGetLastError();   // no room for the grid: stay on the hash table
+                    ok = false;
+                } else {
+                    HIPCHK(h, hipMemcpyAsync(bigger, h->map.match, (size_t)h->map.max_nodes * sizeof(lk_match_rec), hipMemcpyDeviceToDevice, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    hipFree(h->map.match);
+                    h->map.match = bigger;
+                    h->grid_cap = want;
+                    fm.match = bigger;
+                }
+            }
+            if (ok) {
+                for (int c = 0; c < 3; ++c) fm.gmin[c] = mm[c], fm.gdim[c] = (int)dim[c];
+                fm.grid_base = h->map.max_nodes;
+                HIPCHK(h, hipMemsetAsync(fm.match + fm.grid_base, 0xff, cells * sizeof(lk_match_rec), h->stream));
+                hipLaunchKernelGGL(lk_grid_fill_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, fm, h->hash_cap);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipStreamSynchronize(h->stream));   // the side streams of the replay entries may read it at once
+                fm.grid_on = 1;
+            }
+        }
+        h->fmap = fm;
+        h->grid_valid = true;
+    }
+    *out = h->fmap;
+    return LK_OK;
+}
+
+// The residual kernel of the uniform batch entries, specialised at compile time for what is launch-uniform: root lookup through
+// the frozen-map grid, and ext_R == I (no 3 x 3 extrinsic products, and 18 fewer scalar registers in a kernel whose occupancy
+// is set by registers).  LEGKILO_XID=0 keeps the generic instantiation (A/B).
+using ResidualKernelFn = void (*)(LkMap, LkParams, const LkFilter*, const lk_point*, size_t, int, double*, size_t, ResidualOut, size_t);
+static ResidualKernelFn batch_residual_kernel(const lk_handle* h, const LkMap& fmap) {
+    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    if (!fmap.grid_on) return lk_residual_kernel<false, 0, false>;
+    return (h->pr.ext_identity && xid_enable) ? lk_residual_kernel<false, 1, true> : lk_residual_kernel<false, 1, false>;
+}
+
 static int zero_scan_counters(lk_handle* h, uint32_t first_slot, uint32_t n_slots) {
     // n_effect, n_updates, n_buckets, updated, last_N are contiguous (24 bytes)
     HIPCHK(h, hipMemset2DAsync(&h->d_filters[first_slot].n_effect, sizeof(LkFilter), 0, 24, n_slots, h->stream));
@@ -663,6 +745,7 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     unsigned int ctr[LK_CTR_COUNT];
     HIPCHK(h, hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost));
     if (ctr[LK_CTR_NODES] != 0) return fail(h, LK_ERR_STATE, "lk_map_build needs an empty map (BuildVoxelMap runs once)");
+    h->grid_valid = false;
     float *d_w = nullptr, *d_b = nullptr;
     lk_pt_rec* d_bpts = nullptr;
     unsigned int *d_k0 = nullptr, *d_k1 = nullptr;
@@ -699,6 +782,7 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     CHECK_H(h);
     if (n == 0) return LK_OK;
     if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n exceeds max_scan_points");
+    h->grid_valid = false;
     std::vector<lk_pt_rec> st(n);
     for (size_t i = 0; i < n; ++i) {
         for (int c = 0; c < 3; ++c) st[i].pw[c] = pw[3 * i + c];
@@ -757,6 +841,7 @@ int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, doub
 // clearMemOutOfMap (voxel_map.cc:571-594) as a pool compaction; see lk_map_kernels.h
 static int clear_outside(lk_handle* h, const LkSlideBox& box, uint32_t* n_removed) {
     if (n_removed) *n_removed = 0;
+    h->grid_valid = false;
     unsigned int ctr[LK_CTR_COUNT];
     HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -964,6 +1049,7 @@ __global__ void lk_validate_ids_kernel(LkMap map, unsigned int n_nodes, unsigned
 }
 
 static int reset_pools(lk_handle* h) {
+    h->grid_valid = false;
     unsigned int ninit = std::max(h->hash_cap, h->map.max_nodes);
     hipLaunchKernelGGL(lk_pool_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, h->stream, h->map, h->hash_cap);
     HIPCHK(h, hipGetLastError());
@@ -1437,8 +1523,12 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
     const int S = (int)n_scans;
-    int rc = zero_scan_counters(h, 0, (uint32_t)n_scans);
+    LkMap fmap;
+    int rc = frozen_map(h, &fmap);
     if (rc) return rc;
+    rc = zero_scan_counters(h, 0, (uint32_t)n_scans);
+    if (rc) return rc;
+    const auto res_kernel = batch_residual_kernel(h, fmap);
     hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, h->stream, h->d_filters, S, t_begin);
     HIPCHK(h, hipGetLastError());
     ResidualOut ro;
@@ -1482,7 +1572,7 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                     else
                         LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
                 }
-                LAUNCH(h, "residual", hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl,
+                LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, sn), dim3(LK_RB), 0, st, fmap, h->pr, fl,
                                                          pts, n_pts, nb, parts, h->part_stride, ro, (size_t)0));
                 if (h->wave_update)
                     LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts,
@@ -1497,7 +1587,7 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                     else
                         hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
                 }
-                hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, sn), dim3(LK_RB), 0, st, h->map, h->pr, fl, pts, n_pts, nb, parts,
+                hipLaunchKernelGGL(res_kernel, dim3(nblk, sn), dim3(LK_RB), 0, st, fmap, h->pr, fl, pts, n_pts, nb, parts,
                                    h->part_stride, ro, (size_t)0);
                 if (h->wave_update)
                     hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE),
@@ -1624,7 +1714,10 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     rg.kin_noise = h->cfg.kin_meas_noise;
     rg.acc_scale = h->cfg.gravity / h->acc_norm;
     imu_noise(h->cfg, rg.Rn);
-    int rc = zero_scan_counters(h, 0, (uint32_t)S);
+    LkMap fmap;
+    int rc = frozen_map(h, &fmap);
+    if (rc) return rc;
+    rc = zero_scan_counters(h, 0, (uint32_t)S);
     if (rc) return rc;
     hipStream_t st = h->stream;
     LkFilter* fl = h->d_filters;
@@ -1633,19 +1726,20 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     if (biggest <= LK_SCAN_WAVE_MAX && (n_imu || !getenv("LEGKILO_RAGGED_LEVELS"))) {
         // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
         if (n_imu && msg_bytes == sizeof(lk_kin_imu))
-            hipLaunchKernelGGL(lk_scan_wave_kin_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+            hipLaunchKernelGGL(lk_scan_wave_kin_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
         else if (n_imu)
-            hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+            hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
         else
-            hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, h->map, h->pr, fl, d_pts, rg, h->d_Q);
+            hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
         ldb = 0;
     } else {
         hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
     }
     for (size_t b = 0; b < ldb; ++b) {
         const int nblk = (max_n[b] + LK_RB - 1) / LK_RB;
-        hipLaunchKernelGGL(lk_residual_ragged_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts, rg, (int)b,
-                           h->d_partials, h->part_stride);
+        const auto rag_kernel = fmap.grid_on ? lk_residual_ragged_kernel<1> : lk_residual_ragged_kernel<0>;
+        hipLaunchKernelGGL(rag_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts, rg, (int)b, h->d_partials,
+                           h->part_stride);
         hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg,
                            (int)b);
     }
@@ -1703,6 +1797,11 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     for (size_t b = 0; b < n_buckets; ++b)   // all checks before the first enqueue
         if (bucket_off[b + 1] > bucket_off[b] && (size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan)
             return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+    LkMap fmap;
+    {
+        const int rc = frozen_map(h, &fmap);   // synchronises once per map snapshot (grid rebuild), otherwise free
+        if (rc) return rc;
+    }
     hipStream_t st = ((first_slot / (uint32_t)n_scans) & 1u) ? h->side[0] : h->stream;
     LkFilter* fl = h->d_filters + first_slot;
     double* parts = h->d_partials + (size_t)first_slot * h->part_stride;
@@ -1737,8 +1836,9 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
                 hipLaunchKernelGGL(lk_predict_kernel, dim3(S), dim3(LK_FB), 0, st, fl, h->d_Q, t);
         }
         first = false;
-        hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk, S), dim3(LK_RB), 0, st, h->map, h->pr, fl, d_pts + bucket_off[b], n_pts, nb,
-                           parts, h->part_stride, ro, (size_t)0);
+        const auto res_kernel = batch_residual_kernel(h, fmap);
+        hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts + bucket_off[b], n_pts, nb, parts,
+                           h->part_stride, ro, (size_t)0);
         if (h->wave_update)
             hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,
                                h->d_Q, t_next, has_next ? 3 : 1);

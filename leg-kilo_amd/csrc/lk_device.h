@@ -64,6 +64,7 @@ struct LkParams {                // immutable per handle, passed by value
     float planer_threshold;      // voxel_map.h:140
     int max_layer, max_points_num;
     int layer_init_num[5];
+    int ext_identity;            // ext_R is exactly the identity (leg_fusion.yaml / diter.yaml): ext_R v == v bit for bit, the two 3x3 products per point / candidate are skipped
 };
 
 // Compact, derived copy of a plane for the residual kernel (device-only, never exported): 144 B = 9 x 16-B
@@ -117,7 +118,17 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int* free_list;              // point blocks that may be re-allocated during this bucket
     int* freed_next;             // point blocks retired during this bucket (allocatable from the next bucket on)
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;
+    // Frozen-map acceleration structure of batch replay (frozen_map(), legkilo_hip.hip): the root voxels' match records in a
+    // DENSE 3-D array over the bounding box of the root keys, so that the per-point chain scan point -> hash slot -> record
+    // loses its middle trip (key -> cell index is arithmetic).  The cells live in the SAME array as the nodes' match records,
+    // behind them: cell c = match[grid_base + c] - one base address and 32-bit record indices for both, which is what keeps
+    // the matcher's addressing scalar-base + lane-offset.  cell.pad_ = node id, LK_GRID_EMPTY where no root exists.
+    // Derived data: rebuilt after any change of the map, never exported; grid_on = 0 selects the hash table.
+    unsigned int grid_base;
+    int gmin[3], gdim[3];
+    int grid_on;
 };
+#define LK_GRID_EMPTY 0xffffffffu
 
 // Device tables of a RAGGED batch (lk_batch_replay_ragged_dev): every scan has its own number of points, its own
 // time buckets and its own start time.  Passed by value.
@@ -305,10 +316,11 @@ struct PointLite {
     double alpha_n, beta;  // alpha / |pb|^2, beta
     float gz;              // 1e-4 when calcBodyCov's z == 0 guard fired (voxel_map.cc:23), else 0
 };
+template <bool XID = false>
 __device__ __forceinline__ PointLite point_lite(float bx, float by, float bz, const BucketConst& bc, const LkParams& pr) {
     PointLite g;
     V3 pb = V3{(double)bx, (double)by, (double)bz};
-    V3 e = mat3_mul_v(pr.ext_R, pb);
+    V3 e = XID ? pb : mat3_mul_v(pr.ext_R, pb);   // XID: ext_R is exactly I, and 1 * x + 0 * y + 0 * z == x bit for bit
     g.p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
     V3 w = mat3_mul_v(bc.R, g.p_i);
     g.p_w = V3{w.x + bc.p[0], w.y + bc.p[1], w.z + bc.p[2]};
@@ -324,10 +336,11 @@ struct PlaneTerms {  // per (point, candidate normal)
     V3 w;            // p_i x (R^T n)
     double ta;       // n^T (R ext_R) body_cov (R ext_R)^T n
 };
+template <bool XID = false>
 __device__ __forceinline__ PlaneTerms plane_terms(const PointLite& g, const BucketConst& bc, const LkParams& pr, V3 n) {
     PlaneTerms t;
     const V3 u = mat3T_mul_v(bc.R, n);
-    const V3 m = mat3T_mul_v(pr.ext_R, u);
+    const V3 m = XID ? u : mat3T_mul_v(pr.ext_R, u);
     // pb.m = pb^T ext_R^T u = (ext_R pb).u = (p_i - ext_T).u  (+ the guard's 1e-4 along ext_R's third column = 1e-4 m.z):
     // the body point itself need not stay in registers
     const double dm = dot3(g.p_i.x - pr.ext_T[0], u.x, g.p_i.y - pr.ext_T[1], u.y, g.p_i.z - pr.ext_T[2], u.z) + (double)g.gz * m.z;

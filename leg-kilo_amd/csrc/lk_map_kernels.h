@@ -1232,6 +1232,26 @@ __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned i
     if (i < LK_CTR_COUNT) map.counters[i] = 0;
 }
 
+// ---- frozen-map grid (LkMap::grid): bounding box of the root keys, then one cell per root
+__global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned int n_hash, int* __restrict__ mm /* min xyz, max xyz */) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hash) return;
+    const int4 e = map.hash[i];
+    if (e.w < 0) return;
+    atomicMin(&mm[0], e.x), atomicMin(&mm[1], e.y), atomicMin(&mm[2], e.z);
+    atomicMax(&mm[3], e.x), atomicMax(&mm[4], e.y), atomicMax(&mm[5], e.z);
+}
+__global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned int n_hash) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hash) return;
+    const int4 e = map.hash[i];
+    if (e.w < 0) return;
+    const size_t c = ((size_t)(e.z - map.gmin[2]) * (size_t)map.gdim[1] + (size_t)(e.y - map.gmin[1])) * (size_t)map.gdim[0] + (size_t)(e.x - map.gmin[0]);
+    lk_match_rec r = map.match[e.w];
+    r.pad_ = (unsigned int)e.w;
+    map.match[map.grid_base + c] = r;
+}
+
 // derive the compact match records of imported planes (lk_map_import / lk_map_import_dev)
 __global__ void __launch_bounds__(256) lk_derive_match_kernel(LkMap map, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;

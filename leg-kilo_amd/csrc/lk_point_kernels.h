@@ -16,6 +16,20 @@
 #include "lk_device.h"
 
 #define LK_PB 256
+// perf-attribution switches (tools/ab_env.sh builds with -DLK_X_...=1): each removes one piece of the residual pass so that its
+// marginal cost can be measured; results are wrong with any of them set, the product build sets none
+#ifndef LK_X_NORETRY
+#define LK_X_NORETRY 0
+#endif
+#ifndef LK_X_NOCHILD
+#define LK_X_NOCHILD 0
+#endif
+#ifndef LK_X_NOEVAL
+#define LK_X_NOEVAL 0
+#endif
+#ifndef LK_X_NORED
+#define LK_X_NORED 0
+#endif
 // The residual kernel runs ONE wave per workgroup: with no block barrier in it there is nothing to share, and the
 // scheduler can refill a SIMD slot the moment a wave retires instead of waiting for a 4-wave workgroup's worth of
 // slots and LDS (measured on the 1024-scan batch: 642 us per bucket at 256 threads, 582 at 128, 578 at 64).
@@ -33,6 +47,7 @@ struct Match {
 // voxel_map.cc:371-413 for one plane node.  q0..q2 / tail = the first 64 B of the node's match record (center,
 // normal, d, radius, flags), already in registers; the remaining 80 B (S11, w, s22) are requested BEFORE the float
 // range gate is evaluated so that the whole record costs one memory round trip.
+template <bool XID>
 __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, double2 q0, double2 q1, double2 q2,
                                            float pd, float pradius, int node, int layer, const PointLite& g,
                                            const BucketConst& bc, const LkParams& pr, bool& success, double& prob,
@@ -50,7 +65,7 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
     const S3 s11 = S3{v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
     // J plane_var J^T = q^T S11 q - 2 q.w + s22   (w = S12 n, s22 = n^T S22 n precomputed per plane)
     const double sig_pl = quad3(s11, q) - 2.0 * dot3(q.x, v3.x, q.y, v3.y, q.z, v4.x) + v4.y;
-    const PlaneTerms t = plane_terms(g, bc, pr, n);
+    const PlaneTerms t = plane_terms<XID>(g, bc, pr, n);
     const double sig_r = sig_pl + t.ta;
     const double sigma_l = sig_r + (quad3(bc.Prr, t.w) + quad3(bc.Ppp, n));
     // 3-sigma gate  |d| < sigma_num sqrt(sigma_l)  (voxel_map.cc:388) in squared form: both sides are >= 0, and a
@@ -86,27 +101,35 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
 // build_single_residual (voxel_map.cc:363-427): pre-order DFS, children in index order, written as ONE flat loop
 // (a single copy of the plane evaluation in the instruction stream; the <=5-deep path lives in scalar registers
 // selected with compares, so no dynamically indexed private array / scratch is needed).
-__device__ __forceinline__ void match_root(const LkMap& m, int root, const PointLite& g, const BucketConst& bc,
-                                           const LkParams& pr, bool& success, double& prob, Match& best) {
+// `root` indexes m.match[]: a node id (hash hit), or - grid_cell - a cell of the frozen-map grid, which may be empty and
+// otherwise carries its node id in pad_.  Returns whether a root voxel exists there (the lookup of KILO.cc:149 succeeded).
+template <bool XID>
+__device__ __forceinline__ bool match_root(const LkMap& m, int root, const bool grid_cell, const PointLite& g,
+                                           const BucketConst& bc, const LkParams& pr, bool& success, double& prob, Match& best) {
     const int max_layer = pr.max_layer;
     int n0 = root, n1 = -1, n2 = -1, n3 = -1, n4 = -1;
     unsigned int cis = 0;  // next child index of each level, 4 bits per level
     int level = 0;
     bool fresh = true;
     while (level >= 0) {
-        const int node = (level == 0) ? n0 : (level == 1) ? n1 : (level == 2) ? n2 : (level == 3) ? n3 : n4;
+        int node = (level == 0) ? n0 : (level == 1) ? n1 : (level == 2) ? n2 : (level == 3) ? n3 : n4;
         if (fresh) {
             const lk_match_rec* pl = &m.match[node];
             const double2* q = reinterpret_cast<const double2*>(pl);
             double2 q0 = q[0], q1 = q[1], q2 = q[2];
-            const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad
-            if (__float_as_uint(tail.z) & LK_PLANE_IS_PLANE) {
-                eval_plane(pl, q0, q1, q2, tail.x, tail.y, node, level, g, bc, pr, success, prob, best);
+            const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad (grid cells: node id)
+            if (grid_cell && level == 0) {
+                const unsigned int id = __float_as_uint(tail.w);
+                if (id == LK_GRID_EMPTY) return false;  // no root voxel at this key
+                n0 = node = (int)id;
+            }
+            if (!LK_X_NOEVAL && (__float_as_uint(tail.z) & LK_PLANE_IS_PLANE)) {
+                eval_plane<XID>(pl, q0, q1, q2, tail.x, tail.y, node, level, g, bc, pr, success, prob, best);
                 --level;
                 fresh = false;
                 continue;
             }
-            if (level >= max_layer || level >= LK_MAX_LAYER) {
+            if (LK_X_NOCHILD || level >= max_layer || level >= LK_MAX_LAYER) {
                 --level;
                 fresh = false;
                 continue;
@@ -135,6 +158,19 @@ __device__ __forceinline__ void match_root(const LkMap& m, int root, const Point
             fresh = false;
         }
     }
+    return true;
+}
+
+// Root voxel of a key for the matcher: index into m.match[] (a node id from the hash table, or a grid cell), -1 = none.
+// GRID: 0 = hash table (compile-time), 1 = frozen-map grid (compile-time), 2 = decided by m.grid_on at run time
+template <int GRID>
+__device__ __forceinline__ int find_root(const LkMap& m, int kx, int ky, int kz) {
+    if (GRID == 1 || (GRID == 2 && m.grid_on)) {
+        const unsigned int ux = (unsigned int)(kx - m.gmin[0]), uy = (unsigned int)(ky - m.gmin[1]), uz = (unsigned int)(kz - m.gmin[2]);
+        if (ux >= (unsigned int)m.gdim[0] || uy >= (unsigned int)m.gdim[1] || uz >= (unsigned int)m.gdim[2]) return -1;
+        return (int)(m.grid_base + (uz * (unsigned int)m.gdim[1] + uy) * (unsigned int)m.gdim[0] + ux);
+    }
+    return hash_find(m, kx, ky, kz);  // KILO.cc:149
 }
 
 // KILO.cc:156-172: key of the ONE neighbour voxel that is tried when the home voxel gave no match.  loc is in
@@ -177,7 +213,7 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 // doubles).  Returns, in lane (q, half) = (lane & 31, lane >> 5), component q of [A(21) b(6) sumR count] summed over the
 // tile's 64 rows (both halves hold the same value).  Shared by lk_residual_kernel (one tile per single-wave workgroup)
 // and lk_small_bucket_kernel (legkilo_hip.hip: a small bucket's tiles inside one workgroup).
-template <bool EMIT_ROWS>
+template <bool EMIT_ROWS, int GRID = 2, bool XID = false>
 __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams& pr, const BucketConst& bc,
                                                 const float4* __restrict__ spts, int i, int n, double* rows, int lane,
                                                 const ResidualOut& out, size_t out_base) {
@@ -188,7 +224,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         int root = -1, nroot = -1;
         if (i < n) {
             const float4 p = spts[i];
-            g = point_lite(p.x, p.y, p.z, bc, pr);
+            g = point_lite<XID>(p.x, p.y, p.z, bc, pr);
             if (out.world) {
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
                 reinterpret_cast<float4*>(out.world + out_base * 4)[i] = w;
@@ -196,23 +232,25 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             float loc[3];
             int key[3];
             key_trunc(g.p_w, pr, loc, key);
-            root = hash_find(map, key[0], key[1], key[2]);  // KILO.cc:149
+            root = find_root<GRID>(map, key[0], key[1], key[2]);  // KILO.cc:149
         }
         // K2: home voxel first (the root's 144-B record is fetched in one round trip inside match_root)
         bool success = false;
         double prob = 0;
         Match best;
         best.row = rows + lane * LK_ROW2;
-        if (root >= 0) match_root(map, root, g, bc, pr, success, prob, best);
-        // the one-neighbour retry (KILO.cc:156-178)
-        if (root >= 0 && !success) {
+        const bool grid_cell = GRID == 1 || (GRID == 2 && map.grid_on != 0);
+        bool home = false;
+        if (root >= 0) home = match_root<XID>(map, root, grid_cell, g, bc, pr, success, prob, best);
+        // the one-neighbour retry (KILO.cc:156-178): only when the home voxel EXISTS (the lookup at KILO.cc:149 found a tree)
+        if (home && !success && !LK_X_NORETRY) {
             float loc[3];     // re-derived here rather than kept alive across the home voxel's walk
             int key[3], near[3];
             key_trunc(g.p_w, pr, loc, key);
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
-            if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = hash_find(map, near[0], near[1], near[2]);
-            if (nroot >= 0) match_root(map, nroot, g, bc, pr, success, prob, best);
+            if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = find_root<GRID>(map, near[0], near[1], near[2]);
+            if (nroot >= 0) match_root<XID>(map, nroot, grid_cell, g, bc, pr, success, prob, best);
         }
         ok = success;
         if (ok) {  // KILO.cc:195-209: h (1x6), z, R for the matched point, from the parked row
@@ -250,6 +288,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (LK_X_NORED) return (lane == 28) ? (ok ? 1.0 : 0.0) : 0.0;
     const int q = lane & 31, half = lane >> 5;
     // component q = sum over rows of r[a] * r[b]:  A(i,j) = sum (h_i / R) h_j (upper triangle, row-major: q < 21,
     // a = 7 + i, b = j), b_i = sum (h_i / R) z (q = 21 + i: a = 7 + i, b = 6), sum R (q = 27: 13, 14), count (14, 14).
@@ -269,7 +308,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
 }
 
 // One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
-template <bool EMIT_ROWS>
+template <bool EMIT_ROWS, int GRID = 0, bool XID = false>
 __global__ void LK_RES_BOUNDS
     lk_residual_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                        size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
@@ -281,7 +320,7 @@ __global__ void LK_RES_BOUNDS
     const int lane = tid & 63, wv = tid >> 6;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
-    const double acc = residual_tile<EMIT_ROWS>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
+    const double acc = residual_tile<EMIT_ROWS, GRID, XID>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
                                                 blockIdx.x * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
     if (lane < LK_NPART) {
         const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
@@ -291,6 +330,7 @@ __global__ void LK_RES_BOUNDS
 
 // Ragged batch: bucket b of every scan that has one.  grid = (waves of the LARGEST bucket b, scans); a workgroup beyond
 // its scan's bucket leaves at once (two scalar loads).
+template <int GRID>
 __global__ void LK_RES_BOUNDS
     lk_residual_ragged_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                               LkRagged rg, int b, double* __restrict__ partials, size_t part_slot_stride) {
@@ -307,7 +347,7 @@ __global__ void LK_RES_BOUNDS
     load_bucket_const<false>(&filters[slot], pr, bc);
     ResidualOut out;
     out.h6 = nullptr, out.z = nullptr, out.R = nullptr, out.valid = nullptr, out.world = nullptr;
-    const double acc = residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), blockIdx.x * LK_RB + tid, n,
+    const double acc = residual_tile<false, GRID>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), blockIdx.x * LK_RB + tid, n,
                                             &stage[wv][0], lane, out, (size_t)0);
     if (lane < LK_NPART) {
         const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;

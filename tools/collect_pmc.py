@@ -11,7 +11,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*"))):
     c = sqlite3.connect(f).cursor()
     acc = {}
     for name, gy, cn, val, dur in c.execute("select kernel_name, grid_size_y, counter_name, value, duration from counters_collection"):
-        if "lk_residual_kernel<false>" in name and gy > 1:
+        if "lk_residual_kernel<false" in name and gy > 1:
             a = acc.setdefault(cn, [0, 0.0, 0.0])
             a[0] += 1; a[1] += val; a[2] += dur
     for cn, (n, v, du) in acc.items():

@@ -80,8 +80,8 @@ def pmc(path, counter, kernel_like):
 
 
 res = {"tag": tag, "kernel": "lk_residual_kernel<false>", "note": "FETCH_SIZE/WRITE_SIZE in KiB; gfx950 correction: FETCH doubled"}
-fetch = pmc(f"prof_{tag}_fetch", "FETCH_SIZE", "lk_residual_kernel<false>")
-write = pmc(f"prof_{tag}_write", "WRITE_SIZE", "lk_residual_kernel<false>")
+fetch = pmc(f"prof_{tag}_fetch", "FETCH_SIZE", "lk_residual_kernel<false")
+write = pmc(f"prof_{tag}_write", "WRITE_SIZE", "lk_residual_kernel<false")
 geo = {}
 for k in sorted(set(fetch) | set(write)):
     f_ = fetch.get(k, [])
@@ -104,7 +104,7 @@ try:
     sq = {}
     c = db(f"prof_{tag}_sq").cursor()
     for name, cn, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
-        if "lk_residual_kernel<false>" in name:
+        if "lk_residual_kernel<false" in name:
             sq.setdefault(cn, []).append(val)
     res["sq_avg_per_launch_all_geometries"] = {k: sum(v) / len(v) for k, v in sq.items()}
 except Exception as e:  # noqa: BLE001
