@@ -200,7 +200,7 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     }
     if (const char* e = getenv("LEGKILO_UPDATE_CLASSIC")) h->wave_update = atoi(e) == 0;
     if (const char* e = getenv("LEGKILO_GRID")) h->grid_enable = atoi(e) != 0;
-    HIPCHK(h, hipMalloc(&h->d_grid_mm, 6 * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->d_grid_mm, 8 * sizeof(int)));
     if (const char* e = getenv("LEGKILO_REPLAY_GROUPS")) h->replay_groups = std::min(std::max(atoi(e), 1), (int)lk_handle::kMaxGroups);
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -669,10 +669,10 @@ static int frozen_map(lk_handle* h, LkMap* out) {
                 cells = ok ? cells * dim[c] : cells;
                 ok = ok && cells <= kGridMaxCells;
             }
-            if (ok && cells > h->grid_cap) {   // grow the match pool: [max_nodes node records | grid cells]
+            if (ok && cells > h->grid_cap) {   // grow the match pool: [max_nodes node records | grid cells (+ slack) | flattened subtree lists]
                 lk_match_rec* bigger = nullptr;
                 const size_t want = cells + cells / 4;
-                if (hipMalloc(&bigger, ((size_t)h->map.max_nodes + want) * sizeof(lk_match_rec)) != hipSuccess) {
+                if (hipMalloc(&bigger, (2 * (size_t)h->map.max_nodes + want) * sizeof(lk_match_rec)) != hipSuccess) {
                     (void)hipGetLastError();   // no room for the grid: stay on the hash table
                     ok = false;
                 } else {
@@ -688,7 +688,12 @@ static int frozen_map(lk_handle* h, LkMap* out) {
                 for (int c = 0; c < 3; ++c) fm.gmin[c] = mm[c], fm.gdim[c] = (int)dim[c];
                 fm.grid_base = h->map.max_nodes;
                 HIPCHK(h, hipMemsetAsync(fm.match + fm.grid_base, 0xff, cells * sizeof(lk_match_rec), h->stream));
-                hipLaunchKernelGGL(lk_grid_fill_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, fm, h->hash_cap);
+                // the lists (every non-root node at most once) live behind the allocated cells
+                const unsigned int cand0 = (unsigned int)((size_t)h->map.max_nodes + h->grid_cap);
+                unsigned int* cursor = reinterpret_cast<unsigned int*>(h->d_grid_mm + 6);
+                HIPCHK(h, hipMemcpyAsync(cursor, &cand0, sizeof(cand0), hipMemcpyHostToDevice, h->stream));
+                hipLaunchKernelGGL(lk_grid_fill_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, fm, h->hash_cap, h->pr.max_layer,
+                                   cursor, cand0 + h->map.max_nodes);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipStreamSynchronize(h->stream));   // the side streams of the replay entries may read it at once
                 fm.grid_on = 1;

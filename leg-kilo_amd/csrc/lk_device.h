@@ -129,6 +129,11 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int grid_on;
 };
 #define LK_GRID_EMPTY 0xffffffffu
+// A grid cell of a root that is NOT a plane is a list header: flags carries LK_GRID_LIST, the first 8 bytes (center[0]) hold
+// {first, count}: the plane nodes of the root's subtree in the pre-order of build_single_residual (voxel_map.cc:415-421),
+// flattened into consecutive match records behind the grid (count == 0: nothing to evaluate).  The matcher of the frozen map
+// is then a counted loop over consecutive records - no child pointers, no walk state.
+#define LK_GRID_LIST 0x100u
 
 // Device tables of a RAGGED batch (lk_batch_replay_ragged_dev): every scan has its own number of points, its own
 // time buckets and its own start time.  Passed by value.

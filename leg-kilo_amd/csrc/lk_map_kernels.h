@@ -1241,7 +1241,11 @@ __global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned
     atomicMin(&mm[0], e.x), atomicMin(&mm[1], e.y), atomicMin(&mm[2], e.z);
     atomicMax(&mm[3], e.x), atomicMax(&mm[4], e.y), atomicMax(&mm[5], e.z);
 }
-__global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned int n_hash) {
+// One thread per root: a plane root's record goes into its cell; any other root gets a list header and its subtree's plane
+// nodes, in pre-order (children in index order, a plane is not descended into, nothing below max_layer), appended behind the
+// grid (`cursor` = next free record; the order of the lists among each other does not matter).
+__global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned int n_hash, int max_layer, unsigned int* __restrict__ cursor,
+                                                           unsigned int cand_end) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_hash) return;
     const int4 e = map.hash[i];
@@ -1249,6 +1253,56 @@ __global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned i
     const size_t c = ((size_t)(e.z - map.gmin[2]) * (size_t)map.gdim[1] + (size_t)(e.y - map.gmin[1])) * (size_t)map.gdim[0] + (size_t)(e.x - map.gmin[0]);
     lk_match_rec r = map.match[e.w];
     r.pad_ = (unsigned int)e.w;
+    if (!(r.flags & LK_PLANE_IS_PLANE)) {
+        // pass 1: count the plane nodes of the subtree; pass 2: copy them
+        unsigned int first = 0, count = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                if (count == 0) break;
+                first = atomicAdd(cursor, count);
+                if (first + count > cand_end) {   // cannot happen (sized for every non-root node); fail safe: no list
+                    count = 0;
+                    break;
+                }
+            }
+            unsigned int k = 0;
+            int stack_node[LK_MAX_LAYER + 1], stack_ci[LK_MAX_LAYER + 1];
+            int level = 0;
+            stack_node[0] = e.w, stack_ci[0] = 0;
+            while (level >= 0) {
+                const int node = stack_node[level];
+                if (stack_ci[level] == 0 && level > 0) {   // first visit of a non-root node
+                    const unsigned int fl = map.match[node].flags;
+                    if (fl & LK_PLANE_IS_PLANE) {
+                        if (pass == 1) {
+                            lk_match_rec cr = map.match[node];
+                            cr.pad_ = (unsigned int)node;
+                            map.match[first + k] = cr;
+                        }
+                        ++k;
+                        --level;
+                        continue;
+                    }
+                }
+                if (level >= max_layer || level >= LK_MAX_LAYER) {
+                    --level;
+                    continue;
+                }
+                int child = -1;
+                while (stack_ci[level] < 8 && child < 0) child = map.nodes[node].child[stack_ci[level]++];
+                if (child >= 0) {
+                    ++level;
+                    stack_node[level] = child, stack_ci[level] = 0;
+                } else {
+                    --level;
+                }
+            }
+            if (pass == 0) count = k;
+        }
+        r.flags = LK_GRID_LIST;
+        unsigned int fc[2] = {first, count};
+        memcpy(&r.center[0], fc, sizeof(fc));
+    }
     map.match[map.grid_base + c] = r;
 }
 

@@ -161,6 +161,37 @@ __device__ __forceinline__ bool match_root(const LkMap& m, int root, const bool 
     return true;
 }
 
+// Matcher of the FROZEN map (grid cells, LkMap::grid_base): the root's cell is a plane record, or the header of the flattened
+// list of its subtree's planes (LK_GRID_LIST) - a counted loop over consecutive records, candidates in the reference's
+// pre-order, one copy of the plane evaluation.  Returns whether a root voxel exists at the cell.
+template <bool XID>
+__device__ __forceinline__ bool match_flat(const LkMap& m, int cell, const PointLite& g, const BucketConst& bc, const LkParams& pr,
+                                           bool& success, double& prob, Match& best) {
+    int idx = cell, remaining = 1;
+    bool header = true;   // the record at idx is the cell itself
+    while (remaining > 0) {
+        const lk_match_rec* pl = &m.match[idx];
+        const double2* q = reinterpret_cast<const double2*>(pl);
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2];
+        const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, node id
+        const unsigned int fl = __float_as_uint(tail.z);
+        if (header) {
+            header = false;
+            if (__float_as_uint(tail.w) == LK_GRID_EMPTY) return false;  // no root voxel at this key
+            if (!(fl & LK_PLANE_IS_PLANE)) {
+                if (LK_X_NOCHILD) return true;
+                idx = (int)(unsigned int)__double_as_longlong(q0.x);            // {first, count} in the header's first 8 bytes
+                remaining = (int)(unsigned int)(__double_as_longlong(q0.x) >> 32);
+                continue;
+            }
+        }
+        if (!LK_X_NOEVAL) eval_plane<XID>(pl, q0, q1, q2, tail.x, tail.y, 0, 0, g, bc, pr, success, prob, best);
+        ++idx;
+        --remaining;
+    }
+    return true;
+}
+
 // Root voxel of a key for the matcher: index into m.match[] (a node id from the hash table, or a grid cell), -1 = none.
 // GRID: 0 = hash table (compile-time), 1 = frozen-map grid (compile-time), 2 = decided by m.grid_on at run time
 template <int GRID>
@@ -241,7 +272,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         best.row = rows + lane * LK_ROW2;
         const bool grid_cell = GRID == 1 || (GRID == 2 && map.grid_on != 0);
         bool home = false;
-        if (root >= 0) home = match_root<XID>(map, root, grid_cell, g, bc, pr, success, prob, best);
+        if (root >= 0) home = grid_cell ? match_flat<XID>(map, root, g, bc, pr, success, prob, best) : match_root<XID>(map, root, false, g, bc, pr, success, prob, best);
         // the one-neighbour retry (KILO.cc:156-178): only when the home voxel EXISTS (the lookup at KILO.cc:149 found a tree)
         if (home && !success && !LK_X_NORETRY) {
             float loc[3];     // re-derived here rather than kept alive across the home voxel's walk
@@ -250,7 +281,10 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = find_root<GRID>(map, near[0], near[1], near[2]);
-            if (nroot >= 0) match_root<XID>(map, nroot, grid_cell, g, bc, pr, success, prob, best);
+            if (nroot >= 0) {
+                if (grid_cell) match_flat<XID>(map, nroot, g, bc, pr, success, prob, best);
+                else match_root<XID>(map, nroot, false, g, bc, pr, success, prob, best);
+            }
         }
         ok = success;
         if (ok) {  // KILO.cc:195-209: h (1x6), z, R for the matched point, from the parked row
