@@ -39,8 +39,9 @@ def db(path):
 
 
 rows = {}
-cur = db(f"prof_{tag}_stats").cursor()
-disp = list(cur.execute("select name, grid_x, grid_y, workgroup_x, duration, vgpr_count, sgpr_count, lds_size, scratch_size, start, end "
+have_stats = os.path.exists(os.path.join(G, f"prof_{tag}_stats", "bench_results.db"))
+cur = db(f"prof_{tag}_stats").cursor() if have_stats else None
+disp = [] if not have_stats else list(cur.execute("select name, grid_x, grid_y, workgroup_x, duration, vgpr_count, sgpr_count, lds_size, scratch_size, start, end "
                         "from kernels order by start"))
 # Launches of the asynchronous batch loop run two at a time (one per stream) and share the GPU: their trace durations
 # are not per-launch costs.  A launch is "shared" when other chip-filling launches (>= 1024 workgroups) cover more than
@@ -57,7 +58,7 @@ for i, (name, gx, gy, wx, dur, vg, sg, lds, scr, _s, _e) in enumerate(disp):
     r = rows.setdefault(key, dict(calls=0, total_ns=0, vgpr=vg, sgpr=sg, lds=lds, scratch=scr))
     r["calls"] += 1
     r["total_ns"] += dur
-tot = sum(r["total_ns"] for r in rows.values())
+tot = sum(r["total_ns"] for r in rows.values()) or 1
 with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "blocks_x", "blocks_y", "gpu", "calls", "total_us", "avg_us", "pct", "vgpr", "sgpr", "lds_bytes", "scratch_bytes"])

@@ -17,6 +17,9 @@ run() {  # name, extra bench args, rocprof args...
   timeout 420 rocprofv3 "$@" -d $OUT/$name -o bench -- python $REPO/bench.py $COMMON $bargs > $OUT/$name.log 2>&1 < /dev/null
   echo "$name: rc=$? $(ls $OUT/$name 2>/dev/null | head -1) errors=$(grep -ciE 'error|invalid' $OUT/$name.log)"
 }
+# populate the input cache OUTSIDE rocprofv3: the generator forks a worker pool, and forking a process that has the profiler's
+# counter tool (HSA already initialised) loaded can hang
+timeout 300 python $REPO/bench.py $COMMON --steps 1 --warmup 0 --stream-scans 3 > $OUT/prof_${TAG}_warm.log 2>&1 < /dev/null
 for p in $PASSES; do
   case $p in
     stats) run prof_${TAG}_stats "--steps 3 --warmup 1 --stream-scans 3" --kernel-trace --stats ;;
