@@ -57,6 +57,7 @@ struct lk_handle {
     void* h_rag = nullptr;
     size_t rag_cap = 0;
     double acc_norm = 1.0;
+    bool q_diag = true;        // d_Q holds a diagonal matrix (zero-initialised; lk_set_Q re-checks)
     // frozen-map grid of batch replay (LkMap::grid): valid until the map changes
     LkMap fmap;                // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
     size_t grid_cap = 0;       // grid cells allocated behind the max_nodes match records of map.match
@@ -332,6 +333,14 @@ int lk_get_state(lk_handle* h, uint32_t slot, double* x36, double* P900) {
 }
 int lk_set_Q(lk_handle* h, const double* Q900) {
     CHECK_H(h);
+    if (!Q900) return fail(h, LK_ERR_INVALID, "Q is null");
+    h->q_diag = true;
+    for (int i = 0; i < 30 && h->q_diag; ++i)
+        for (int j = 0; j < 30; ++j)
+            if (i != j && Q900[i * 30 + j] != 0.0) {
+                h->q_diag = false;
+                break;
+            }
     HIPCHK(h, hipMemcpyAsync(h->d_Q, Q900, sizeof(double) * 900, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return LK_OK;
@@ -531,7 +540,7 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
         const size_t mstride = MSG == 2 ? 33 : 7;
         const bool is_imu = WITH_IMU && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
         const double t = is_imu ? rg.imu[mstride * (size_t)qi] : tb_;
-        wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane);   // KILO.cc:111-115 / :240-244
+        if (!LK_X_NOPRED) wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
         t_pred = t;
         if (is_imu) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
             const double* m = rg.imu + mstride * (size_t)qi;
@@ -558,7 +567,8 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
         double totv = 0.0;  // tot[j] in lanes 0..31
         for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
             __builtin_amdgcn_wave_barrier();  // the previous tile's reads of the rows are complete
-            const double a = residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
+            const double a = LK_X_NORES ? ((lane == 28) ? 1.0 : 0.0)
+                                        : residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
             totv += (lane < 29) ? a : 0.0;
         }
         const int N = (int)(__shfl(totv, 28, LK_WAVE) + 0.5);
@@ -566,7 +576,7 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
         if (N > 0) {
             n_updates += 1, n_effect += (unsigned long long)N;
             t_upd = t;  // KILO.cc:212
-            wave_update_core(sm, totv, N, lane);
+            if (!LK_X_NOUPD) wave_update_core(sm, totv, N, lane);
         }
         __syncthreads();
         ++b;
@@ -1717,6 +1727,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     rg.imu = reinterpret_cast<const double*>(dr + o_im);
     rg.msg_stride = (int)(msg_bytes / sizeof(double));
     rg.kin_noise = h->cfg.kin_meas_noise;
+    rg.q_diag = h->q_diag ? 1 : 0;
     rg.acc_scale = h->cfg.gravity / h->acc_norm;
     imu_noise(h->cfg, rg.Rn);
     LkMap fmap;

@@ -146,6 +146,7 @@ struct LkRagged {
     const double* imu;                 // [n][msg_stride]: lk_imu (7 doubles: stamp, acc, gyr) or lk_kin_imu (33 doubles, stamp first)
     int msg_stride;                    // 7 (only_imu_use) or 33 (leg fusion: kinematic + IMU messages)
     double kin_noise;                  // kin_meas_noise (KILO.cc:305)
+    int q_diag;                        // the process noise Q is diagonal (initProcessCovQ, eskf.cc:47-62): P += dt^2 Q touches 30 entries
     double acc_scale;                  // gravity / acc_norm (KILO.cc:246)
     double Rn[6];                      // IMU measurement noise: acc, acc, acc_z, gyr, gyr, gyr
 };
@@ -211,9 +212,22 @@ __device__ __forceinline__ void rodrigues3(V3 axis, double ang, double* R) {
     double K[9], KK[9];
     skew3(axis, K);
     mat3_mul(K, K, KK);
-    double s = sin(ang), c1 = 1.0 - cos(ang);
+    double s, c;
+    sincos(ang, &s, &c);   // one argument reduction for both (same values as sin() and cos())
+    const double c1 = 1.0 - c;
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s * K[i] + c1 * KK[i];
+}
+// Both Exp overloads of math_utils.hpp as one instruction stream (they differ in the threshold only): lets two lanes of a wave
+// evaluate one each AT THE SAME TIME (wave_predict_core) instead of one after the other.
+__device__ __forceinline__ void exp_so3_thr(double v1, double v2, double v3, double thr, double* R) {
+    double n = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    if (n > thr) {
+        rodrigues3(V3{v1 / n, v2 / n, v3 / n}, n, R);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
 }
 // Exp(v1,v2,v3), threshold 1e-5 (math_utils.hpp:54-68)
 __device__ __forceinline__ void exp3_1e5(double v1, double v2, double v3, double* R) {

@@ -12,6 +12,9 @@
 #include "lk_device.h"
 
 #define LK_FB 256  // threads per filter block
+#ifndef LK_X_P
+#define LK_X_P 0   // perf attribution only (never set in the product build): bit 1 skip the rotations of the wave predict, 2 the
+#endif             // covariance products, 4 the Q term, 8 the Gauss-Jordan sweep of the wave update, 16 its P update, 32 its (+)
 
 struct FilterSmem {
     double P[900];
@@ -384,7 +387,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
     }
     // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < ((LK_X_P & 8) ? 0 : 6); ++k) {
         int p = k;
         double best = fabs(col[k]);
 #pragma unroll
@@ -400,11 +403,17 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
                 col[k] = col[i];
                 col[i] = tmp;
             }
-        const double piv = __shfl(col[k], k, LK_WAVE);
+        // row factors S[i][k] / S[k][k]: lane i divides ONE of them (the column lives in lane k's registers), then they are
+        // broadcast - one fp64 division per step on the critical path instead of five; the same quotients, the same bits
+        double sk[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sk[i] = __shfl(col[i], k, LK_WAVE);
+        const double mine = lane == 0 ? sk[0] : lane == 1 ? sk[1] : lane == 2 ? sk[2] : lane == 3 ? sk[3] : lane == 4 ? sk[4] : sk[5];
+        const double fac = mine / sk[k];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i == k) continue;
-            double fi = __shfl(col[i], k, LK_WAVE) / piv;
+            const double fi = __shfl(fac, i, LK_WAVE);
             col[i] -= fi * col[k];
         }
     }
@@ -426,7 +435,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
 #pragma unroll
         for (int m = 0; m < 6; ++m) X[m] = __shfl(col[m], 6 + jc, LK_WAVE);
 #pragma unroll 1
-        for (int r0 = 0; r0 < 15; r0 += 5) {
+        for (int r0 = 0; r0 < ((LK_X_P & 16) ? 0 : 15); r0 += 5) {
             double nv[5];
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -446,7 +455,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
     }
     // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
     const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
-    if (lane == 0) {
+    if (lane == 0 && !(LK_X_P & 32)) {
         double E[9], Rn[9];
         exp3_1e5(d0, d1, d2, E);
         mat3_mul(sm.x, E, Rn);
@@ -495,11 +504,17 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
                 col[k] = col[i];
                 col[i] = tmp;
             }
-        const double piv = __shfl(col[k], k, LK_WAVE);
+        // row factors S[i][k] / S[k][k]: lane i divides ONE of them (the column lives in lane k's registers), then they are
+        // broadcast - one fp64 division per step on the critical path instead of five; the same quotients, the same bits
+        double sk[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sk[i] = __shfl(col[i], k, LK_WAVE);
+        const double mine = lane == 0 ? sk[0] : lane == 1 ? sk[1] : lane == 2 ? sk[2] : lane == 3 ? sk[3] : lane == 4 ? sk[4] : sk[5];
+        const double fac = mine / sk[k];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i == k) continue;
-            double fi = __shfl(col[i], k, LK_WAVE) / piv;
+            const double fi = __shfl(fac, i, LK_WAVE);
             col[i] -= fi * col[k];
         }
     }
@@ -743,106 +758,136 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
 }
 
 // ESKF::predict(dt_cov, false, true) then predict(dt, true, false) (KILO.cc:111-115) on LDS-resident state.
-__device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane) {
-    if (lane == 0) {  // getFx, eskf.cc:72-81
+__device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane,
+                                                  const bool q_diag = false) {
+    // The two rotations of a predict - Exp(-dt_cov w) for Fx (getFx, eskf.cc:74) and Exp(dt w) for the state (operator+=,
+    // eskf.cc:19) - depend on the OLD state only: lanes 0 and 1 evaluate one each in the same instruction stream (a wave
+    // executes both sides of a lane-0 / lane-1 branch one after the other; sqrt, three divisions and a sin / cos pair are a
+    // ~4 k-cycle dependent chain each).  Lane 1 keeps the propagated rotation / position / velocity in registers until the
+    // covariance product has read the old rotation out of sm.x.
+    double Rn[9], dpv[6];
+    if (lane < 2 && !(LK_X_P & 1)) {
         const double* x = sm.x;
-        V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
-        double E[9], K[9], mR[9], B60[9];
-        expv_1e7(V3{(-dt_cov) * w.x, (-dt_cov) * w.y, (-dt_cov) * w.z}, E);
-        skew3(a, K);
-        for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
-        mat3_mul(mR, K, B60);
-        for (int i = 0; i < 9; ++i) sm.fx[i] = E[i], sm.fx[9 + i] = B60[i];
+        const double sc = lane == 0 ? -dt_cov : dt;
+        const double thr = lane == 0 ? 0.0000001 : 0.00001;   // math_utils.hpp:19-32 / :54-68
+        double E[9];
+        exp_so3_thr(sc * x[27], sc * x[28], sc * x[29], thr, E);
+        if (lane == 0) {  // getFx, eskf.cc:72-81
+            V3 a = V3{x[24], x[25], x[26]};
+            double K[9], mR[9], B60[9];
+            skew3(a, K);
+            for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
+            mat3_mul(mR, K, B60);
+            for (int i = 0; i < 9; ++i) sm.fx[i] = E[i], sm.fx[9 + i] = B60[i];
+        } else {          // getFunctionf + operator+=, eskf.cc:64-70,18-29 (state_boxplus with d[9..29] = 0)
+            V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
+            for (int i = 0; i < 3; ++i) dpv[i] = dt * x[12 + i];
+            dpv[3] = dt * (Ra.x + x[21]), dpv[4] = dt * (Ra.y + x[22]), dpv[5] = dt * (Ra.z + x[23]);
+            mat3_mul(x, E, Rn);
+        }
     }
     __syncthreads();
     const double* E = sm.fx;
     const double* B60 = sm.fx + 9;
-    {  // rows 0..8 of B = Fx * P, in place (rows >= 9 of B are rows of P)
-        double nb[5];
+    // Fx differs from I in three row blocks of different shape (eskf.cc:72-81): rows 0..2 = [E | dt I at col 21], rows 3..5 =
+    // [I | dt I at col 6], rows 6..8 = [B60 | I | dt I at col 15 | dt R at col 18].  Each block is handled by ALL lanes with one
+    // straight-line expression (90 entries = two rounds of 64 lanes) instead of one loop whose lanes fall into different blocks
+    // and execute all three shapes in turn; every entry is the same sum in the same order as before (bit-identical).
+    if (!(LK_X_P & 2)) {  // rows 0..8 of B = Fx * P, in place (rows >= 9 of B are rows of P)
+        double nb[6];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = lane + 64 * q;
-            const int i = e < 270 ? e / 30 : 0, c = e % 30;
-            double s = 0.0;
-            if (i < 3) {
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q, i = e < 90 ? e / 30 : 0, c = e % 30;
+            {
+                double s = 0.0;
                 s += E[3 * i + 0] * sm.P[0 * 30 + c];
                 s += E[3 * i + 1] * sm.P[1 * 30 + c];
                 s += E[3 * i + 2] * sm.P[2 * 30 + c];
                 s += dt_cov * sm.P[(21 + i) * 30 + c];
-            } else if (i < 6) {
-                s += 1.0 * sm.P[i * 30 + c];
-                s += dt_cov * sm.P[(3 + i) * 30 + c];
-            } else {
-                const int ii = i - 6;
-                s += B60[3 * ii + 0] * sm.P[0 * 30 + c];
-                s += B60[3 * ii + 1] * sm.P[1 * 30 + c];
-                s += B60[3 * ii + 2] * sm.P[2 * 30 + c];
-                s += 1.0 * sm.P[i * 30 + c];
-                s += dt_cov * sm.P[(15 + ii) * 30 + c];
-                s += (dt_cov * sm.x[3 * ii + 0]) * sm.P[18 * 30 + c];
-                s += (dt_cov * sm.x[3 * ii + 1]) * sm.P[19 * 30 + c];
-                s += (dt_cov * sm.x[3 * ii + 2]) * sm.P[20 * 30 + c];
+                nb[q] = s;
             }
-            nb[q] = s;
+            {
+                double s = 0.0;
+                s += 1.0 * sm.P[(3 + i) * 30 + c];
+                s += dt_cov * sm.P[(6 + i) * 30 + c];
+                nb[2 + q] = s;
+            }
+            {
+                double s = 0.0;
+                s += B60[3 * i + 0] * sm.P[0 * 30 + c];
+                s += B60[3 * i + 1] * sm.P[1 * 30 + c];
+                s += B60[3 * i + 2] * sm.P[2 * 30 + c];
+                s += 1.0 * sm.P[(6 + i) * 30 + c];
+                s += dt_cov * sm.P[(15 + i) * 30 + c];
+                s += (dt_cov * sm.x[3 * i + 0]) * sm.P[18 * 30 + c];
+                s += (dt_cov * sm.x[3 * i + 1]) * sm.P[19 * 30 + c];
+                s += (dt_cov * sm.x[3 * i + 2]) * sm.P[20 * 30 + c];
+                nb[4 + q] = s;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const int e = lane + 64 * q;
-            if (e < 270) sm.P[e] = nb[q];
+            if (e < 90) sm.P[e] = nb[q], sm.P[90 + e] = nb[2 + q], sm.P[180 + e] = nb[4 + q];
         }
     }
     __syncthreads();
-    {  // columns 0..8 of B * Fx^T, in place
-        double nc[5];
+    if (!(LK_X_P & 2)) {  // columns 0..8 of B * Fx^T, in place: the same three shapes, 30 rows x 3 columns each
+        double nc[6];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = lane + 64 * q;
-            const int i = e < 270 ? e / 9 : 0, c = e % 9;
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q, i = e < 90 ? e / 3 : 0, c = e % 3;
             const double* Bi = &sm.P[i * 30];
-            double s = 0.0;
-            if (c < 3) {
+            {
+                double s = 0.0;
                 s += Bi[0] * E[3 * c + 0];
                 s += Bi[1] * E[3 * c + 1];
                 s += Bi[2] * E[3 * c + 2];
                 s += Bi[21 + c] * dt_cov;
-            } else if (c < 6) {
-                s += Bi[c] * 1.0;
-                s += Bi[3 + c] * dt_cov;
-            } else {
-                const int cc = c - 6;
-                s += Bi[0] * B60[3 * cc + 0];
-                s += Bi[1] * B60[3 * cc + 1];
-                s += Bi[2] * B60[3 * cc + 2];
-                s += Bi[c] * 1.0;
-                s += Bi[15 + cc] * dt_cov;
-                s += Bi[18] * (dt_cov * sm.x[3 * cc + 0]);
-                s += Bi[19] * (dt_cov * sm.x[3 * cc + 1]);
-                s += Bi[20] * (dt_cov * sm.x[3 * cc + 2]);
+                nc[q] = s;
             }
-            nc[q] = s;
+            {
+                double s = 0.0;
+                s += Bi[3 + c] * 1.0;
+                s += Bi[6 + c] * dt_cov;
+                nc[2 + q] = s;
+            }
+            {
+                double s = 0.0;
+                s += Bi[0] * B60[3 * c + 0];
+                s += Bi[1] * B60[3 * c + 1];
+                s += Bi[2] * B60[3 * c + 2];
+                s += Bi[6 + c] * 1.0;
+                s += Bi[15 + c] * dt_cov;
+                s += Bi[18] * (dt_cov * sm.x[3 * c + 0]);
+                s += Bi[19] * (dt_cov * sm.x[3 * c + 1]);
+                s += Bi[20] * (dt_cov * sm.x[3 * c + 2]);
+                nc[4 + q] = s;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 2; ++q) {
             const int e = lane + 64 * q;
-            if (e < 270) sm.P[(e / 9) * 30 + (e % 9)] = nc[q];
+            if (e < 90) {
+                const int i = e / 3, c = e % 3;
+                sm.P[i * 30 + c] = nc[q], sm.P[i * 30 + 3 + c] = nc[2 + q], sm.P[i * 30 + 6 + c] = nc[4 + q];
+            }
         }
     }
     __syncthreads();
     const double dt2 = dt_cov * dt_cov;
-    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = sm.P[e] + dt2 * Q[e];
-    if (lane == 0) {  // getFunctionf + operator+=, eskf.cc:64-70,18-29
+    if (LK_X_P & 4) {
+    } else if (q_diag) {   // Q of initProcessCovQ (eskf.cc:47-62) is diagonal: the other 870 terms are + dt^2 * 0
+        if (lane < 30) sm.P[lane * 31] = sm.P[lane * 31] + dt2 * Q[lane * 31];
+    } else {
+        for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = sm.P[e] + dt2 * Q[e];
+    }
+    if (lane == 1 && !(LK_X_P & 1)) {
         double* x = sm.x;
-        double d[9];
-        V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
-        for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
-        d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
-        double E[9], Rn[9];  // state_boxplus with d[9..29] = 0
-        exp3_1e5(d[0], d[1], d[2], E);
-        mat3_mul(x, E, Rn);
         for (int i = 0; i < 9; ++i) x[i] = Rn[i];
-        for (int i = 0; i < 6; ++i) x[9 + i] += d[3 + i];
+        for (int i = 0; i < 6; ++i) x[9 + i] += dpv[i];
     }
     __syncthreads();
 }

@@ -30,6 +30,15 @@
 #ifndef LK_X_NORED
 #define LK_X_NORED 0
 #endif
+#ifndef LK_X_NOPRED
+#define LK_X_NOPRED 0
+#endif
+#ifndef LK_X_NOUPD
+#define LK_X_NOUPD 0
+#endif
+#ifndef LK_X_NORES
+#define LK_X_NORES 0
+#endif
 // The residual kernel runs ONE wave per workgroup: with no block barrier in it there is nothing to share, and the
 // scheduler can refill a SIMD slot the moment a wave retires instead of waiting for a 4-wave workgroup's worth of
 // slots and LDS (measured on the 1024-scan batch: 642 us per bucket at 256 threads, 582 at 128, 578 at 64).
