@@ -46,65 +46,107 @@ __device__ void dev_predict(LkFilter* f, const double* __restrict__ Q, double t,
     const int tid = threadIdx.x;
     const double dt_cov = t - f->last_update_t;
     const double dt = t - f->last_predict_t;
-    for (int i = tid; i < 900; i += LK_FB) {
-        sm.P[i] = f->P[i];
-        sm.A[i] = ((i / 30) == (i % 30)) ? 1.0 : 0.0;  // Fx = I
-    }
+    for (int i = tid; i < 900; i += LK_FB) sm.P[i] = f->P[i];
     if (tid < 36) sm.vec[tid] = f->x[tid];
     __syncthreads();
-    if (tid == 0) {  // getFx, eskf.cc:72-81
+    // The two rotations of a predict depend on the old state only: thread 0 builds the non-trivial blocks of Fx (getFx,
+    // eskf.cc:72-81: E = Exp(-dt_cov w) -> sm.A[0..8], B60 = -dt_cov R [a]x -> sm.A[9..17]) while thread 64 - another wave -
+    // propagates the state (getFunctionf + operator+=, eskf.cc:64-70,18-29) into its registers.
+    double Rn[9], dpv[6];
+    if (tid == 0 || tid == 64) {
         const double* x = sm.vec;
-        V3 w = V3{x[27], x[28], x[29]}, a = V3{x[24], x[25], x[26]};
-        double E[9], K[9], mR[9], B60[9];
-        expv_1e7(V3{(-dt_cov) * w.x, (-dt_cov) * w.y, (-dt_cov) * w.z}, E);
-        skew3(a, K);
-        for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
-        mat3_mul(mR, K, B60);
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                sm.A[(0 + i) * 30 + 0 + j] = E[3 * i + j];
-                sm.A[(0 + i) * 30 + 21 + j] = (i == j) ? dt_cov : 0.0;
-                sm.A[(3 + i) * 30 + 6 + j] = (i == j) ? dt_cov : 0.0;
-                sm.A[(6 + i) * 30 + 0 + j] = B60[3 * i + j];
-                sm.A[(6 + i) * 30 + 15 + j] = (i == j) ? dt_cov : 0.0;
-                sm.A[(6 + i) * 30 + 18 + j] = dt_cov * x[3 * i + j];
-            }
+        const double sc = tid == 0 ? -dt_cov : dt;
+        const double thr = tid == 0 ? 0.0000001 : 0.00001;   // math_utils.hpp:19-32 / :54-68
+        double E[9];
+        exp_so3_thr(sc * x[27], sc * x[28], sc * x[29], thr, E);
+        if (tid == 0) {
+            V3 a = V3{x[24], x[25], x[26]};
+            double K[9], mR[9], B60[9];
+            skew3(a, K);
+            for (int i = 0; i < 9; ++i) mR[i] = (-dt_cov) * x[i];
+            mat3_mul(mR, K, B60);
+            for (int i = 0; i < 9; ++i) sm.A[i] = E[i], sm.A[9 + i] = B60[i];
+        } else {
+            V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
+            for (int i = 0; i < 3; ++i) dpv[i] = dt * x[12 + i];
+            dpv[3] = dt * (Ra.x + x[21]), dpv[4] = dt * (Ra.y + x[22]), dpv[5] = dt * (Ra.z + x[23]);
+            mat3_mul(x, E, Rn);
+        }
     }
     __syncthreads();
-    // Fx differs from the identity only in rows 0..8 (getFx, eskf.cc:72-81).  A row i >= 9 of Fx * P is
-    // sum_k delta_ik P_kj = P_ij exactly (the other terms are exact zeros, 1.0 * P_ij is exact), so only rows 0..8 are
-    // computed - with the same full-length dot product as before, i.e. bit-identical - and the rest is copied; the same
-    // holds for the columns of (Fx P) Fx^T.  3.3x fewer FMAs and LDS reads on the one kernel that is serial per filter.
-    for (int e = tid; e < 900; e += LK_FB) {  // B = Fx * P
-        int i = e / 30, j = e % 30;
-        double s = sm.P[e];
-        if (i < 9) {
-            s = 0.0;
-            for (int k = 0; k < 30; ++k) s += sm.A[i * 30 + k] * sm.P[k * 30 + j];
-        }
-        sm.B[e] = s;
+    // Fx P Fx^T over the three non-identity row blocks of Fx, each as one straight-line expression over its non-zero terms
+    // (rows 0..2 = [E | dt I at 21], rows 3..5 = [I | dt I at 6], rows 6..8 = [B60 | I | dt I at 15 | dt R at 18]): the same
+    // sums in the same order as the dense 30-term dot products (the skipped terms are exact zeros) and as wave_predict_core.
+    const double* E = sm.A;
+    const double* B60 = sm.A + 9;
+    const double* xr = sm.vec;
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (tid < 90) {
+        const int i = tid / 30, c = tid % 30;
+        double s = 0.0;
+        s += E[3 * i + 0] * sm.P[0 * 30 + c];
+        s += E[3 * i + 1] * sm.P[1 * 30 + c];
+        s += E[3 * i + 2] * sm.P[2 * 30 + c];
+        s += dt_cov * sm.P[(21 + i) * 30 + c];
+        n0 = s;
+        s = 0.0;
+        s += 1.0 * sm.P[(3 + i) * 30 + c];
+        s += dt_cov * sm.P[(6 + i) * 30 + c];
+        n1 = s;
+        s = 0.0;
+        s += B60[3 * i + 0] * sm.P[0 * 30 + c];
+        s += B60[3 * i + 1] * sm.P[1 * 30 + c];
+        s += B60[3 * i + 2] * sm.P[2 * 30 + c];
+        s += 1.0 * sm.P[(6 + i) * 30 + c];
+        s += dt_cov * sm.P[(15 + i) * 30 + c];
+        s += (dt_cov * xr[3 * i + 0]) * sm.P[18 * 30 + c];
+        s += (dt_cov * xr[3 * i + 1]) * sm.P[19 * 30 + c];
+        s += (dt_cov * xr[3 * i + 2]) * sm.P[20 * 30 + c];
+        n2 = s;
+    }
+    __syncthreads();
+    if (tid < 90) sm.P[tid] = n0, sm.P[90 + tid] = n1, sm.P[180 + tid] = n2;
+    __syncthreads();
+    if (tid < 90) {
+        const int i = tid / 3, c = tid % 3;
+        const double* Bi = &sm.P[i * 30];
+        double s = 0.0;
+        s += Bi[0] * E[3 * c + 0];
+        s += Bi[1] * E[3 * c + 1];
+        s += Bi[2] * E[3 * c + 2];
+        s += Bi[21 + c] * dt_cov;
+        n0 = s;
+        s = 0.0;
+        s += Bi[3 + c] * 1.0;
+        s += Bi[6 + c] * dt_cov;
+        n1 = s;
+        s = 0.0;
+        s += Bi[0] * B60[3 * c + 0];
+        s += Bi[1] * B60[3 * c + 1];
+        s += Bi[2] * B60[3 * c + 2];
+        s += Bi[6 + c] * 1.0;
+        s += Bi[15 + c] * dt_cov;
+        s += Bi[18] * (dt_cov * xr[3 * c + 0]);
+        s += Bi[19] * (dt_cov * xr[3 * c + 1]);
+        s += Bi[20] * (dt_cov * xr[3 * c + 2]);
+        n2 = s;
+    }
+    __syncthreads();
+    if (tid < 90) {
+        const int i = tid / 3, c = tid % 3;
+        sm.P[i * 30 + c] = n0, sm.P[i * 30 + 3 + c] = n1, sm.P[i * 30 + 6 + c] = n2;
     }
     __syncthreads();
     const double dt2 = dt_cov * dt_cov;
-    for (int e = tid; e < 900; e += LK_FB) {  // P = B * Fx^T + dt^2 Q
-        int i = e / 30, j = e % 30;
-        double s = sm.B[e];
-        if (j < 9) {
-            s = 0.0;
-            for (int k = 0; k < 30; ++k) s += sm.B[i * 30 + k] * sm.A[j * 30 + k];
-        }
-        double v = s + dt2 * Q[e];
+    for (int e = tid; e < 900; e += LK_FB) {  // P += dt^2 Q
+        double v = sm.P[e] + dt2 * Q[e];
         sm.P[e] = v;
         f->P[e] = v;
     }
-    if (tid == 0) {  // getFunctionf + operator+=, eskf.cc:64-70,18-29
+    if (tid == 64) {
         double* x = f->x;
-        double d[30];
-        for (int i = 0; i < 30; ++i) d[i] = 0.0;
-        V3 Ra = mat3_mul_v(x, V3{x[24], x[25], x[26]});
-        for (int i = 0; i < 3; ++i) d[i] = dt * x[27 + i], d[3 + i] = dt * x[12 + i];
-        d[6] = dt * (Ra.x + x[21]), d[7] = dt * (Ra.y + x[22]), d[8] = dt * (Ra.z + x[23]);
-        state_boxplus(x, d);
+        for (int i = 0; i < 9; ++i) x[i] = Rn[i];
+        for (int i = 0; i < 6; ++i) x[9 + i] += dpv[i];
         f->last_predict_t = t;
     }
     __syncthreads();
