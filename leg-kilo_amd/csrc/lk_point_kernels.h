@@ -16,6 +16,9 @@
 #include "lk_device.h"
 
 #define LK_PB 256
+#ifndef LK_MFMA_RED
+#define LK_MFMA_RED 0   // 1: the per-tile normal-equation sums on v_mfma_f64_4x4x4 (A/B build; see residual_tile)
+#endif
 // perf-attribution switches (tools/ab_env.sh builds with -DLK_X_...=1): each removes one piece of the residual pass so that its
 // marginal cost can be measured; results are wrong with any of them set, the product build sets none
 #ifndef LK_X_NORETRY
@@ -332,6 +335,35 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (LK_X_NORED) return (lane == 28) ? (ok ? 1.0 : 0.0) : 0.0;
+#if LK_MFMA_RED
+    // K3 on the matrix cores: G = X^T Y over the tile's 64 rows with X = [h/R (6), R, valid] (row doubles 7..14) and
+    // Y = [h (6), z, valid] (row doubles 0..6, 14): G(i,j), i <= j < 6, is A; G(i,6) is b; G(6,7) = sum R; G(7,7) = count.
+    // v_mfma_f64_4x4x4_4b: four independent 4 x 4 blocks, K = 4 per instruction -> the four blocks are the 2 x 2 tiling of the
+    // 8 x 8 result and 16 instructions walk the 64 rows.  Operand layout measured on gfx950 (tools/probes/mfma_f64_4x4x4_layout.hip):
+    // lane = 16 k + 4 b + m supplies A[b][m][k] and B[b][k][m]; D[b][i][j] lands in lane 16 i + 4 b + j.
+    {
+        const int k = lane >> 4, b = (lane >> 2) & 3, m = lane & 3;
+        const int ca = 7 + 4 * (b >> 1) + m;
+        const int cb0 = 4 * (b & 1) + m, cb = cb0 < 7 ? cb0 : 14;
+        const double* pa = rows + k * LK_ROW2 + ca;
+        const double* pb = rows + k * LK_ROW2 + cb;
+        double d0 = 0.0, d1 = 0.0;   // two accumulators: consecutive MFMAs do not wait for each other
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[(4 * t) * LK_ROW2], pb[(4 * t) * LK_ROW2], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[(4 * t + 4) * LK_ROW2], pb[(4 * t + 4) * LK_ROW2], d1, 0, 0, 0);
+        }
+        const double g = d0 + d1;
+        // lane q (both halves) wants component q of [A(21) b(6) sumR count]
+        const int q = lane & 31;
+        // (gi, gj) of component q, packed gi | gj << 4, eight per 64-bit word: the upper triangle of A row by row, then (i, 6), (6, 7), (7, 7)
+        const unsigned long long tw = (q < 8) ? 0x2111504030201000ull : (q < 16) ? 0x3352423222514131ull : (q < 24) ? 0x6261605554445343ull : 0x0000007776656463ull;
+        const unsigned int ij = (unsigned int)(tw >> ((q & 7) * 8)) & 0xffu;
+        const int gi = (int)(ij & 15u), gj = (int)(ij >> 4);
+        const int src = 16 * (gi & 3) + 4 * (2 * (gi >> 2) + (gj >> 2)) + (gj & 3);
+        return __shfl(g, src, LK_WAVE);
+    }
+#endif
     const int q = lane & 31, half = lane >> 5;
     // component q = sum over rows of r[a] * r[b]:  A(i,j) = sum (h_i / R) h_j (upper triangle, row-major: q < 21,
     // a = 7 + i, b = j), b_i = sum (h_i / R) z (q = 21 + i: a = 7 + i, b = 6), sum R (q = 27: 13, 14), count (14, 14).

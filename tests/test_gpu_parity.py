@@ -680,6 +680,92 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     o.close()
 
 
+def test_frozen_grid_equals_hash_and_follows_the_map(scene, oracle_lib, hip_lib, monkeypatch):
+    """Batch replay looks root voxels up through the frozen-map grid (dense array of root records + flattened subtree lists,
+    rebuilt when the map changes) and runs the kernel specialised for ext_R == I; LEGKILO_GRID=0 / LEGKILO_XID=0 keep the hash
+    table and the generic kernel.  On a map WITH cut voxels (clutter: non-plane roots whose planes sit at layers 1 and 2) all
+    variants must give the same bits and equal the oracle; after the map has changed (new voxels inserted through the stream
+    path) a second replay must see the new map - on every variant."""
+    n_pts, nb, S = 6000, 3, 5
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0, n_scans=4)
+    xs0, Ps0 = o.get_state()
+    # clutter around the robot's path: corners of 0.25 m cells -> layer-0 and layer-1 nodes fail the plane test, planes at layer 2
+    rngc = np.random.default_rng(77)
+    centre = scene.traj.pos(t0 + 1.3)
+    clutter = scenes.corner_clutter(rngc, n_cells=40, per_cell=80, origin=(centre[0] + 2.0, centre[1] - 1.0, 3.0))
+    var = np.tile((1e-4 * np.eye(3)).reshape(1, 9), (len(clutter), 1))
+    o.map_update(clutter, var)
+    blob = o.map_export()
+    cm = scenes.canon_map(blob)
+    assert sum(1 for n in cm.values() if not n["is_plane"] and n["children"]) >= 3, "the map must contain cut voxels"
+    o.set_map_insert(False)
+    rng = np.random.default_rng(991)
+    xs, Ps, scans = [], [], []
+    for s in range(S):
+        tb = t0 + 1.2 + 0.05 * s
+        scans.append(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=7100 + s, seed_noise=7200 + s))
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+    # points ON the clutter (body frame of scan 0's prior), so that the flattened lists are really walked
+    R0, p0 = xs[0][:9].reshape(3, 3), xs[0][9:12]
+    E = np.array(scene.P["extrinsic_R"], float).reshape(3, 3)
+    T = np.array(scene.P["extrinsic_T"], float)
+    cb = ((clutter[:n_pts // nb] - p0) @ R0 - T) @ E
+    scans[0]["x"][:len(cb)], scans[0]["y"][:len(cb)], scans[0]["z"][:len(cb)] = cb[:, 0], cb[:, 1], cb[:, 2]
+    off, dt = synth.buckets_of(scans[0])
+    allpts = np.concatenate(scans)
+    want = []
+    for s in range(S):
+        o.set_state(xs[s], Ps[s])
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(scans[s], 0.0)
+        want.append((po.n_buckets, po.n_updates, po.n_effect, o.get_state()[0].copy()))
+    results = {}
+    for name, env in (("grid+xid", {}), ("grid", {"LEGKILO_XID": "0"}), ("hash", {"LEGKILO_GRID": "0"})):
+        for k in ("LEGKILO_XID", "LEGKILO_GRID"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+        g.map_import(blob)
+        g.init_process_cov_q()
+        d_pts = g.device_malloc(allpts.nbytes)
+        g.h2d(d_pts, allpts)
+        g.batch_set_priors(np.array(xs), np.array(Ps))
+        poses = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
+        first = [(poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect, g.get_state(slot=s)[0].copy()) for s in range(S)]
+        # the map changes: a stream-mode scan with insert from a pose the map has not seen (new roots, new planes) ...
+        tb = t0 + 2.5
+        g.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30), slot=0)
+        g.set_times(tb, tb)
+        roots_before = g.map_stats()[0]
+        g.process_scan(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=20000, n_buckets=2, seed_scan=7300, seed_noise=7301), tb)
+        assert g.map_stats()[0] > roots_before
+        # ... and the next replay of the same batch runs against the NEW map
+        g.batch_set_priors(np.array(xs), np.array(Ps))
+        poses2 = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
+        second = [(poses2[s].n_buckets, poses2[s].n_updates, poses2[s].n_effect, g.get_state(slot=s)[0].copy()) for s in range(S)]
+        results[name] = (first, second)
+        g.device_free(d_pts)
+        g.close()
+    for k in ("LEGKILO_XID", "LEGKILO_GRID"):
+        monkeypatch.delenv(k, raising=False)
+    ref_first, ref_second = results["hash"]
+    for s in range(S):
+        assert ref_first[s][:3] == want[s][:3], (s, ref_first[s][:3], want[s][:3])
+        assert np.allclose(ref_first[s][3], want[s][3], rtol=1e-8, atol=1e-9), (s, np.abs(ref_first[s][3] - want[s][3]).max())
+    assert want[0][2] > 200, "scan 0 must match points in the cut voxels"
+    for name in ("grid", "grid+xid"):
+        for which, (a, b) in (("first", (results[name][0], ref_first)), ("second", (results[name][1], ref_second))):
+            for s in range(S):
+                assert a[s][:3] == b[s][:3], (name, which, s, a[s][:3], b[s][:3])
+                assert np.array_equal(a[s][3], b[s][3]), (name, which, s, np.abs(a[s][3] - b[s][3]).max())
+    assert any(ref_first[s][2] != ref_second[s][2] for s in range(S)), "the inserted scan must have changed what the batch matches"
+    o.close()
+
+
 def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     """lk_batch_replay_ragged_dev: scans of different sizes, bucket tables and start times in one batch (what a recorded
     run looks like) - each must come out as the oracle's own bucket loop over that scan alone; on equally shaped scans the
