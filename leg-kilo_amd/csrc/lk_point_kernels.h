@@ -16,6 +16,10 @@
 #include "lk_device.h"
 
 #define LK_PB 256
+#ifndef LK_ROWS_AT_TAKE
+#define LK_ROWS_AT_TAKE 1   // a matched lane writes its final LDS row [h z | h/R | R 1] when it takes its plane: no LDS read-back before K3
+                            // (0 = park the raw row and finish it after the matching; A/B: 1.798 -> 1.775 ms per step, same bits)
+#endif
 #ifndef LK_MFMA_RED
 #define LK_MFMA_RED 0   // 1: the per-tile normal-equation sums on v_mfma_f64_4x4x4 (A/B build; see residual_tile)
 #endif
@@ -106,7 +110,17 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
         r[0] = t.w.x, r[1] = t.w.y, r[2] = t.w.z;
         r[3] = n.x, r[4] = n.y, r[5] = n.z;
         r[6] = -(double)(float)sd;  // z = -dis_to_plane_, the signed distance stored as float (voxel_map.h:92, .cc:401-402)
+#if LK_ROWS_AT_TAKE
+        // the row in its final form [h z | h/R | R 1] right here: nothing is read back from LDS before the reduction
+        const double Rv = pr.lidar_ratio * sig_r;   // KILO.cc:205-206
+        const double ri = 1.0 / Rv;
+        r[7] = t.w.x * ri, r[8] = t.w.y * ri, r[9] = t.w.z * ri;
+        r[10] = n.x * ri, r[11] = n.y * ri, r[12] = n.z * ri;
+        r[13] = Rv;
+        r[14] = 1.0;
+#else
         r[13] = sig_r;              // J_nq plane_var J_nq^T + n^T (R ext_R) body_cov (R ext_R)^T n (KILO.cc:205-206, before lidar_ratio)
+#endif
     }
 }
 
@@ -299,6 +313,15 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             }
         }
         ok = success;
+#if LK_ROWS_AT_TAKE
+        if (EMIT_ROWS && ok) {
+            const double* r = best.row;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) h[a] = r[a];
+            z = r[6];
+            R = r[13];
+        }
+#else
         if (ok) {  // KILO.cc:195-209: h (1x6), z, R for the matched point, from the parked row
             const double* r = best.row;
 #pragma unroll
@@ -306,6 +329,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             z = r[6];
             R = pr.lidar_ratio * r[13];  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
         }
+#endif
         if (EMIT_ROWS && i < n) {
             size_t o = out_base + i;
             out.valid[o] = ok ? 1 : 0;
@@ -320,6 +344,13 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
     // of [A(21) b(6) sumR count] over the 32 rows of its half, in row order, branch-free and with ONE fma per row
     // (ds_read_b64 broadcasts, all loads independent of the arithmetic); the two halves are combined with one
     // cross-lane read.
+#if LK_ROWS_AT_TAKE
+    if (!ok) {   // matched lanes wrote their final row when they took their plane
+        double* r = rows + lane * LK_ROW2;
+#pragma unroll
+        for (int a = 0; a < LK_ROW2; ++a) r[a] = 0.0;
+    }
+#else
     {
         double* r = rows + lane * LK_ROW2;
         const double ri = ok ? 1.0 / R : 0.0;
@@ -331,6 +362,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         r[13] = ok ? R : 0.0;
         r[14] = ok ? 1.0 : 0.0;
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -846,6 +846,26 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
         assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
         if po.n_buckets > 100:
             assert not np.array_equal(xg, res[0][0][s][0])   # the IMU updates did change the outcome
+    # a process noise with off-diagonal terms (the scan-resident wave has a fast path for the diagonal Q of initProcessCovQ)
+    Qn = o.get_Q().copy()
+    Qn[6, 7] = Qn[7, 6] = 3.0
+    Qn[18, 21] = Qn[21, 18] = 40.0
+    o.set_Q(Qn)
+    g.set_Q(Qn)
+    ps = g.batch_replay_ragged(small_scans[:3], small_tb[:3], small_x[:3], small_P[:3])
+    for s in range(3):
+        o.set_state(small_x[s], small_P[s])
+        o.set_times(small_tb[s], small_tb[s])
+        po, _ = o.process_scan(small_scans[s], small_tb[s])
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (ps[s].n_buckets, ps[s].n_updates, ps[s].n_effect), s
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+        assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+        if po.n_buckets > 1:   # a one-bucket scan starts at its bucket's time: dt = 0, Q does not enter
+            assert not np.array_equal(Pg, res[0][0][s][1])
+    o.init_process_cov_q()
+    g.init_process_cov_q()
     # equally shaped scans: ragged == uniform, bit for bit
     uni = [synth.dense_scan(scene.world, scene.traj, t0 + 2.0 + 0.1 * s, scene.P, n=4000, n_buckets=5, seed_scan=8400 + s, seed_noise=8500 + s)
            for s in range(3)]
