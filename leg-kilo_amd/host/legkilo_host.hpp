@@ -336,13 +336,18 @@ class KiloPath {
     // Many recorded scans at once against the CURRENT map, frozen (lk_batch_replay_ragged(_imu)_dev): scan s runs the bucket
     // loop of KILO::process (KILO.cc:375-395) on filter slot s from its own prior; buckets are the runs of equal curvature
     // of each time-sorted scan (KILO.cc:376-378), t_begin[s] its start time; `imus` (optional, one time-sorted vector per
-    // scan) are applied between the buckets as in only_imu_use mode.  n scans need DeviceCaps::n_slots >= n.
+    // scan) are applied between the buckets as in only_imu_use mode (KILO.cc:379-383), `kins` as in the default leg-fusion
+    // mode (KILO.cc:384-390); at most one of the two.  n scans need DeviceCaps::n_slots >= n.
     std::vector<lk_pose> replayRecordedRun(const std::vector<PointCloudType>& sorted_scans, const std::vector<double>& t_begin,
                                            const std::vector<State>& prior_states, const std::vector<StateCov>& prior_covs,
-                                           const std::vector<std::vector<lk_imu>>* imus = nullptr) {
+                                           const std::vector<std::vector<lk_imu>>* imus = nullptr,
+                                           const std::vector<std::vector<lk_kin_imu>>* kins = nullptr) {
         const size_t S = sorted_scans.size();
-        if (t_begin.size() != S || prior_states.size() != S || prior_covs.size() != S || (imus && imus->size() != S))
+        if (t_begin.size() != S || prior_states.size() != S || prior_covs.size() != S || (imus && imus->size() != S) ||
+            (kins && kins->size() != S))
             throw std::runtime_error("replayRecordedRun: one start time, prior state and prior covariance per scan");
+        if (imus && kins) throw std::runtime_error("replayRecordedRun: IMU messages or kinematic + IMU messages, not both");
+        std::vector<lk_kin_imu> kin_flat;
         std::vector<lk_point> pts;
         std::vector<uint64_t> scan_off(1, 0);
         std::vector<uint32_t> n_buckets, bucket_off, n_imu;
@@ -368,13 +373,20 @@ class KiloPath {
                 n_imu.push_back((uint32_t)(*imus)[s].size());
                 imu_flat.insert(imu_flat.end(), (*imus)[s].begin(), (*imus)[s].end());
             }
+            if (kins) {
+                n_imu.push_back((uint32_t)(*kins)[s].size());
+                kin_flat.insert(kin_flat.end(), (*kins)[s].begin(), (*kins)[s].end());
+            }
         }
         void* d_pts = nullptr;
         dev_->check(lk_device_malloc(dev_->h(), &d_pts, sizeof(lk_point) * std::max<size_t>(pts.size(), 1)));
         std::vector<lk_pose> out(S);
         int rc = lk_memcpy_h2d(dev_->h(), d_pts, pts.data(), sizeof(lk_point) * pts.size());
         if (!rc) rc = lk_batch_set_priors(dev_->h(), x36.data(), P900.data(), S);
-        if (!rc)
+        if (!rc && kins)
+            rc = lk_batch_replay_ragged_kin_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
+                                                bucket_off.data(), bucket_dt.data(), t_begin.data(), n_imu.data(), kin_flat.data(), out.data());
+        else if (!rc)
             rc = imus ? lk_batch_replay_ragged_imu_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
                                                        bucket_off.data(), bucket_dt.data(), t_begin.data(), n_imu.data(), imu_flat.data(),
                                                        out.data())
