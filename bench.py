@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--sustained-s", type=float, default=1.2, help="length of the sustained run reported in extra (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (slot ranges / streams they rotate over: 2 or 3; 3 gains 2 % in steady state - 1.753 vs 1.789 ms at 60 steps - and loses it to the longer drain of a 20-step region)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes generating the synthetic scans (0 = auto)")
     ap.add_argument("--cache-dir", default="", help="keep generated inputs here between runs of one session (profiling passes)")
     args = ap.parse_args()
@@ -247,7 +248,7 @@ def main():
 
     # capacities sized to the scene (a 40 x 30 x 8 m room has ~20 k root voxels)
     mr = args.max_roots_log2
-    cfg = config.make_config(P, device_id=local_rank, n_slots=2 * S_max, max_roots=1 << mr, max_nodes=1 << (mr + 1),
+    cfg = config.make_config(P, device_id=local_rank, n_slots=max(2, args.in_flight) * S_max, max_roots=1 << mr, max_nodes=1 << (mr + 1),
                              max_point_blocks=1 << 17, max_scan_points=1 << 17)
     g = binding.LegKiloHip(cfg)  # raises without the HIP library / a gfx950 device
 
@@ -291,8 +292,8 @@ def main():
     ring = torch.empty((ring_rows, S * pose_sz), dtype=torch.uint8).pin_memory()
 
     def step(k):
-        g.batch_replay_async_dev(d_batch.data_ptr(), (k & 1) * S_max, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(), d_P900=d_P.data_ptr(),
-                                 host_out_ptr=ring[k % ring_rows].data_ptr())
+        g.batch_replay_async_dev(d_batch.data_ptr(), (k % max(2, args.in_flight)) * S_max, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(),
+                                 d_P900=d_P.data_ptr(), host_out_ptr=ring[k % ring_rows].data_ptr())
 
     def finish(k_steps):
         g.synchronize()

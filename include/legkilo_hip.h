@@ -301,8 +301,8 @@ int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
 /* Asynchronous, double-buffered variant: the batch uses filter slots [first_slot, first_slot + n_scans); batches whose
- * slot ranges alternate (first_slot = 0, n_scans, 0, ...) run on alternate streams, so the latency-bound update / predict
- * kernels of one batch overlap the residual launches of the next.  d_x36 / d_P900 (device, n_scans x 36 / 900; both NULL =
+ * slot ranges rotate (first_slot = 0, n_scans, [2 n_scans,] 0, ...) run on up to three streams, so the latency-bound update / predict
+ * kernels of one batch overlap the residual launches of the others.  d_x36 / d_P900 (device, n_scans x 36 / 900; both NULL =
  * keep the slots' state) arm the priors on the batch's own stream; the poses are copied into host_out (n_scans records;
  * PINNED host memory for a truly asynchronous copy; may be NULL).  Nothing synchronises: lk_synchronize() completes all
  * enqueued batches.  Buffers must stay valid / untouched until then. */

@@ -1818,7 +1818,10 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
         const int rc = frozen_map(h, &fmap);   // synchronises once per map snapshot (grid rebuild), otherwise free
         if (rc) return rc;
     }
-    hipStream_t st = ((first_slot / (uint32_t)n_scans) & 1u) ? h->side[0] : h->stream;
+    // batches on slot ranges 0, n, 2n, ... rotate over up to three streams (the handle's + two side streams): with three batches in
+    // flight there is (almost) always a residual launch ready while the other two sit in their update / predict launches
+    const uint32_t ring = (first_slot / (uint32_t)n_scans) % 3u;
+    hipStream_t st = ring == 0 ? h->stream : h->side[ring - 1];
     LkFilter* fl = h->d_filters + first_slot;
     double* parts = h->d_partials + (size_t)first_slot * h->part_stride;
     if (st != h->stream && !d_x36) {

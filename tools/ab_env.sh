@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of environment switches / library builds on the batch step:  tools/ab_env.sh "LEGKILO_GRID=0" "LEGKILO_GRID=1" "LEGKILO_HIP_LIB=$PWD/leg-kilo_amd/lib_x.so" ...
 # Each variant runs bench.py (1024 distinct scans, generated once and cached under /tmp for the session) with the extras off.
-ARGS="--steps 20 --warmup 3 --cpu-sample ${AB_CPU_SAMPLE:-0} --stream-scans 0 --config1-scans 0 --no-pcie --sustained-s 0 --cache-dir /tmp/lkcache"
+ARGS="${AB_EXTRA:-} --steps ${AB_STEPS:-20} --warmup 3 --cpu-sample ${AB_CPU_SAMPLE:-0} --stream-scans 0 --config1-scans 0 --no-pcie --sustained-s 0 --cache-dir /tmp/lkcache"
 for v in "$@"; do
   for rep in 1 2; do
     env $v python bench.py $ARGS 2>/dev/null > /tmp/ab_env.json
