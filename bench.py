@@ -143,8 +143,11 @@ def build_map(obj, traj, P, first, warm, warm_t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 30 untimed + 40 timed steps (~0.12 s of GPU time).  A region this short is sensitive to where the clocks are when it
+    # starts: after the idle set-up phase 3 warm-up steps (5 ms) leave ~1.7 ms of ramp inside a 20-step region (1.775 vs 1.69 ms per
+    # step; `--step-sweep`: elapsed(K) = 0.15 + 1.685 K ms once warm); `extra.sustained_*` is the >= 1 s figure
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scans-per-gpu", type=int, default=1024, help="weak scaling: a batch of 1024 scans per GPU (fits one GPU)")
     ap.add_argument("--total-scans", type=int, default=0, help="strong scaling: this many scans in total, block-sharded over the GPUs "
                     "(BASELINE config 5 as worded: 1024 -> 128 per GPU at N=8); 0 = weak scaling")
@@ -158,6 +161,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (slot ranges / streams they rotate over: 2 or 3; 3 gains 2 % in steady state - 1.753 vs 1.789 ms at 60 steps - and loses it to the longer drain of a 20-step region)")
+    ap.add_argument("--step-sweep", action="store_true", help="also time regions of 1..64 steps (extra.step_sweep_ms)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes generating the synthetic scans (0 = auto)")
     ap.add_argument("--cache-dir", default="", help="keep generated inputs here between runs of one session (profiling passes)")
     args = ap.parse_args()
@@ -342,6 +346,18 @@ def main():
         extra["sustained_scans_per_s"] = round((args.total_scans if strong else S * world_size) * n_sus / sus, 1)
         extra["sustained_steps"] = n_sus
         extra["sustained_seconds"] = round(sus, 3)
+
+    if args.step_sweep:   # diagnostic: fixed cost (ramp + drain) vs per-step cost of a timed region, elapsed(K) = a + b K
+        sweep = {}
+        for K in (1, 2, 4, 8, 16, 32, 64):
+            sync_all()
+            ts = time.perf_counter()
+            for k in range(K):
+                step(k)
+            finish(min(K, ring_rows))
+            sync_all()
+            sweep[K] = round((time.perf_counter() - ts) * 1e3, 3)
+        extra["step_sweep_ms"] = sweep
 
     # ---- kernel-level timing pass (HIP events on the handle's stream, whole-batch launches on ONE stream), outside the timed region
     g.profile_reset()

@@ -1235,11 +1235,24 @@ __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned i
 // ---- frozen-map grid (LkMap::grid): bounding box of the root keys, then one cell per root
 __global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned int n_hash, int* __restrict__ mm /* min xyz, max xyz */) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_hash) return;
-    const int4 e = map.hash[i];
-    if (e.w < 0) return;
-    atomicMin(&mm[0], e.x), atomicMin(&mm[1], e.y), atomicMin(&mm[2], e.z);
-    atomicMax(&mm[3], e.x), atomicMax(&mm[4], e.y), atomicMax(&mm[5], e.z);
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    if (i < n_hash) {
+        const int4 e = map.hash[i];
+        if (e.w >= 0) lo[0] = hi[0] = e.x, lo[1] = hi[1] = e.y, lo[2] = hi[2] = e.z;
+    }
+    // one set of atomics per wave, not per occupied slot (all of them hit the same six words)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = min(lo[c], __shfl_xor(lo[c], o, LK_WAVE));
+            hi[c] = max(hi[c], __shfl_xor(hi[c], o, LK_WAVE));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && lo[0] <= hi[0]) {
+        atomicMin(&mm[0], lo[0]), atomicMin(&mm[1], lo[1]), atomicMin(&mm[2], lo[2]);
+        atomicMax(&mm[3], hi[0]), atomicMax(&mm[4], hi[1]), atomicMax(&mm[5], hi[2]);
+    }
 }
 // One thread per root: a plane root's record goes into its cell; any other root gets a list header and its subtree's plane
 // nodes, in pre-order (children in index order, a plane is not descended into, nothing below max_layer), appended behind the
