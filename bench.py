@@ -293,7 +293,8 @@ def main():
     # the timed region ends with everything synchronised and, for N > 1, the poses of all steps all-gathered.
     pose_sz = _abi.pose_dtype().itemsize
     ring_rows = max(args.steps, args.warmup, 2)
-    ring = torch.empty((ring_rows, S * pose_sz), dtype=torch.uint8).pin_memory()
+    ring = torch.zeros((ring_rows, S_max * pose_sz), dtype=torch.uint8).pin_memory()   # S_max columns: equal bytes on every rank
+    gathered = [None]
 
     def step(k):
         g.batch_replay_async_dev(d_batch.data_ptr(), (k % max(2, args.in_flight)) * S_max, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(),
@@ -301,9 +302,8 @@ def main():
 
     def finish(k_steps):
         g.synchronize()
-        if dist is not None:
-            rows = replay.pose_rows(ring[:min(k_steps, ring_rows)].numpy().reshape(-1).view(_abi.pose_dtype()))
-            replay.gather_results(dist, rows, world_size, dev)
+        if dist is not None:   # every step's poses of every rank, all-gathered as raw records; the result stays on the device
+            gathered[0] = replay.gather_pose_bytes(dist, ring[:min(k_steps, ring_rows)], world_size, dev)
 
     def sync_all():
         g.synchronize()
@@ -326,7 +326,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    timed_last = ring[(args.steps - 1) % ring_rows].numpy().view(_abi.pose_dtype()).copy()   # what the timed loop delivered
+    timed_last = ring[(args.steps - 1) % ring_rows][: S * pose_sz].numpy().view(_abi.pose_dtype()).copy()   # what the timed loop delivered
+    gather_ok = None
+    if dist is not None:   # untimed: the gathered records are what every rank delivered (rank r's last step == its own ring row)
+        rec = gathered[0].cpu().numpy().reshape(world_size, -1, S_max * pose_sz)
+        mine = rec[rank, (args.steps - 1) % ring_rows, : S * pose_sz].view(_abi.pose_dtype())
+        gather_ok = bool(np.array_equal(mine["pos"], timed_last["pos"]) and all(
+            (rec[r, (args.steps - 1) % ring_rows].view(_abi.pose_dtype())["n_buckets"][:1] == N_BUCKETS).all() for r in range(world_size)))
     n_eff = float(timed_last["n_effect"].astype(np.float64).mean())
     total_scans = (args.total_scans if strong else S * world_size) * args.steps
     value = total_scans / elapsed
@@ -410,7 +416,7 @@ def main():
     }
 
     extra.update({"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
-                  "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "rccl_map_broadcast_ms": bcast_ms,
+                  "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok, "rccl_map_broadcast_ms": bcast_ms,
                   "rccl_map_scatter_allgather_ms": bcast2_ms})
     # ---- extra: the same batch step when the scans start in (pinned) host memory: upload of batch k+1 on a copy stream under
     # the replay of batch k (the boundary also takes host buffers; this rate is never `value`)

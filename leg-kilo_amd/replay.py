@@ -102,6 +102,20 @@ def gather_results(dist, local, world, device):
     return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)
 
 
+def gather_pose_bytes(dist, local_bytes, world, device):
+    """All-gather the raw lk_pose records of a replay (a uint8 tensor, e.g. the pinned ring the asynchronous batch entry
+    writes its poses to; the same number of bytes on every rank) and leave the result ON THE DEVICE: [world, n_bytes] uint8.
+    Nothing is converted or copied back here - that is the caller's business outside any timed region."""
+    import torch
+
+    t = local_bytes.reshape(-1).to(device, non_blocking=True)
+    if world == 1:
+        return t.reshape(1, -1)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return torch.stack(out)
+
+
 def pose_rows(poses):
     """lk_pose records (a ctypes array, or any buffer / numpy array of abi.pose_dtype()) -> float64 rows
     [pos(3), vel(3), rot(9), n_effect, n_buckets, n_updates]; vectorised (a 1024-scan batch per step)."""

@@ -113,6 +113,10 @@ def _worker(rank, world, port, algo, q):
     local = np.array([[float(i), float(i) * 0.5, float(rank)] for i in range(start, stop)])
     allr = replay.gather_results(dist, local, world, dev)
     ok_gather = allr.shape == (11, 3) and np.array_equal(allr[:, 0], np.arange(11.0))
+    # raw pose records (what bench.py gathers inside its timed region): every rank gets every rank's bytes, in rank order
+    mine = torch.full((3, 136 * 4), rank + 1, dtype=torch.uint8)
+    allb = replay.gather_pose_bytes(dist, mine, world, dev)
+    ok_gather = ok_gather and tuple(allb.shape) == (world, 3 * 136 * 4) and all(int(allb[r].min()) == int(allb[r].max()) == r + 1 for r in range(world))
     q.put((rank, bool(ok_blob), bool(ok_gather)))
     dist.destroy_process_group()
 
