@@ -505,6 +505,70 @@ __global__ void __launch_bounds__(LK_FB)
     dev_update_from_totals(f, sm, tot, t);
 }
 
+#ifdef LK_DEBUG_PHASES
+// DEBUG BUILD ONLY (-DLK_DEBUG_PHASES): the whole small bucket in one workgroup with cycle stamps per phase, to see where a
+// bucket's ~30 us go.  dbg[0..9] accumulate s_memtime deltas (100 MHz constant clock), dbg[15] counts buckets.
+__device__ __forceinline__ void phase_fence() {
+    __threadfence();
+    __syncthreads();
+}
+__global__ void __launch_bounds__(LK_FB)
+    lk_small_bucket_dbg_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, double t,
+                               const lk_point* __restrict__ pts, int n, float* world, int do_insert, unsigned long long* dbg) {
+    __shared__ FilterSmem sm;
+    __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
+    __shared__ double red[LK_FB / LK_WAVE][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    LkFilter* f = &filters[0];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long t0 = wall_clock64(), t1;
+#define STAMP(k) do { __syncthreads(); t1 = wall_clock64(); if (tid == 0) dbg[k] += t1 - t0; t0 = t1; } while (0)
+    dev_bucket_begin(map);
+    STAMP(0);
+    dev_predict(f, Q, t, sm);
+    STAMP(1);
+    {
+        BucketConst bc;
+        load_bucket_const<false>(f, pr, bc);
+        ResidualOut ro;
+        ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = world;
+        double acc = 0.0;
+        for (int base = wv * LK_WAVE; base < n; base += LK_FB) {
+            __builtin_amdgcn_wave_barrier();
+            acc += residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
+        }
+        if (lane < LK_NPART) red[wv][lane] = (lane < 29) ? acc : 0.0;
+    }
+    __syncthreads();
+    if (tid < LK_NPART) {
+        double s = 0.0;
+        for (int w = 0; w < LK_FB / LK_WAVE; ++w) s += red[w][tid];
+        tot[tid] = s;
+    }
+    STAMP(2);
+    dev_update_from_totals(f, sm, tot, t);
+    STAMP(3);
+    phase_fence();
+    STAMP(4);
+    for (int i = tid; i < n; i += LK_FB) dev_reproject_point(map, pr, filters, pts, world, do_insert, i);
+    STAMP(5);
+    phase_fence();
+    {
+        const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = tid; r < n_touched; r += LK_FB) dev_insert_light_root(map, pr, filters, pts, r);
+    }
+    STAMP(6);
+    phase_fence();
+    dev_insert_group<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, wv, LK_FB / LK_WAVE);
+    STAMP(7);
+    phase_fence();
+    dev_insert_apply<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, wv, LK_FB / LK_WAVE);
+    STAMP(8);
+    if (tid == 0) dbg[15] += 1;
+#undef STAMP
+}
+#endif
+
 // Ragged batch of SMALL buckets (a real scan: 2 ms time bins of tens of points): the whole bucket chain of a scan - predict,
 // residual tiles, update, predict, ... - as ONE WAVE in one launch.  State and covariance stay in LDS from the first
 // predict to the last update (WaveSmem), the bucket totals never leave the registers, and there is no launch boundary
@@ -618,6 +682,29 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     if (do_insert) h->grid_valid = false;   // the map changes: batch replay rebuilds its root grid
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
+#ifdef LK_DEBUG_PHASES
+    if (n <= LK_SMALL_MAX && do_insert) {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) {
+            hipMalloc(&dbg, 16 * sizeof(unsigned long long));
+            hipMemset(dbg, 0, 16 * sizeof(unsigned long long));
+        }
+        hipLaunchKernelGGL(lk_small_bucket_dbg_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters, h->d_Q, t, d_pts, n, d_world, 1, dbg);
+        LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                        h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+        static int calls = 0;
+        if (++calls % 3000 == 0) {
+            unsigned long long hb[16];
+            hipStreamSynchronize(h->stream);
+            hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+            const char* names[9] = {"bucket_begin", "predict", "residual", "update", "fence", "reproject", "light", "group", "apply"};
+            fprintf(stderr, "[phases] %llu buckets:", hb[15]);
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.2f us;", names[k], (double)hb[k] / (double)hb[15] * 0.01);
+            fprintf(stderr, "\n");
+        }
+        return LK_OK;
+    }
+#endif
     if (n <= LK_SMALL_MAX) {
         LAUNCH(h, "small_bucket", hipLaunchKernelGGL(lk_small_bucket_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
                                                      h->d_Q, t, d_pts, n, d_world));
