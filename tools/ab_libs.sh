@@ -5,6 +5,6 @@ for v in "$@"; do
   python - "$v" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab_lib.json").read().strip().splitlines()[-1])
-print(sys.argv[1], "scans/s", d["value"], "ms/step", d["ms_per_step"], "residual_ms", d["roofline"]["avg_launch_ms"], "n_eff", d["extra"]["mean_n_effect"])
+print(sys.argv[1], "scans/s", d["value"], "ms/step", d["ms_per_step"], "residual_ms", d["roofline"]["launch_ms_single_stream_events"], "n_eff", d["extra"]["mean_n_effect"])
 PY
 done

@@ -6,7 +6,7 @@ for s in ${SLOTS_LIST:-32 64 128 256 512}; do
 import json, sys
 d = json.loads(open("/tmp/ab_s.json").read().strip().splitlines()[-1])
 r = d["roofline"]
-print("slots", sys.argv[1], "scans/s", d["value"], "ms/step", d["ms_per_step"], "residual_us", round(r["avg_launch_ms"] * 1e3, 1),
-      "ps/pt", round(r["avg_launch_ms"] * 1e9 / r["points_per_launch"], 2), "other", r["other_kernels_ms"])
+print("slots", sys.argv[1], "scans/s", d["value"], "ms/step", d["ms_per_step"], "residual_us", round(r["launch_ms_single_stream_events"] * 1e3, 1),
+      "ps/pt", round(r["launch_ms_single_stream_events"] * 1e9 / r["points_per_launch"], 2), "other", r["other_kernels_ms"])
 PY
 done
