@@ -749,6 +749,10 @@ static int frozen_map(lk_handle* h, LkMap* out) {
     out->grid_on = 0;
     if (!h->grid_enable) return LK_OK;
     if (!h->grid_valid) {
+        // the rebuild rewrites the cells (and may move the match pool): nothing enqueued earlier - on any of the handle's streams -
+        // may still be reading them
+        for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
+            if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));
         const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
         int mm[6];
         HIPCHK(h, hipMemcpyAsync(h->d_grid_mm, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
