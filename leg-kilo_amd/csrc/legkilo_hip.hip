@@ -474,6 +474,8 @@ __global__ void __launch_bounds__(LK_FB) lk_begin_predict_kernel(LkMap map, LkFi
 // over the workgroup's four waves (same residual_tile code as lk_residual_kernel); wave partials are combined in a
 // fixed order.
 #define LK_SMALL_MAX 512
+}  // extern "C" (the kernel below is a template)
+template <bool XID>
 __global__ void __launch_bounds__(LK_FB)
     lk_small_bucket_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, double t,
                            const lk_point* __restrict__ pts, int n, float* world) {
@@ -492,7 +494,7 @@ __global__ void __launch_bounds__(LK_FB)
     double acc = 0.0;
     for (int base = wv * LK_WAVE; base < n; base += LK_FB) {
         __builtin_amdgcn_wave_barrier();  // the previous tile's reads of this wave's rows are complete
-        acc += residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
+        acc += residual_tile<false, 0, XID>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
     }
     if (lane < LK_NPART) red[wv][lane] = (lane < 29) ? acc : 0.0;
     __syncthreads();
@@ -504,6 +506,7 @@ __global__ void __launch_bounds__(LK_FB)
     __syncthreads();
     dev_update_from_totals(f, sm, tot, t);
 }
+extern "C" {
 
 #ifdef LK_DEBUG_PHASES
 // DEBUG BUILD ONLY (-DLK_DEBUG_PHASES): the whole small bucket in one workgroup with cycle stamps per phase, to see where a
@@ -705,8 +708,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         return LK_OK;
     }
 #endif
+    // the stream path's residual code specialised for ext_R == I like the batch kernel (LEGKILO_XID=0: generic)
+    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const bool xid = h->pr.ext_identity && xid_enable;
     if (n <= LK_SMALL_MAX) {
-        LAUNCH(h, "small_bucket", hipLaunchKernelGGL(lk_small_bucket_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
+        const auto small_kernel = xid ? lk_small_bucket_kernel<true> : lk_small_bucket_kernel<false>;
+        LAUNCH(h, "small_bucket", hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
                                                      h->d_Q, t, d_pts, n, d_world));
     } else {
         // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
@@ -714,8 +721,9 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         ResidualOut ro;
         memset(&ro, 0, sizeof(ro));
         ro.world = d_world;
+        const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
         LAUNCH(h, "residual",
-               hipLaunchKernelGGL(lk_residual_kernel<false>, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
+               hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
                                   d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
                                                h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));

@@ -320,6 +320,16 @@ __device__ __forceinline__ PointGeom point_geom(float bx, float by, float bz, co
     return g;
 }
 
+// The world point alone (KILO.cc:219-222), by the very expressions of point_geom / point_lite: the re-projection only hashes
+// the point and writes it out - the covariance is needed by the insert passes, which derive it themselves.
+__device__ __forceinline__ V3 point_world(float bx, float by, float bz, const BucketConst& bc, const LkParams& pr) {
+    V3 pb = V3{(double)bx, (double)by, (double)bz};
+    V3 e = mat3_mul_v(pr.ext_R, pb);
+    V3 p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
+    V3 w = mat3_mul_v(bc.R, p_i);
+    return V3{w.x + bc.p[0], w.y + bc.p[1], w.z + bc.p[2]};
+}
+
 // Residual-side point geometry: what lk_residual_kernel needs of KILO.cc:126-140 WITHOUT materialising the 3x3
 // covariances.  The matcher and the observation row only ever consume  n^T var n  for a candidate normal n
 // (voxel_map.cc:384-388, KILO.cc:205-206), and with body_cov = alpha d d^T + beta I (calc_body_cov above),

@@ -208,6 +208,7 @@ __device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, lk_match_rec* mr, 
 // plane_var accumulation, so that a chain of refit events inside one bucket costs one full fit, not one per event.
 struct PlaneFit {
     bool is_plane;
+    double s9[9];   // the moment sums (sum p, sum p p^T) the fit was made from: the full fit of a leaf reuses those of its last event
     double c[3];
     double emin, emid, emax;
     double vmin[3], vmid[3], vmax[3];
@@ -217,19 +218,27 @@ struct PlaneFit {
 // (Sylvester).  Used for the refit events in the middle of a bucket, whose eigenvectors nobody ever reads; differs
 // from the Jacobi decision only when lambda_min equals the threshold to rounding.
 template <bool decide_only = false>
-__device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool active, int count, float planer_threshold) {
+__device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool active, int count, float planer_threshold,
+                                                    const double* reuse_s9 = nullptr) {
     double s[9];
+    if (reuse_s9) {   // same points, same count as the event these sums come from: the nine wave reductions are not repeated
 #pragma unroll
-    for (int q = 0; q < 9; ++q) s[q] = 0.0;
-    if (active) {
-        s[0] += pw[0], s[1] += pw[1], s[2] += pw[2];
-        s[3] += pw[0] * pw[0], s[4] += pw[0] * pw[1], s[5] += pw[0] * pw[2];
-        s[6] += pw[1] * pw[1], s[7] += pw[1] * pw[2], s[8] += pw[2] * pw[2];
+        for (int q = 0; q < 9; ++q) s[q] = reuse_s9[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s[q] = 0.0;
+        if (active) {
+            s[0] += pw[0], s[1] += pw[1], s[2] += pw[2];
+            s[3] += pw[0] * pw[0], s[4] += pw[0] * pw[1], s[5] += pw[0] * pw[2];
+            s[6] += pw[1] * pw[1], s[7] += pw[1] * pw[2], s[8] += pw[2] * pw[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s[q] = wave_sum(s[q]);
     }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) s[q] = wave_sum(s[q]);
     const double n = (double)count;
     PlaneFit f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) f.s9[q] = s[q];
     f.c[0] = s[0] / n, f.c[1] = s[1] / n, f.c[2] = s[2] / n;
     double cov[6] = {s[3] / n - f.c[0] * f.c[0], s[4] / n - f.c[0] * f.c[1], s[5] / n - f.c[0] * f.c[2],
                      s[6] / n - f.c[1] * f.c[1], s[7] / n - f.c[1] * f.c[2], s[8] / n - f.c[2] * f.c[2]};
@@ -850,7 +859,10 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
                 if (fitted) {
                     // the one full fit of this leaf in this bucket: the state of its LAST refit event
                     const bool decided = fit.is_plane;
-                    fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold);
+                    double s9[9];   // the last event tested exactly these fit_count points
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) s9[q] = fit.s9[q];
+                    fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold, s9);
                     fit.is_plane = decided;  // control flow above already followed the event's decision
                     double acc21[21];
                     if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);

@@ -552,9 +552,10 @@ __device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkPa
                                                     const int do_insert, const int i) {
     const LkFilter* f = &filters[0];
     BucketConst bc;
-    load_bucket_const(f, pr, bc);
+    load_bucket_const<false>(f, pr, bc);   // R, p only matter here (no R * ext_R product, no covariance blocks used)
     const float4 p = reinterpret_cast<const float4*>(pts)[i];
-    PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
+    struct { V3 p_w; } g;
+    g.p_w = point_world(p.x, p.y, p.z, bc, pr);
     if (world && f->updated) {
         reinterpret_cast<float4*>(world)[i] = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 255.f);
     }
