@@ -476,6 +476,20 @@ def main():
             poses1 = run_c1()
         el1 = (time.perf_counter() - tc) / 3
         p1 = np.frombuffer(poses1, dtype=_abi.pose_dtype())
+        # the same batch with the bucket tables built on the device (lk_batch_replay_scans_dev): no host-side table work at all
+        def run_c1_dev():
+            g.batch_set_priors_dev(d_x1.data_ptr(), d_P1.data_ptr(), S1)
+            return g.batch_replay_scans_dev(d_c1.data_ptr(), scan_off, tbs1)
+
+        run_c1_dev()
+        tc = time.perf_counter()
+        for _ in range(3):
+            poses1d = run_c1_dev()
+        el1d = (time.perf_counter() - tc) / 3
+        p1d = np.frombuffer(poses1d, dtype=_abi.pose_dtype())
+        extra["config1_scans_dev_ms_per_batch"] = round(el1d * 1e3, 2)
+        extra["config1_scans_dev_scans_per_s"] = round(S1 / el1d, 1)
+        extra["config1_scans_dev_equals_host_tables"] = bool(np.array_equal(p1d["pos"], np.frombuffer(poses1, dtype=_abi.pose_dtype())["pos"]))
         extra["config1_ragged_scans_per_s"] = round(S1 / el1, 1)
         extra["config1_ragged_ms_per_batch"] = round(el1 * 1e3, 2)
         extra["config1_batch"] = int(S1)

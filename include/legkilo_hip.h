@@ -335,6 +335,14 @@ int lk_batch_replay_ragged_kin_dev(lk_handle* h, const lk_point* d_pts, size_t n
                                    const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
                                    const double* t_begin, const uint32_t* n_kin, const lk_kin_imu* kins, lk_pose* out);
 
+/* Recorded-run replay without host-side bucket tables: scan s = d_pts[scan_off[s] .. scan_off[s+1]) (time-sorted, scan_off: n_scans + 1
+ * entries, first 0), start time t_begin[s]; the buckets - runs of exactly equal curvature, KILO.cc:375-378 - are found on the
+ * device.  msg_kind 0: no messages; 1: n_msg[s] lk_imu records per scan (only_imu_use, KILO.cc:379-383); 2: lk_kin_imu records
+ * (leg fusion, KILO.cc:384-390), concatenated in `msgs`.  Equivalent to lk_batch_replay_ragged(_imu/_kin)_dev on tables built
+ * from the same scans. */
+int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const double* t_begin,
+                              int msg_kind, const uint32_t* n_msg, const void* msgs, lk_pose* out);
+
 /* ---- measurement hooks ---- */
 int lk_profile_enable(lk_handle* h, int on);                           /* HIP-event timing around each kernel */
 int lk_profile_get(lk_handle* h, const char* kernel, uint64_t* launches, double* total_ms);

@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream",
 ]
 
@@ -372,19 +372,41 @@ class LegKiloHip:
                                                         _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]), poses))
         return poses
 
-    def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None, imus=None, kins=None):
+    def batch_replay_scans_dev(self, d_pts, scan_off, t_begins, imus=None, kins=None, want_poses=True):
+        """Ragged batch on slots [0, n_scans) with the bucket tables built ON THE DEVICE (lk_batch_replay_scans_dev): the host
+        passes the scans' offsets and start times only.  imus / kins: per-scan message arrays (or None)."""
+        so = np.ascontiguousarray(scan_off, dtype=np.uint64)
+        n_scans = len(so) - 1
+        tb = _f64(t_begins)
+        assert len(tb) == n_scans and not (imus is not None and kins is not None)
+        kind, n_msg, flat = 0, None, None
+        msgs = imus if imus is not None else kins
+        if msgs is not None:
+            kind = 1 if imus is not None else 2
+            n_msg = np.fromiter((len(m) for m in msgs), dtype=np.uint32, count=n_scans)
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(m) for m in msgs])) if n_msg.sum() else np.zeros(1, dtype=np.float64)
+        poses = (abi.lk_pose * n_scans)() if want_poses else None
+        self._chk(self.L.lk_batch_replay_scans_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(so), _p(tb), C.c_int(kind), _p(n_msg),
+                                                   _p(flat), poses))
+        return poses
+
+    def batch_replay_ragged(self, scans, t_begins, xs=None, Ps=None, imus=None, kins=None, host_tables=False):
         """Convenience: host scans (lists of lk_point arrays, time-sorted) -> HBM, buckets = runs of equal curvature
-        (KILO.cc:375-378), optional priors, ragged replay.  Returns the poses."""
+        (KILO.cc:375-378), optional priors, ragged replay.  Returns the poses.  The bucket tables are built on the device
+        (lk_batch_replay_scans_dev); host_tables=True builds them here and goes through lk_batch_replay_ragged(_imu/_kin)_dev
+        (same results, bit for bit)."""
         from . import synth
 
         if xs is not None:
             self.batch_set_priors(np.asarray(xs), np.asarray(Ps))
         allpts = np.ascontiguousarray(np.concatenate(scans))
         scan_off = np.r_[0, np.cumsum([len(sc) for sc in scans])]
-        tabs = [synth.buckets_of(sc) for sc in scans]
         d = self.device_malloc(allpts.nbytes)
         try:
             self.h2d(d, allpts)
+            if not host_tables:
+                return self.batch_replay_scans_dev(d, scan_off, t_begins, imus=imus, kins=kins)
+            tabs = [synth.buckets_of(sc) for sc in scans]
             return self.batch_replay_ragged_dev(d, self.ragged_tables(scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins, imus, kins))
         finally:
             self.device_free(d)

@@ -53,6 +53,10 @@ struct lk_handle {
     unsigned char* d_valid = nullptr;
     double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
     lk_pose* d_poses = nullptr;
+    void* d_ragdev = nullptr;     // lk_batch_replay_scans_dev: flags, ranks, CSR tables, messages (grow-only)
+    size_t ragdev_cap = 0;
+    void* d_ragtmp = nullptr;     // rocPRIM scan scratch
+    size_t ragtmp_cap = 0;
     void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev (device copy, pinned staging copy)
     void* h_rag = nullptr;
     size_t rag_cap = 0;
@@ -283,7 +287,7 @@ void lk_destroy(lk_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
-                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm};
+                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -586,10 +590,10 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
     const bool WITH_IMU = MSG != 0;   // 1: lk_imu messages (only_imu_use), 2: lk_kin_imu messages (leg fusion, KILO.cc:384-390)
     const int slot = blockIdx.x, lane = threadIdx.x;
     LkFilter* f = &filters[slot];
-    const int nbk = (int)rg.nb[slot];
+    const int nbk = rag_nb(rg, slot);
     if (nbk == 0) return;
-    const double* T = rg.t + (size_t)slot * rg.ldb;
-    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    const double* T = rag_t(rg, slot);
+    const unsigned long long* po = rag_pt_off(rg, slot);
     for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
     if (lane < 36) sm.x[lane] = f->x[lane];
     double t_upd = f->last_update_t, t_pred = f->last_predict_t;
@@ -1728,6 +1732,48 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     return LK_OK;
 }
 
+// The launches of a ragged batch once its tables (padded or CSR, LkRagged) are in HBM.  msg_kind: 0 none, 1 lk_imu, 2 lk_kin_imu.
+// max_n: largest bucket of every bucket index (null: `biggest` for all of them).
+static int ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,
+                         const int* max_n, int msg_kind, lk_pose* out) {
+    LkMap fmap;
+    int rc = frozen_map(h, &fmap);
+    if (rc) return rc;
+    rc = zero_scan_counters(h, 0, (uint32_t)S);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    LkFilter* fl = h->d_filters;
+    hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, d_tbegin);
+    if (biggest <= LK_SCAN_WAVE_MAX && (msg_kind || !getenv("LEGKILO_RAGGED_LEVELS"))) {
+        // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
+        if (msg_kind == 2)
+            hipLaunchKernelGGL(lk_scan_wave_kin_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
+        else if (msg_kind == 1)
+            hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
+        else
+            hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
+        ldb = 0;
+    } else {
+        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
+    }
+    for (size_t b = 0; b < ldb; ++b) {
+        const int nblk = ((max_n ? max_n[b] : biggest) + LK_RB - 1) / LK_RB;
+        const auto rag_kernel = fmap.grid_on ? lk_residual_ragged_kernel<1> : lk_residual_ragged_kernel<0>;
+        hipLaunchKernelGGL(rag_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts, rg, (int)b, h->d_partials,
+                           h->part_stride);
+        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg,
+                           (int)b);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (out) {
+        rc = fetch_poses(h, out, (int)S);
+        if (rc) return rc;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return LK_OK;
+}
+
 // Ragged batch replay: the scans of a recorded run differ in size, in their time buckets and in their start time.  One
 // launch per bucket INDEX over all scans (grid sized by the largest bucket of that index; scans that have run out of
 // buckets leave at once), every scan reading its own tables (LkRagged).  Same kernels' arithmetic as the uniform entry:
@@ -1829,43 +1875,9 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     rg.q_diag = h->q_diag ? 1 : 0;
     rg.acc_scale = h->cfg.gravity / h->acc_norm;
     imu_noise(h->cfg, rg.Rn);
-    LkMap fmap;
-    int rc = frozen_map(h, &fmap);
-    if (rc) return rc;
-    rc = zero_scan_counters(h, 0, (uint32_t)S);
-    if (rc) return rc;
-    hipStream_t st = h->stream;
-    LkFilter* fl = h->d_filters;
-    hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3(((int)S + 63) / 64), dim3(64), 0, st, fl, (int)S, reinterpret_cast<const double*>(dr + o_tb));
-    const int biggest = (int)biggest_bucket;
-    if (biggest <= LK_SCAN_WAVE_MAX && (n_imu || !getenv("LEGKILO_RAGGED_LEVELS"))) {
-        // small buckets only (a real scan's 2 ms bins): each scan's whole bucket chain as one wave, one launch
-        if (n_imu && msg_bytes == sizeof(lk_kin_imu))
-            hipLaunchKernelGGL(lk_scan_wave_kin_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
-        else if (n_imu)
-            hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
-        else
-            hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
-        ldb = 0;
-    } else {
-        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);
-    }
-    for (size_t b = 0; b < ldb; ++b) {
-        const int nblk = (max_n[b] + LK_RB - 1) / LK_RB;
-        const auto rag_kernel = fmap.grid_on ? lk_residual_ragged_kernel<1> : lk_residual_ragged_kernel<0>;
-        hipLaunchKernelGGL(rag_kernel, dim3(nblk, (unsigned)S), dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts, rg, (int)b, h->d_partials,
-                           h->part_stride);
-        hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg,
-                           (int)b);
-    }
-    HIPCHK(h, hipGetLastError());
-    if (out) {
-        rc = fetch_poses(h, out, (int)S);
-        if (rc) return rc;
-    } else {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    return LK_OK;
+    rg.bstart = nullptr;
+    return ragged_launch(h, d_pts, S, rg, reinterpret_cast<const double*>(dr + o_tb), (int)biggest_bucket, ldb, max_n.data(),
+                         n_imu ? (msg_bytes == sizeof(lk_kin_imu) ? 2 : 1) : 0, out);
 }
 
 int lk_batch_replay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
@@ -1893,6 +1905,98 @@ int lk_batch_replay_ragged_kin_dev(lk_handle* h, const lk_point* d_pts, size_t n
     CHECK_H(h);
     if (!n_kin) return fail(h, LK_ERR_INVALID, "null argument");
     return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, n_kin, kins, sizeof(lk_kin_imu), out);
+}
+
+// Recorded-run replay WITHOUT host-side bucket tables: the scans lie back to back in HBM (scan s = d_pts[scan_off[s] .. scan_off[s+1]),
+// time-sorted), and the runs of equal curvature that KILO::process turns into buckets (KILO.cc:375-378) are found on the device
+// (lk_rag_flag / rocPRIM exclusive scan / lk_rag_scatter: CSR tables in HBM); the host sends S + 1 offsets and S start times and
+// reads back three integers.  msgs: n_msg[s] lk_imu (msg_kind 1) or lk_kin_imu (msg_kind 2) records per scan, concatenated, or
+// msg_kind 0.  Same kernels, same results as lk_batch_replay_ragged(_imu / _kin)_dev with host-built tables.
+int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const double* t_begin,
+                              int msg_kind, const uint32_t* n_msg, const void* msgs, lk_pose* out) {
+    CHECK_H(h);
+    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
+    if (!d_pts || !scan_off || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
+    if (msg_kind < 0 || msg_kind > 2 || (msg_kind && !n_msg)) return fail(h, LK_ERR_INVALID, "msg_kind must be 0 (none), 1 (lk_imu) or 2 (lk_kin_imu) with n_msg given");
+    const size_t S = n_scans;
+    if (scan_off[0] != 0) return fail(h, LK_ERR_INVALID, "scan_off[0] must be 0");
+    for (size_t s = 0; s < S; ++s)
+        if (scan_off[s + 1] <= scan_off[s]) return fail(h, LK_ERR_INVALID, "empty scan");
+    const size_t n = scan_off[S];
+    if (n >= ((size_t)1 << 32)) return fail(h, LK_ERR_CAPACITY, "more than 2^32 points in one batch");
+    const size_t msg_bytes = msg_kind == 2 ? sizeof(lk_kin_imu) : sizeof(lk_imu);
+    size_t n_msg_total = 0;
+    if (msg_kind)
+        for (size_t s = 0; s < S; ++s) n_msg_total += n_msg[s];
+    if (n_msg_total && !msgs) return fail(h, LK_ERR_INVALID, "null message array");
+    // device layout: scan_off u64[S+1] | t_begin f64[S] | pt_start u64[n+1] | tb f64[n] | msgs | flag u32[n] | rank u32[n] | bstart u32[S+1]
+    //                | msg_off u32[S+1] | stats u32[4]
+    const size_t o_so = 0, o_tb0 = o_so + 8 * (S + 1), o_ps = o_tb0 + 8 * S, o_tb = o_ps + 8 * (n + 1), o_ms = o_tb + 8 * n,
+                 o_fl = o_ms + ((msg_bytes * n_msg_total + 7) & ~(size_t)7), o_rk = o_fl + 4 * n, o_bs = o_rk + 4 * n, o_mo = o_bs + 4 * (S + 1),
+                 o_st = o_mo + 4 * (S + 1), bytes = o_st + 16;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (bytes > h->ragdev_cap) {
+        if (h->d_ragdev) hipFree(h->d_ragdev), h->d_ragdev = nullptr, h->ragdev_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ragdev, bytes + bytes / 4));
+        h->ragdev_cap = bytes + bytes / 4;
+    }
+    unsigned char* d = static_cast<unsigned char*>(h->d_ragdev);
+    auto* d_so = reinterpret_cast<unsigned long long*>(d + o_so);
+    auto* d_t0 = reinterpret_cast<double*>(d + o_tb0);
+    auto* d_ps = reinterpret_cast<unsigned long long*>(d + o_ps);
+    auto* d_tb = reinterpret_cast<double*>(d + o_tb);
+    auto* d_fl = reinterpret_cast<unsigned int*>(d + o_fl);
+    auto* d_rk = reinterpret_cast<unsigned int*>(d + o_rk);
+    auto* d_bs = reinterpret_cast<unsigned int*>(d + o_bs);
+    auto* d_mo = reinterpret_cast<unsigned int*>(d + o_mo);
+    auto* d_st = reinterpret_cast<unsigned int*>(d + o_st);
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "scan offsets are 64-bit");
+    HIPCHK(h, hipMemcpyAsync(d_so, scan_off, 8 * (S + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_t0, t_begin, 8 * S, hipMemcpyHostToDevice, h->stream));
+    std::vector<unsigned int> moff;
+    if (msg_kind) {
+        moff.resize(S + 1, 0);
+        for (size_t s = 0; s < S; ++s) moff[s + 1] = moff[s] + n_msg[s];
+        HIPCHK(h, hipMemcpyAsync(d_mo, moff.data(), 4 * (S + 1), hipMemcpyHostToDevice, h->stream));
+        if (n_msg_total) HIPCHK(h, hipMemcpyAsync(d + o_ms, msgs, msg_bytes * n_msg_total, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemsetAsync(d_st, 0, 16, h->stream));
+    const unsigned int nblk = (unsigned int)((n + 255) / 256);
+    hipLaunchKernelGGL(lk_rag_flag_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl);
+    size_t tmp_bytes = 0;
+    HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, d_fl, d_rk, 0u, n, rocprim::plus<unsigned int>(), h->stream));
+    if (tmp_bytes > h->ragtmp_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_ragtmp) hipFree(h->d_ragtmp), h->d_ragtmp = nullptr, h->ragtmp_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ragtmp, tmp_bytes));
+        h->ragtmp_cap = tmp_bytes;
+    }
+    HIPCHK(h, rocprim::exclusive_scan(h->d_ragtmp, tmp_bytes, d_fl, d_rk, 0u, n, rocprim::plus<unsigned int>(), h->stream));
+    hipLaunchKernelGGL(lk_rag_scatter_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl, d_rk, d_t0,
+                       d_ps, d_tb, d_bs, d_st);
+    hipLaunchKernelGGL(lk_rag_stats_kernel, dim3(nblk), dim3(256), 0, h->stream, d_ps, d_bs, (int)S, d_st);
+    HIPCHK(h, hipGetLastError());
+    unsigned int st[4];
+    HIPCHK(h, hipMemcpyAsync(st, d_st, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const unsigned int biggest = st[1], most = st[2];
+    if (biggest > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+    if (msg_kind && biggest > (unsigned int)LK_SCAN_WAVE_MAX)
+        return fail(h, LK_ERR_INVALID, "IMU / kinematic messages between buckets are only replayed for scans whose buckets hold <= 512 points");
+    LkRagged rg;
+    rg.pt_off = d_ps;
+    rg.t = d_tb;
+    rg.nb = nullptr;
+    rg.ldb = (int)most;
+    rg.bstart = d_bs;
+    rg.imu_off = msg_kind ? d_mo : nullptr;
+    rg.imu = reinterpret_cast<const double*>(d + o_ms);
+    rg.msg_stride = (int)(msg_bytes / sizeof(double));
+    rg.kin_noise = h->cfg.kin_meas_noise;
+    rg.q_diag = h->q_diag ? 1 : 0;
+    rg.acc_scale = h->cfg.gravity / h->acc_norm;
+    imu_noise(h->cfg, rg.Rn);
+    return ragged_launch(h, d_pts, S, rg, d_t0, (int)biggest, (size_t)most, nullptr, msg_kind, out);
 }
 
 // Asynchronous, double-buffered batch replay.  The batch uses filter slots [first_slot, first_slot + n_scans); calls whose

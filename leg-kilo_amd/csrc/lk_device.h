@@ -142,6 +142,8 @@ struct LkRagged {
     const double* t;                   // [S][ldb]: absolute time of bucket b of scan s (t_begin + curvature, KILO.cc:376)
     const unsigned int* nb;            // [S]: number of buckets of scan s
     int ldb;                           // row pitch of t; pt_off rows have ldb + 1 entries
+    const unsigned int* bstart;        // optional [S + 1]: CSR form (tables built on the device, lk_batch_replay_scans_dev) - scan s owns the
+                                       // buckets bstart[s] .. bstart[s+1) of the FLAT pt_off / t arrays; null: the padded [S][ldb] form above
     const unsigned int* imu_off;       // optional [S + 1]: messages of scan s = imu[imu_off[s] .. imu_off[s+1]), time-sorted
     const double* imu;                 // [n][msg_stride]: lk_imu (7 doubles: stamp, acc, gyr) or lk_kin_imu (33 doubles, stamp first)
     int msg_stride;                    // 7 (only_imu_use) or 33 (leg fusion: kinematic + IMU messages)
@@ -150,6 +152,16 @@ struct LkRagged {
     double acc_scale;                  // gravity / acc_norm (KILO.cc:246)
     double Rn[6];                      // IMU measurement noise: acc, acc, acc_z, gyr, gyr, gyr
 };
+
+__device__ __forceinline__ int rag_nb(const LkRagged& rg, int slot) {
+    return rg.bstart ? (int)(rg.bstart[slot + 1] - rg.bstart[slot]) : (int)rg.nb[slot];
+}
+__device__ __forceinline__ const unsigned long long* rag_pt_off(const LkRagged& rg, int slot) {
+    return rg.bstart ? rg.pt_off + rg.bstart[slot] : rg.pt_off + (size_t)slot * (rg.ldb + 1);
+}
+__device__ __forceinline__ const double* rag_t(const LkRagged& rg, int slot) {
+    return rg.bstart ? rg.t + rg.bstart[slot] : rg.t + (size_t)slot * rg.ldb;
+}
 
 // ---------------------------------------------------------------- small fp64 helpers
 struct V3 {

@@ -1019,15 +1019,15 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
                                  const double* __restrict__ Q, LkRagged rg, int b) {
     __shared__ WaveSmem sm;
     const int slot = blockIdx.x;
-    const int nbk = (int)rg.nb[slot];
+    const int nbk = rag_nb(rg, slot);
     if (b >= nbk) return;
-    const double* T = rg.t + (size_t)slot * rg.ldb;
+    const double* T = rag_t(rg, slot);
     const double* part = partials + (size_t)slot * slot_stride;
     if (b < 0) {
         dev_update_wave(&filters[slot], sm, part, 0, 0.0, Q, T[0], 2);
         return;
     }
-    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    const unsigned long long* po = rag_pt_off(rg, slot);
     const int n = (int)(po[b + 1] - po[b]);
     const bool has_next = b + 1 < nbk;
     dev_update_wave(&filters[slot], sm, part, (n + LK_WAVE - 1) / LK_WAVE, T[b], Q, has_next ? T[b + 1] : 0.0, has_next ? 3 : 1);

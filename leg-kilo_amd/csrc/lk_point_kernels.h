@@ -443,8 +443,8 @@ __global__ void LK_RES_BOUNDS
                               LkRagged rg, int b, double* __restrict__ partials, size_t part_slot_stride) {
     __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
     const int slot = blockIdx.y;
-    if ((unsigned int)b >= rg.nb[slot]) return;
-    const unsigned long long* po = rg.pt_off + (size_t)slot * (rg.ldb + 1);
+    if (b >= rag_nb(rg, slot)) return;
+    const unsigned long long* po = rag_pt_off(rg, slot);
     const unsigned long long base = po[b];
     const int n = (int)(po[b + 1] - base);
     if ((int)(blockIdx.x * LK_RB) >= n) return;

@@ -170,3 +170,56 @@ __global__ void __launch_bounds__(256)
         out[pos[i]] = o;
     }
 }
+
+
+// ---------------------------------------------------------------- time buckets of a batch of scans, found on the device
+// KILO.cc:375-378: a bucket is a run of EXACTLY equal curvature inside a time-sorted scan.  For a batch laid out back to back
+// (scan s = points [scan_off[s], scan_off[s+1])) the bucket tables of lk_batch_replay_ragged_dev are built here instead of on the
+// host: flag the run starts, exclusive-scan the flags, scatter the runs' first indices and times (CSR over all scans).
+__device__ __forceinline__ int lk_scan_of_point(const unsigned long long* __restrict__ scan_off, int S, unsigned long long i) {
+    int lo = 0, hi = S;   // scan_off[lo] <= i < scan_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (scan_off[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(256)
+    lk_rag_flag_kernel(const lk_point* __restrict__ pts, unsigned long long n, const unsigned long long* __restrict__ scan_off, int S,
+                       unsigned int* __restrict__ flag) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = lk_scan_of_point(scan_off, S, i);
+    flag[i] = (i == scan_off[s] || pts[i].curvature != pts[i - 1].curvature) ? 1u : 0u;
+}
+// stats: [0] total buckets B, [1] largest bucket (points), [2] most buckets in a scan
+__global__ void __launch_bounds__(256)
+    lk_rag_scatter_kernel(const lk_point* __restrict__ pts, unsigned long long n, const unsigned long long* __restrict__ scan_off, int S,
+                          const unsigned int* __restrict__ flag, const unsigned int* __restrict__ rank, const double* __restrict__ t_begin,
+                          unsigned long long* __restrict__ pt_start, double* __restrict__ tb, unsigned int* __restrict__ bstart,
+                          unsigned int* __restrict__ stats) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        const int s = lk_scan_of_point(scan_off, S, i);
+        const unsigned int g = rank[i];
+        pt_start[g] = i;
+        tb[g] = t_begin[s] + (double)pts[i].curvature;   // KILO.cc:376
+        if (i == scan_off[s]) bstart[s] = g;
+    }
+    if (i == n - 1) {
+        const unsigned int B = rank[i] + flag[i];
+        pt_start[B] = n;
+        bstart[S] = B;
+        stats[0] = B;
+    }
+}
+__global__ void __launch_bounds__(256)
+    lk_rag_stats_kernel(const unsigned long long* __restrict__ pt_start, const unsigned int* __restrict__ bstart, int S,
+                        unsigned int* __restrict__ stats) {
+    const unsigned int B = stats[0];
+    const unsigned int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < B) atomicMax(&stats[1], (unsigned int)(pt_start[g + 1] - pt_start[g]));
+    if (g < (unsigned int)S) atomicMax(&stats[2], bstart[g + 1] - bstart[g]);
+}

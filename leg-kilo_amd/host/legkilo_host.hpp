@@ -333,7 +333,7 @@ class KiloPath {
         return true;
     }
 
-    // Many recorded scans at once against the CURRENT map, frozen (lk_batch_replay_ragged(_imu)_dev): scan s runs the bucket
+    // Many recorded scans at once against the CURRENT map, frozen (lk_batch_replay_scans_dev): scan s runs the bucket
     // loop of KILO::process (KILO.cc:375-395) on filter slot s from its own prior; buckets are the runs of equal curvature
     // of each time-sorted scan (KILO.cc:376-378), t_begin[s] its start time; `imus` (optional, one time-sorted vector per
     // scan) are applied between the buckets as in only_imu_use mode (KILO.cc:379-383), `kins` as in the default leg-fusion
@@ -348,33 +348,24 @@ class KiloPath {
             throw std::runtime_error("replayRecordedRun: one start time, prior state and prior covariance per scan");
         if (imus && kins) throw std::runtime_error("replayRecordedRun: IMU messages or kinematic + IMU messages, not both");
         std::vector<lk_kin_imu> kin_flat;
+        // the scans go to HBM back to back; their time buckets (runs of equal curvature, KILO.cc:375-378) are found on the device
         std::vector<lk_point> pts;
         std::vector<uint64_t> scan_off(1, 0);
-        std::vector<uint32_t> n_buckets, bucket_off, n_imu;
-        std::vector<double> bucket_dt, x36(S * LK_STATE_DOUBLES), P900(S * DIM_STATE * DIM_STATE);
+        std::vector<uint32_t> n_msg;
+        std::vector<double> x36(S * LK_STATE_DOUBLES), P900(S * DIM_STATE * DIM_STATE);
         std::vector<lk_imu> imu_flat;
         for (size_t s = 0; s < S; ++s) {
             const PointCloudType& sc = sorted_scans[s];
-            uint32_t nb = 0;
-            for (size_t i = 0; i < sc.size(); ++i) {
-                if (i == 0 || sc[i].curvature != sc[i - 1].curvature) {
-                    bucket_off.push_back((uint32_t)i);
-                    bucket_dt.push_back((double)sc[i].curvature);
-                    ++nb;
-                }
-                pts.push_back(lk_point{sc[i].x, sc[i].y, sc[i].z, sc[i].curvature});
-            }
-            bucket_off.push_back((uint32_t)sc.size());
-            n_buckets.push_back(nb);
+            for (size_t i = 0; i < sc.size(); ++i) pts.push_back(lk_point{sc[i].x, sc[i].y, sc[i].z, sc[i].curvature});
             scan_off.push_back(pts.size());
             prior_states[s].to_x36(&x36[s * LK_STATE_DOUBLES]);
             std::memcpy(&P900[s * DIM_STATE * DIM_STATE], prior_covs[s].d.data(), sizeof(double) * DIM_STATE * DIM_STATE);
             if (imus) {
-                n_imu.push_back((uint32_t)(*imus)[s].size());
+                n_msg.push_back((uint32_t)(*imus)[s].size());
                 imu_flat.insert(imu_flat.end(), (*imus)[s].begin(), (*imus)[s].end());
             }
             if (kins) {
-                n_imu.push_back((uint32_t)(*kins)[s].size());
+                n_msg.push_back((uint32_t)(*kins)[s].size());
                 kin_flat.insert(kin_flat.end(), (*kins)[s].begin(), (*kins)[s].end());
             }
         }
@@ -383,15 +374,10 @@ class KiloPath {
         std::vector<lk_pose> out(S);
         int rc = lk_memcpy_h2d(dev_->h(), d_pts, pts.data(), sizeof(lk_point) * pts.size());
         if (!rc) rc = lk_batch_set_priors(dev_->h(), x36.data(), P900.data(), S);
-        if (!rc && kins)
-            rc = lk_batch_replay_ragged_kin_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
-                                                bucket_off.data(), bucket_dt.data(), t_begin.data(), n_imu.data(), kin_flat.data(), out.data());
-        else if (!rc)
-            rc = imus ? lk_batch_replay_ragged_imu_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
-                                                       bucket_off.data(), bucket_dt.data(), t_begin.data(), n_imu.data(), imu_flat.data(),
-                                                       out.data())
-                      : lk_batch_replay_ragged_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(),
-                                                   bucket_off.data(), bucket_dt.data(), t_begin.data(), out.data());
+        if (!rc)
+            rc = lk_batch_replay_scans_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), t_begin.data(), kins ? 2 : (imus ? 1 : 0),
+                                           (imus || kins) ? n_msg.data() : nullptr,
+                                           kins ? static_cast<const void*>(kin_flat.data()) : static_cast<const void*>(imu_flat.data()), out.data());
         lk_device_free(dev_->h(), d_pts);
         dev_->check(rc);
         return out;

@@ -793,7 +793,7 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
     g.map_import(blob)
     g.init_process_cov_q()
-    poses = g.batch_replay_ragged(scans, tbs, xs, Ps)
+    poses = g.batch_replay_ragged(scans, tbs, xs, Ps, host_tables=True)
     for s in range(S):
         o.set_state(xs[s], Ps[s])
         o.set_times(tbs[s], tbs[s])
@@ -804,6 +804,20 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
         assert po.n_buckets == nbs[s]
         assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
         assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
+    # the same batch with the bucket tables built ON THE DEVICE (lk_batch_replay_scans_dev: runs of equal curvature found by a flag /
+    # scan / scatter pass, CSR tables): bit-identical to the host-table entry, dense scans (per-bucket-index launches) included
+    first = [(poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect, g.get_state(slot=s)) for s in range(S)]
+    allp = np.ascontiguousarray(np.concatenate(scans))
+    so = np.r_[0, np.cumsum([len(sc) for sc in scans])]
+    d_all = g.device_malloc(allp.nbytes)
+    g.h2d(d_all, allp)
+    g.batch_set_priors(np.asarray(xs), np.asarray(Ps))
+    pd = g.batch_replay_scans_dev(d_all, so, tbs)
+    for s in range(S):
+        assert (pd[s].n_buckets, pd[s].n_updates, pd[s].n_effect) == first[s][:3], (s, first[s][:3])
+        xd, Pd = g.get_state(slot=s)
+        assert np.array_equal(xd, first[s][3][0]) and np.array_equal(Pd, first[s][3][1]), s
+    g.device_free(d_all)
     # small buckets only (<= 512 points each): the entry runs each scan's whole bucket chain as ONE wave in one launch
     # (lk_scan_wave_kernel); it must equal the per-bucket launches (LEGKILO_RAGGED_LEVELS=1) bit for bit, and the oracle
     small = [i for i, sc in enumerate(scans) if np.diff(synth.buckets_of(sc)[0].astype(np.int64)).max() <= 512]
@@ -816,7 +830,7 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     for levels in (False, True):
         if levels:
             monkeypatch.setenv("LEGKILO_RAGGED_LEVELS", "1")
-        ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P)
+        ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P, host_tables=True)
         res.append(([g.get_state(slot=s) for s in range(len(small_scans))], [(p.n_buckets, p.n_updates, p.n_effect) for p in ps]))
         if levels:
             monkeypatch.delenv("LEGKILO_RAGGED_LEVELS")
@@ -834,7 +848,7 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     g.set_acc_norm(9.81)
     o.set_acc_norm(9.81)
     small_imus = [synth.imu_stream(scene.traj, tb_, tb_ + 0.1, seed=8600 + s) for s, tb_ in enumerate(small_tb)]
-    ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P, imus=small_imus)
+    ps = g.batch_replay_ragged(small_scans, small_tb, small_x, small_P, imus=small_imus, host_tables=True)
     for s in range(len(small_scans)):
         o.set_state(small_x[s], small_P[s])
         o.set_times(small_tb[s], small_tb[s])
@@ -846,13 +860,27 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
         assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
         if po.n_buckets > 100:
             assert not np.array_equal(xg, res[0][0][s][0])   # the IMU updates did change the outcome
+    with_imu = [g.get_state(slot=s) for s in range(len(small_scans))]
+    allp = np.ascontiguousarray(np.concatenate(small_scans))
+    so = np.r_[0, np.cumsum([len(sc) for sc in small_scans])]
+    d_all = g.device_malloc(allp.nbytes)
+    g.h2d(d_all, allp)
+    g.batch_set_priors(np.asarray(small_x), np.asarray(small_P))
+    pd = g.batch_replay_scans_dev(d_all, so, small_tb, imus=small_imus)      # device-built tables + IMU messages
+    for s in range(len(small_scans)):
+        assert (pd[s].n_buckets, pd[s].n_updates, pd[s].n_effect) == (ps[s].n_buckets, ps[s].n_updates, ps[s].n_effect), s
+        xd, Pd = g.get_state(slot=s)
+        assert np.array_equal(xd, with_imu[s][0]) and np.array_equal(Pd, with_imu[s][1]), s
+    with pytest.raises(hip_lib.LegKiloError):
+        g.batch_replay_scans_dev(d_all, np.r_[so[:-1], so[-2]], small_tb)     # an empty scan is refused
+    g.device_free(d_all)
     # a process noise with off-diagonal terms (the scan-resident wave has a fast path for the diagonal Q of initProcessCovQ)
     Qn = o.get_Q().copy()
     Qn[6, 7] = Qn[7, 6] = 3.0
     Qn[18, 21] = Qn[21, 18] = 40.0
     o.set_Q(Qn)
     g.set_Q(Qn)
-    ps = g.batch_replay_ragged(small_scans[:3], small_tb[:3], small_x[:3], small_P[:3])
+    ps = g.batch_replay_ragged(small_scans[:3], small_tb[:3], small_x[:3], small_P[:3], host_tables=True)
     for s in range(3):
         o.set_state(small_x[s], small_P[s])
         o.set_times(small_tb[s], small_tb[s])
@@ -927,7 +955,7 @@ def test_batch_replay_ragged_leg_fusion(oracle_lib, hip_lib):
     g.init_process_cov_q()
     g.set_acc_norm(9.81)
     o.set_acc_norm(9.81)
-    ps = g.batch_replay_ragged(scans, tbs, xs, Ps, kins=kins)
+    ps = g.batch_replay_ragged(scans, tbs, xs, Ps, kins=kins, host_tables=True)
     plain = None
     for s in range(S):
         o.set_state(xs[s], Ps[s])
@@ -941,6 +969,19 @@ def test_batch_replay_ragged_leg_fusion(oracle_lib, hip_lib):
         assert np.allclose(Po, Pg, rtol=1e-6, atol=1e-11), (s, np.abs(Po - Pg).max())
         if s == 0:
             plain = xg.copy()
+    # device-built bucket tables + kinematic messages: the same bits
+    host_tab = [g.get_state(slot=s) for s in range(S)]
+    allp = np.ascontiguousarray(np.concatenate(scans))
+    so = np.r_[0, np.cumsum([len(sc_) for sc_ in scans])]
+    d_all = g.device_malloc(allp.nbytes)
+    g.h2d(d_all, allp)
+    g.batch_set_priors(np.asarray(xs), np.asarray(Ps))
+    pd = g.batch_replay_scans_dev(d_all, so, tbs, kins=kins)
+    for s in range(S):
+        assert (pd[s].n_buckets, pd[s].n_updates, pd[s].n_effect) == (ps[s].n_buckets, ps[s].n_updates, ps[s].n_effect), s
+        xd, Pd = g.get_state(slot=s)
+        assert np.array_equal(xd, host_tab[s][0]) and np.array_equal(Pd, host_tab[s][1]), s
+    g.device_free(d_all)
     # without the messages the outcome differs (they are really applied)
     g.batch_replay_ragged(scans[:1], tbs[:1], xs[:1], Ps[:1])
     assert not np.array_equal(g.get_state(slot=0)[0], plain)
@@ -949,6 +990,8 @@ def test_batch_replay_ragged_leg_fusion(oracle_lib, hip_lib):
         g.ragged_tables([0, len(scans[0])], [synth.buckets_of(scans[0])[0]], [synth.buckets_of(scans[0])[1]], [tbs[0]],
                         imus=[synth.imu_stream(sc.traj, tbs[0], tbs[0] + 0.1)], kins=kins[:1])
     dense = synth.dense_scan(sc.world, sc.traj, tbs[0], sc.P, n=4000, n_buckets=2, seed_scan=1)
+    with pytest.raises(hip_lib.LegKiloError, match="512"):
+        g.batch_replay_ragged([dense], tbs[:1], xs[:1], Ps[:1], kins=kins[:1], host_tables=True)
     with pytest.raises(hip_lib.LegKiloError, match="512"):
         g.batch_replay_ragged([dense], tbs[:1], xs[:1], Ps[:1], kins=kins[:1])
     g.close()
