@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 TAG=${1:-r02a}
 PASSES=${2:-"stats fetch write sq1 sq2 tcc"}
-COMMON="--cpu-sample 0 --config1-scans 0 --no-pcie --sustained-s 0 --cache-dir /tmp/lkcache"
+COMMON=${COMMON:-"--cpu-sample 0 --config1-scans 0 --no-pcie --sustained-s 0 --cache-dir /tmp/lkcache"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, extra bench args, rocprof args...
