@@ -339,7 +339,8 @@ int lk_batch_replay_ragged_kin_dev(lk_handle* h, const lk_point* d_pts, size_t n
  * entries, first 0), start time t_begin[s]; the buckets - runs of exactly equal curvature, KILO.cc:375-378 - are found on the
  * device.  msg_kind 0: no messages; 1: n_msg[s] lk_imu records per scan (only_imu_use, KILO.cc:379-383); 2: lk_kin_imu records
  * (leg fusion, KILO.cc:384-390), concatenated in `msgs`.  Equivalent to lk_batch_replay_ragged(_imu/_kin)_dev on tables built
- * from the same scans. */
+ * from the same scans.  A scan whose curvature decreases somewhere (the sort of KILO.cc:367-370 was skipped) or is NaN is
+ * refused with LK_ERR_INVALID before any filter slot is touched. */
 int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const double* t_begin,
                               int msg_kind, const uint32_t* n_msg, const void* msgs, lk_pose* out);
 

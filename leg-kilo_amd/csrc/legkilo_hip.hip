@@ -1962,7 +1962,7 @@ int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scan
     }
     HIPCHK(h, hipMemsetAsync(d_st, 0, 16, h->stream));
     const unsigned int nblk = (unsigned int)((n + 255) / 256);
-    hipLaunchKernelGGL(lk_rag_flag_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl);
+    hipLaunchKernelGGL(lk_rag_flag_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl, d_st);
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, d_fl, d_rk, 0u, n, rocprim::plus<unsigned int>(), h->stream));
     if (tmp_bytes > h->ragtmp_cap) {
@@ -1980,6 +1980,7 @@ int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scan
     HIPCHK(h, hipMemcpyAsync(st, d_st, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const unsigned int biggest = st[1], most = st[2];
+    if (st[3]) return fail(h, LK_ERR_INVALID, "a scan is not sorted by time (curvature must be non-decreasing within a scan, and finite)");
     if (biggest > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
     if (msg_kind && biggest > (unsigned int)LK_SCAN_WAVE_MAX)
         return fail(h, LK_ERR_INVALID, "IMU / kinematic messages between buckets are only replayed for scans whose buckets hold <= 512 points");
@@ -2011,6 +2012,7 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     CHECK_H(h);
     if (n_scans == 0 || (size_t)first_slot + n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot range must lie in [0, n_slots]");
     if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
+    if (!d_pts || !bucket_off || !bucket_dt) return fail(h, LK_ERR_INVALID, "null argument");
     if ((d_x36 == nullptr) != (d_P900 == nullptr)) return fail(h, LK_ERR_INVALID, "give both prior buffers or neither");
     const int S = (int)n_scans;
     for (size_t b = 0; b < n_buckets; ++b)   // all checks before the first enqueue

@@ -187,13 +187,17 @@ __device__ __forceinline__ int lk_scan_of_point(const unsigned long long* __rest
 }
 __global__ void __launch_bounds__(256)
     lk_rag_flag_kernel(const lk_point* __restrict__ pts, unsigned long long n, const unsigned long long* __restrict__ scan_off, int S,
-                       unsigned int* __restrict__ flag) {
+                       unsigned int* __restrict__ flag, unsigned int* __restrict__ stats) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int s = lk_scan_of_point(scan_off, S, i);
-    flag[i] = (i == scan_off[s] || pts[i].curvature != pts[i - 1].curvature) ? 1u : 0u;
+    const float c = pts[i].curvature;
+    const bool head = i == scan_off[s];
+    const float cp = head ? c : pts[i - 1].curvature;
+    flag[i] = (head || c != cp) ? 1u : 0u;
+    if (!(c >= cp)) stats[3] = 1u;   // out of time order (or NaN): the caller skipped the sort of KILO.cc:367
 }
-// stats: [0] total buckets B, [1] largest bucket (points), [2] most buckets in a scan
+// stats: [0] total buckets B, [1] largest bucket (points), [2] most buckets in a scan, [3] 1: some scan is not sorted by time
 __global__ void __launch_bounds__(256)
     lk_rag_scatter_kernel(const lk_point* __restrict__ pts, unsigned long long n, const unsigned long long* __restrict__ scan_off, int S,
                           const unsigned int* __restrict__ flag, const unsigned int* __restrict__ rank, const double* __restrict__ t_begin,
@@ -220,6 +224,15 @@ __global__ void __launch_bounds__(256)
                         unsigned int* __restrict__ stats) {
     const unsigned int B = stats[0];
     const unsigned int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < B) atomicMax(&stats[1], (unsigned int)(pt_start[g + 1] - pt_start[g]));
-    if (g < (unsigned int)S) atomicMax(&stats[2], bstart[g + 1] - bstart[g]);
+    if (blockIdx.x * 256u >= B && blockIdx.x * 256u >= (unsigned int)S) return;
+    unsigned int big = g < B ? (unsigned int)(pt_start[g + 1] - pt_start[g]) : 0u;
+    unsigned int most = g < (unsigned int)S ? bstart[g + 1] - bstart[g] : 0u;
+    for (int m = 32; m; m >>= 1) {   // one atomic per wave, not per bucket
+        big = max(big, (unsigned int)__shfl_xor((int)big, m));
+        most = max(most, (unsigned int)__shfl_xor((int)most, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (big) atomicMax(&stats[1], big);
+        if (most) atomicMax(&stats[2], most);
+    }
 }

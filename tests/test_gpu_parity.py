@@ -873,6 +873,22 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
         assert np.array_equal(xd, with_imu[s][0]) and np.array_equal(Pd, with_imu[s][1]), s
     with pytest.raises(hip_lib.LegKiloError):
         g.batch_replay_scans_dev(d_all, np.r_[so[:-1], so[-2]], small_tb)     # an empty scan is refused
+    # a scan that skipped the time sort of KILO.cc:367 is refused before any slot is touched (a NaN stamp counts as unsorted)
+    for spoil in ("swap", "nan"):
+        bad = allp.copy()
+        sb = next(i for i, sc in enumerate(small_scans) if len(synth.buckets_of(sc)[1]) > 100)
+        j = int(so[sb]) + 5
+        k = j + int(np.nonzero(bad["curvature"][j:so[sb + 1]] != bad["curvature"][j])[0][0])
+        if spoil == "swap":
+            bad[[j, k]] = bad[[k, j]]
+        else:
+            bad["curvature"][k] = np.nan
+        g.h2d(d_all, bad)
+        before = g.get_state(slot=1)
+        with pytest.raises(hip_lib.LegKiloError, match="not sorted by time"):
+            g.batch_replay_scans_dev(d_all, so, small_tb)
+        after = g.get_state(slot=1)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
     g.device_free(d_all)
     # a process noise with off-diagonal terms (the scan-resident wave has a fast path for the diagonal Q of initProcessCovQ)
     Qn = o.get_Q().copy()
