@@ -11,7 +11,7 @@ import scenes
 import torch
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
 sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3) if mode == "kin" else None)
-S = 2048
+S = int(os.environ.get("AB_S", "2048"))
 g = binding.LegKiloHip(sc.cfg(n_slots=S, max_roots=1 << 15, max_nodes=1 << 16, max_point_blocks=1 << 16))
 t0 = 1.0
 x0 = scenes.init_filter(g, sc, t0)
