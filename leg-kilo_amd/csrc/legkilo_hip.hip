@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(LK_FB)
     double acc = 0.0;
     for (int base = wv * LK_WAVE; base < n; base += LK_FB) {
         __builtin_amdgcn_wave_barrier();  // the previous tile's reads of this wave's rows are complete
-        acc += residual_tile<false, 0, XID>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
+        acc += residual_tile<false, 0, XID, true>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
     }
     if (lane < LK_NPART) red[wv][lane] = (lane < 29) ? acc : 0.0;
     __syncthreads();
@@ -585,6 +585,12 @@ __global__ void __launch_bounds__(LK_FB)
 // the order lk_update_wave_kernel uses for up to 8 tiles (one per group) - the host takes this path only when every bucket
 // has <= LK_SCAN_WAVE_MAX points, so both paths give the same bits.
 #define LK_SCAN_WAVE_MAX 512
+#ifdef LK_DEBUG_PHASES
+__device__ unsigned long long lk_sw_dbg[16];   // DEBUG BUILD ONLY: s_memtime deltas per phase of dev_scan_wave, [15] = buckets
+#define SW_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); ph_[k] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define SW_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& pr, LkFilter* filters, const lk_point* __restrict__ pts,
                                               const LkRagged& rg, const double* __restrict__ Q, WaveSmem& sm, double* rows, const int MSG) {
     const bool WITH_IMU = MSG != 0;   // 1: lk_imu messages (only_imu_use), 2: lk_kin_imu messages (leg fusion, KILO.cc:384-390)
@@ -605,13 +611,18 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
     if (WITH_IMU) qi = rg.imu_off[slot], qn = rg.imu_off[slot + 1];
     ResidualOut ro;
     ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = nullptr;
+#ifdef LK_DEBUG_PHASES
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, t0_ = wall_clock64();
+#endif
     for (int b = 0; b < nbk;) {
         // next event of the scan: an IMU message stamped before the bucket's time (KILO.cc:379-383), else the bucket
         const double tb_ = T[b];
         const size_t mstride = MSG == 2 ? 33 : 7;
         const bool is_imu = WITH_IMU && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
         const double t = is_imu ? rg.imu[mstride * (size_t)qi] : tb_;
+        SW_STAMP(0);
         if (!LK_X_NOPRED) wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
+        SW_STAMP(1);
         t_pred = t;
         if (is_imu) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
             const double* m = rg.imu + mstride * (size_t)qi;
@@ -636,22 +647,32 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
             bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
         }
         double totv = 0.0;  // tot[j] in lanes 0..31
+        SW_STAMP(2);
         for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
             __builtin_amdgcn_wave_barrier();  // the previous tile's reads of the rows are complete
             const double a = LK_X_NORES ? ((lane == 28) ? 1.0 : 0.0)
-                                        : residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
+                                        : residual_tile<false, 2, false, true>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
             totv += (lane < 29) ? a : 0.0;
         }
-        const int N = (int)(__shfl(totv, 28, LK_WAVE) + 0.5);
+        const int N = (int)(lane_bcast<28>(totv) + 0.5);
+        SW_STAMP(3);
         n_buckets += 1, last_N = N, updated = N > 0;
         if (N > 0) {
             n_updates += 1, n_effect += (unsigned long long)N;
             t_upd = t;  // KILO.cc:212
             if (!LK_X_NOUPD) wave_update_core(sm, totv, N, lane);
         }
+        SW_STAMP(4);
         __syncthreads();
         ++b;
+        SW_STAMP(5);
     }
+#ifdef LK_DEBUG_PHASES
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&lk_sw_dbg[k], ph_[k]);
+        atomicAdd(&lk_sw_dbg[15], (unsigned long long)nbk);
+    }
+#endif
     __syncthreads();
     for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
     if (lane < 36) f->x[lane] = sm.x[lane];
@@ -1752,6 +1773,19 @@ static int ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const Lk
             hipLaunchKernelGGL(lk_scan_wave_imu_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
         else
             hipLaunchKernelGGL(lk_scan_wave_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fmap, h->pr, fl, d_pts, rg, h->d_Q);
+#ifdef LK_DEBUG_PHASES
+        {
+            unsigned long long hb[16];
+            hipStreamSynchronize(st);
+            hipMemcpyFromSymbol(hb, HIP_SYMBOL(lk_sw_dbg), sizeof(hb));
+            const char* names[6] = {"head", "predict", "bc", "residual", "update", "tail"};
+            fprintf(stderr, "[scan-wave phases] %llu buckets:", hb[15]);
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.2f us;", names[k], (double)hb[k] / (double)hb[15] * 0.01);
+            fprintf(stderr, "\n");
+            memset(hb, 0, sizeof(hb));
+            hipMemcpyToSymbol(HIP_SYMBOL(lk_sw_dbg), hb, sizeof(hb));
+        }
+#endif
         ldb = 0;
     } else {
         hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3((unsigned)S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, -1);

@@ -444,6 +444,46 @@ __device__ __forceinline__ int hash_find(const LkMap& m, int kx, int ky, int kz)
     return -1;
 }
 
+// Broadcast of one lane's value when the SOURCE LANE IS A COMPILE-TIME CONSTANT: two v_readlane_b32 into an SGPR pair instead of
+// the two ds_bpermute_b32 that __shfl compiles to - no trip through the LDS pipe (which the one-wave filter kernels saturate) and
+// the result is a scalar operand.  Same bits as __shfl(v, lane).
+#ifndef LK_READLANE
+#define LK_READLANE 1
+#endif
+template <int LANE>
+__device__ __forceinline__ double lane_bcast(double v) {
+#if LK_READLANE
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE), hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+    return __hiloint2double(hi, lo);
+#else
+    return __shfl(v, LANE, LK_WAVE);
+#endif
+}
+template <int LANE>
+__device__ __forceinline__ int lane_bcast(int v) {
+#if LK_READLANE
+    return __builtin_amdgcn_readlane(v, LANE);
+#else
+    return __shfl(v, LANE, LK_WAVE);
+#endif
+}
+// the same for a lane index that is constant after unrolling (i in a `#pragma unroll` loop): the builtin wants a uniform value
+__device__ __forceinline__ double lane_bcast_u(double v, int lane) {
+#if LK_READLANE
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+#else
+    return __shfl(v, lane, LK_WAVE);
+#endif
+}
+__device__ __forceinline__ int lane_bcast_u(int v, int lane) {
+#if LK_READLANE
+    return __builtin_amdgcn_readlane(v, lane);
+#else
+    return __shfl(v, lane, LK_WAVE);
+#endif
+}
+
 // wave-wide sum, result in every lane
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

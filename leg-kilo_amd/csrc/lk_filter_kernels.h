@@ -411,7 +411,7 @@ __device__ __forceinline__ int tri6(int i, int j) {  // index of (i,j) in the pa
 // The N > 0 branch of updateByPoints on LDS-resident state: tot[j] in lanes 0..31 of totv (see dev_update_wave).
 __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int N, int lane) {
     if (N == 1) {  // eskf.cc:98-104
-        double r = __shfl(totv, 27, LK_WAVE);
+        double r = lane_bcast_u(totv, 27);
         double sc = r / (r + 0.0001);
         if (lane < 27) totv *= sc;
     }
@@ -423,8 +423,8 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
     for (int i = 0; i < 6; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s += __shfl(totv, tri6(i, k), LK_WAVE) * sm.P[k * 30 + pc];
-        double bi = __shfl(totv, 21 + i, LK_WAVE);
+        for (int k = 0; k < 6; ++k) s += lane_bcast_u(totv, tri6(i, k)) * sm.P[k * 30 + pc];
+        double bi = lane_bcast_u(totv, 21 + i);
         col[i] = lane == 36 ? bi : (lane < 6 ? ((i == lane) ? 1.0 : 0.0) + s : s);
     }
     // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane
@@ -437,7 +437,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
             double v = fabs(col[i]);
             if (v > best) best = v, p = i;
         }
-        p = __shfl(p, k, LK_WAVE);  // the pivot search belongs to column k
+        p = lane_bcast_u(p, k);  // the pivot search belongs to column k
 #pragma unroll
         for (int i = k + 1; i < 6; ++i)
             if (i == p) {
@@ -449,24 +449,24 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         // broadcast - one fp64 division per step on the critical path instead of five; the same quotients, the same bits
         double sk[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sk[i] = __shfl(col[i], k, LK_WAVE);
+        for (int i = 0; i < 6; ++i) sk[i] = lane_bcast_u(col[i], k);
         const double mine = lane == 0 ? sk[0] : lane == 1 ? sk[1] : lane == 2 ? sk[2] : lane == 3 ? sk[3] : lane == 4 ? sk[4] : sk[5];
         const double fac = mine / sk[k];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i == k) continue;
-            const double fi = __shfl(fac, i, LK_WAVE);
+            const double fi = lane_bcast_u(fac, i);
             col[i] -= fi * col[k];
         }
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);  // X = G / diag(S)
+    for (int i = 0; i < 6; ++i) col[i] = col[i] / lane_bcast_u(col[i], i);  // X = G / diag(S)
     // -- dx = P[:,0:6] X[:,30]
     double dxv = 0.0;
     {
         const int i = lane < 30 ? lane : 29;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) dxv += sm.P[i * 30 + m] * __shfl(col[m], 36, LK_WAVE);
+        for (int m = 0; m < 6; ++m) dxv += sm.P[i * 30 + m] * lane_bcast_u(col[m], 36);
         asm volatile("" : "+v"(dxv));  // finished here: keeps its six operands from living across the loop below
     }
     // -- P -= P[:,0:6] X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...  A row's new values depend on
@@ -496,7 +496,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         }
     }
     // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
-    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0 && !(LK_X_P & 32)) {
         double E[9], Rn[9];
         exp3_1e5(d0, d1, d2, E);
@@ -538,7 +538,7 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
             double v = fabs(col[i]);
             if (v > best) best = v, p = i;
         }
-        p = __shfl(p, k, LK_WAVE);
+        p = lane_bcast_u(p, k);
 #pragma unroll
         for (int i = k + 1; i < 6; ++i)
             if (i == p) {
@@ -550,23 +550,23 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
         // broadcast - one fp64 division per step on the critical path instead of five; the same quotients, the same bits
         double sk[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sk[i] = __shfl(col[i], k, LK_WAVE);
+        for (int i = 0; i < 6; ++i) sk[i] = lane_bcast_u(col[i], k);
         const double mine = lane == 0 ? sk[0] : lane == 1 ? sk[1] : lane == 2 ? sk[2] : lane == 3 ? sk[3] : lane == 4 ? sk[4] : sk[5];
         const double fac = mine / sk[k];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i == k) continue;
-            const double fi = __shfl(fac, i, LK_WAVE);
+            const double fi = lane_bcast_u(fac, i);
             col[i] -= fi * col[k];
         }
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);
+    for (int i = 0; i < 6; ++i) col[i] = col[i] / lane_bcast_u(col[i], i);
     double dxv = 0.0;
     {
         const int i = lane < 30 ? lane : 29;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) dxv += pht(i, m) * __shfl(col[m], 36, LK_WAVE);
+        for (int m = 0; m < 6; ++m) dxv += pht(i, m) * lane_bcast_u(col[m], 36);
         asm volatile("" : "+v"(dxv));
     }
     {
@@ -593,7 +593,7 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
             __syncthreads();
         }
     }
-    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0) {
         double E[9], Rn[9];
         exp3_1e5(d0, d1, d2, E);
@@ -757,14 +757,14 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
     }
 #pragma unroll
     for (int i = 0; i < 18; ++i)
-        if (i < M) col[i] = col[i] / __shfl(col[i], i, LK_WAVE);   // X = G / diag(S)
+        if (i < M) col[i] = col[i] / lane_bcast_u(col[i], i);   // X = G / diag(S)
     // -- dx = P H^T X[:,30]
     double dxv = 0.0;
     {
         const int i = lane < 30 ? lane : 29;
 #pragma unroll
         for (int m = 0; m < 18; ++m) {
-            const double xm = __shfl(col[m], 48, LK_WAVE);
+            const double xm = lane_bcast_u(col[m], 48);
             if (m < M) dxv += ks.pht[i * 18 + m] * xm;
         }
     }
@@ -787,7 +787,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
         }
     }
     __syncthreads();
-    const double d0 = __shfl(dxv, 0, LK_WAVE), d1 = __shfl(dxv, 1, LK_WAVE), d2 = __shfl(dxv, 2, LK_WAVE);
+    const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0) {
         double E[9], Rn[9];
         exp3_1e5(d0, d1, d2, E);
@@ -973,7 +973,7 @@ __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const
             totv += mine;   // group 2*gi   (meaningful in lanes 0..31)
             totv += other;  // group 2*gi+1
         }
-        const int N = (int)(__shfl(totv, 28, LK_WAVE) + 0.5);
+        const int N = (int)(lane_bcast_u(totv, 28) + 0.5);
         if (lane == 0) {
             f->n_buckets += 1;
             f->last_N = N;

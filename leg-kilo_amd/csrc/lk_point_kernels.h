@@ -270,7 +270,10 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 // doubles).  Returns, in lane (q, half) = (lane & 31, lane >> 5), component q of [A(21) b(6) sumR count] summed over the
 // tile's 64 rows (both halves hold the same value).  Shared by lk_residual_kernel (one tile per single-wave workgroup)
 // and lk_small_bucket_kernel (legkilo_hip.hip: a small bucket's tiles inside one workgroup).
-template <bool EMIT_ROWS, int GRID = 2, bool XID = false>
+// SHORT (the small-bucket kernels, where a tile usually holds a handful of points): the sums run over the rows that hold points,
+// rounded up to eight - the rows behind them are zero rows, and fma(0, 0, acc) == acc for every acc this loop can hold (it starts
+// at +0 and can never become -0), so the bits are those of the full loop.
+template <bool EMIT_ROWS, int GRID = 2, bool XID = false, bool SHORT = false>
 __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams& pr, const BucketConst& bc,
                                                 const float4* __restrict__ spts, int i, int n, double* rows, int lane,
                                                 const ResidualOut& out, size_t out_base) {
@@ -405,10 +408,22 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
     const int a = (int)(ab & 15u), b = (int)(ab >> 4);
     const double* base = rows + (half * 32) * LK_ROW2;
     double acc = 0.0;
+    if (SHORT) {
+        const int nv = __builtin_amdgcn_readfirstlane(n - (i - lane));   // points in this tile (wave-uniform)
+        const int jm = nv >= 32 ? 32 : ((nv + 7) & ~7);
+        for (int j0 = 0; j0 < jm; j0 += 8) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const double* r = base + j * LK_ROW2;
-        acc = __builtin_fma(r[a], r[b], acc);
+            for (int j = 0; j < 8; ++j) {
+                const double* r = base + (j0 + j) * LK_ROW2;
+                acc = __builtin_fma(r[a], r[b], acc);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const double* r = base + j * LK_ROW2;
+            acc = __builtin_fma(r[a], r[b], acc);
+        }
     }
     acc += __shfl_xor(acc, 32, LK_WAVE);
     return acc;
