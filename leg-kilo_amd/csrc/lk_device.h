@@ -484,9 +484,43 @@ __device__ __forceinline__ int lane_bcast_u(int v, int lane) {
 #endif
 }
 
-// wave-wide sum, result in every lane
+// wave-wide sum, result in every lane: the xor butterfly 32, 16, 8, 4, 2, 1.  Built from gfx950's v_permlane32_swap / v_permlane16_swap
+// (a swap of a register with a copy of itself leaves the two halves / row pairs side by side, and a + b == b + a) and DPP moves
+// (row_ror:8 == lane ^ 8 inside a row of 16; row_half_mirror then quad_perm [3,2,1,0] == lane ^ 4; quad_perm for ^ 2 and ^ 1)
+// instead of six pairs of ds_bpermute_b32: the same partners, the same additions, the same bits in every lane
+// (tools/probes/wave_sum_dpp_butterfly.hip), no trip through the LDS pipe.  LK_DPP_SUM=0: the __shfl_xor form.
+#ifndef LK_DPP_SUM
+#define LK_DPP_SUM 1
+#endif
+typedef unsigned int lk_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#if LK_DPP_SUM
+    {
+        const unsigned int lo = (unsigned int)__double2loint(v), hi = (unsigned int)__double2hiint(v);
+        const lk_u2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const lk_u2 h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    {
+        const unsigned int lo = (unsigned int)__double2loint(v), hi = (unsigned int)__double2hiint(v);
+        const lk_u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const lk_u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    v += dpp_mov_f64<0x128>(v);
+    v += dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0xB1>(v);
+    return v;
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, LK_WAVE);
     return v;
+#endif
 }
