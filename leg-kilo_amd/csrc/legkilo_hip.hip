@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(LK_FB) lk_begin_predict_kernel(LkMap map, LkFi
 template <bool XID>
 __global__ void __launch_bounds__(LK_FB)
     lk_small_bucket_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, double t,
-                           const lk_point* __restrict__ pts, int n, float* world) {
+                           const lk_point* __restrict__ pts, int n, float* world, int reproject) {
     __shared__ FilterSmem sm;
     __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
     __shared__ double red[LK_FB / LK_WAVE][LK_NPART];
@@ -509,6 +509,25 @@ __global__ void __launch_bounds__(LK_FB)
     }
     __syncthreads();
     dev_update_from_totals(f, sm, tot, t);
+    // reproject != 0 (tiny buckets): the re-projection with the posterior (KILO.cc:216-230) and the root hashing of the insert
+    // (reproject == 2) follow in the same workgroup - a device-scope fence + barrier instead of a launch boundary (~4 us on a
+    // dependent stream); the same dev_reproject_point per point as lk_reproject_kernel
+    if (reproject) {
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < n; i += LK_FB) dev_reproject_point(map, pr, filters, pts, world, reproject == 2 ? 1 : 0, i);
+    }
+}
+// Tiny buckets: the light insert (one thread per touched root) and the group pass (one wave per root on the work list) of the
+// per-root insert as ONE single-workgroup launch - the same dev_insert_light_root / dev_insert_group as the two kernels it replaces,
+// which decide per root, so the result does not depend on which wave handles a root.
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_light_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, int n) {
+    const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = threadIdx.x; r < n_touched; r += LK_MB) dev_insert_light_root(map, pr, filters, pts, r);
+    __threadfence();
+    __syncthreads();
+    dev_insert_group<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
 }
 extern "C" {
 
@@ -736,10 +755,14 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     // the stream path's residual code specialised for ext_R == I like the batch kernel (LEGKILO_XID=0: generic)
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const bool xid = h->pr.ext_identity && xid_enable;
+    // tiny buckets (a real scan's 2 ms bins: a dozen points): fewer dependent launches - re-projection inside the bucket kernel, light +
+    // group pass as one launch (LEGKILO_FUSE_MAX: largest such bucket, 0 = off)
+    static const int fuse_max = getenv("LEGKILO_FUSE_MAX") ? atoi(getenv("LEGKILO_FUSE_MAX")) : 64;
+    const bool fuse = n <= fuse_max && n <= LK_SMALL_MAX;
     if (n <= LK_SMALL_MAX) {
         const auto small_kernel = xid ? lk_small_bucket_kernel<true> : lk_small_bucket_kernel<false>;
         LAUNCH(h, "small_bucket", hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
-                                                     h->d_Q, t, d_pts, n, d_world));
+                                                     h->d_Q, t, d_pts, n, d_world, fuse && (d_world || do_insert) ? (do_insert ? 2 : 1) : 0));
     } else {
         // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
         LAUNCH(h, "predict", hipLaunchKernelGGL(lk_begin_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_Q, t));
@@ -753,18 +776,23 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
                                                h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
     }
-    if (d_world || do_insert)
+    if ((d_world || do_insert) && !fuse)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
     if (do_insert) {
-        LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
-                                                     h->d_filters, d_pts, n));
+        if (fuse)
+            LAUNCH(h, "insert_light_group", hipLaunchKernelGGL(lk_insert_light_group_kernel, dim3(1), dim3(LK_MB), 0, h->stream, m, h->pr,
+                                                               h->d_filters, d_pts, n));
+        else
+            LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
+                                                         h->d_filters, d_pts, n));
         // ordered part: group pass (one wave per root, light), apply pass (one wave per leaf group; 2 resident waves
         // per SIMD at 206 VGPRs: 512 blocks x 4 waves is exactly one resident round on 256 CUs), then the generic
         // fallback for the few groups that need it; all loops are grid-stride and read their work counts on the device
         int grid = std::min(std::max((n + 3) / 4, 1), 512);
-        LAUNCH(h, "insert_group", hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                     h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+        if (!fuse)
+            LAUNCH(h, "insert_group", hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                         h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
