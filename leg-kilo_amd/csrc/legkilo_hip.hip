@@ -518,6 +518,61 @@ __global__ void __launch_bounds__(LK_FB)
         for (int i = tid; i < n; i += LK_FB) dev_reproject_point(map, pr, filters, pts, world, reproject == 2 ? 1 : 0, i);
     }
 }
+// Tiny buckets (n <= 64: ONE tile): the whole filter side of the bucket as ONE WAVE - pool bookkeeping, predict, the tile, update,
+// re-projection - with the one-wave filter cores of the batch-replay kernels (wave_predict_core / wave_update_core: P and x stay
+// in 7.7 KB of LDS, the 6 x 37 system one column per lane, broadcasts through v_readlane) instead of the 256-thread
+// dev_predict / dev_update_from_totals, whose steps are separated by workgroup barriers.  Same sums in the same order (the
+// one-wave cores agree with the 256-thread kernels bit for bit, test_batch_replay_frozen_map; one tile = no cross-wave sum).
+template <bool XID>
+__global__ void __launch_bounds__(LK_WAVE)
+    lk_tiny_bucket_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, int q_diag, double t,
+                          const lk_point* __restrict__ pts, int n, float* world, int reproject) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    LkFilter* f = &filters[0];
+    const int lane = threadIdx.x;
+    dev_bucket_begin(map);
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+    if (lane < 36) sm.x[lane] = f->x[lane];
+    const double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    __syncthreads();
+    wave_predict_core(sm, Q, t - t_upd, t - t_pred, lane, q_diag != 0);   // KILO.cc:111-115
+    BucketConst bc;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bc.R[i] = sm.x[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc.p[i] = sm.x[9 + i];
+    {
+        const double* P = sm.P;
+        bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
+        bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
+    }
+    ResidualOut ro;
+    ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = world;
+    const double a = residual_tile<false, 0, XID, true>(map, pr, bc, reinterpret_cast<const float4*>(pts), lane, n, rows, lane, ro, (size_t)0);
+    const double totv = (lane < 29) ? a : 0.0;   // tot[j] in lanes 0..31
+    const int N = (int)(lane_bcast<28>(totv) + 0.5);
+    if (lane == 0) {   // the bookkeeping of dev_predict / dev_update_from_totals (KILO.cc:193,211-212)
+        f->last_predict_t = t;
+        f->n_buckets += 1;
+        f->last_N = N;
+        f->updated = N > 0;
+        if (N > 0) {
+            f->n_updates += 1;
+            f->n_effect += (unsigned long long)N;
+            f->last_update_t = t;
+        }
+    }
+    if (N > 0) wave_update_core(sm, totv, N, lane);
+    __syncthreads();
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+    if (lane < 36) f->x[lane] = sm.x[lane];
+    if (reproject) {
+        __threadfence();
+        __syncthreads();
+        for (int i = lane; i < n; i += LK_WAVE) dev_reproject_point(map, pr, filters, pts, world, reproject == 2 ? 1 : 0, i);
+    }
+}
 // Tiny buckets: the light insert (one thread per touched root) and the group pass (one wave per root on the work list) of the
 // per-root insert as ONE single-workgroup launch - the same dev_insert_light_root / dev_insert_group as the two kernels it replaces,
 // which decide per root, so the result does not depend on which wave handles a root.
@@ -759,7 +814,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     // group pass as one launch (LEGKILO_FUSE_MAX: largest such bucket, 0 = off)
     static const int fuse_max = getenv("LEGKILO_FUSE_MAX") ? atoi(getenv("LEGKILO_FUSE_MAX")) : 64;
     const bool fuse = n <= fuse_max && n <= LK_SMALL_MAX;
-    if (n <= LK_SMALL_MAX) {
+    static const bool tiny_enable = getenv("LEGKILO_TINY") == nullptr || atoi(getenv("LEGKILO_TINY")) != 0;
+    if (fuse && tiny_enable && n <= LK_WAVE) {
+        const auto tiny_kernel = xid ? lk_tiny_bucket_kernel<true> : lk_tiny_bucket_kernel<false>;
+        LAUNCH(h, "small_bucket", hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(LK_WAVE), 0, h->stream, m, h->pr, h->d_filters, h->d_Q,
+                                                     h->q_diag ? 1 : 0, t, d_pts, n, d_world, (d_world || do_insert) ? (do_insert ? 2 : 1) : 0));
+    } else if (n <= LK_SMALL_MAX) {
         const auto small_kernel = xid ? lk_small_bucket_kernel<true> : lk_small_bucket_kernel<false>;
         LAUNCH(h, "small_bucket", hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
                                                      h->d_Q, t, d_pts, n, d_world, fuse && (d_world || do_insert) ? (do_insert ? 2 : 1) : 0));

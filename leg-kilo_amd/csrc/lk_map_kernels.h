@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void dev_bucket_begin(const LkMap& map) {
         map.counters[LK_CTR_FALLBACK] = 0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nfreed; i += 256) map.free_list[base + i] = map.freed_next[i];
+    for (int i = threadIdx.x; i < nfreed; i += (int)blockDim.x) map.free_list[base + i] = map.freed_next[i];
     __syncthreads();
     if (threadIdx.x == 0) {
         map.counters[LK_CTR_FREE] = (unsigned int)(base + nfreed);
