@@ -285,6 +285,8 @@ void lk_destroy(lk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
+    for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)   // an asynchronous batch may still be running on a side stream
+        if (h->side[i]) hipStreamSynchronize(h->side[i]);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp};
