@@ -178,6 +178,14 @@ class Oracle:
         p = _f64(p).copy()
         self.L.lko_map_slide_position(self.h, 1, _p(p))
 
+    def residual_margins(self, xyz_body3):
+        """(valid, [range-gate margin, sigma-gate margin, key margin]) of one body point: relative distance of the closest gate
+        on its match path from its threshold (test diagnostic, lko_residual_margins)."""
+        b = np.ascontiguousarray(xyz_body3, dtype=np.float32).reshape(3)
+        out = np.zeros(3)
+        v = self.L.lko_residual_margins(self.h, _p(b), _p(out))
+        return int(v), out
+
     def match_voxel(self, key, pw, var):
         """build_single_residual on root voxel `key` (is_success = False, prob = 0 on entry) ->
         dict(found, success, prob, normal, center, d, dis_to_plane, layer)."""

@@ -4,6 +4,7 @@
 // Mirrors the lk_* calls of include/legkilo_hip.h with an lko_ prefix so a parity
 // test is the same call sequence on both sides.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -164,6 +165,27 @@ int lko_residuals(lko_handle* h, const float* xyz_body, size_t n, double* h6, do
         R[i] = rows[i].R;
     }
     return 0;
+}
+// TEST DIAGNOSTIC: the smallest relative distance of any gate on the match path of ONE body point from its threshold, with the
+// current state: out3 = {range gate (float arithmetic), sigma gate, voxel key: distance of p_w / voxel_size from an integer}.
+int lko_residual_margins(lko_handle* h, const float* xyz_body3, double* out3) {
+    out3[0] = out3[1] = out3[2] = 1e300;
+    auto* m = h->kilo->map_manager_.get();
+    m->gate_margin_probe_ = out3;
+    std::vector<ResidualRow> rows;
+    h->kilo->residualsOnly(xyz_body3, 1, rows);
+    m->gate_margin_probe_ = nullptr;
+    lk_point pt{xyz_body3[0], xyz_body3[1], xyz_body3[2], 0.f};
+    pointWithVar pv;
+    PointToPlane pl;
+    float w[4];
+    h->kilo->matchPoint(pt, pv, pl, w);
+    for (int j = 0; j < 3; ++j) {
+        const double loc = pv.point_w[j] / m->config_setting_.max_voxel_size_;
+        const double d = std::fabs(loc - std::nearbyint(loc));
+        if (d < out3[2]) out3[2] = d;
+    }
+    return rows[0].valid ? 1 : 0;
 }
 int lko_update_points(lko_handle* h, double t, const float* xyz_body, size_t n, float* xyz_world_out,
                       float* intensity_out, size_t* n_effect) {

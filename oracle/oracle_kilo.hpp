@@ -54,8 +54,7 @@ class KILO {
     Vec3 ext_t_ = Vec3::Zero();
     bool map_insert_enabled_ = true;  // false = frozen-map batch replay (config 5); not a reference switch
 
-   private:
-    // KILO.cc:122-183 for one point; returns is_success
+    // KILO.cc:122-183 for one point; returns is_success (public for the diagnostics of oracle_capi.cc)
     bool matchPoint(const lk_point& cur_pt, pointWithVar& cur_pt_var, PointToPlane& single_ptpl, float* world_xyzi);
     void rowFromPtpl(const PointToPlane& p, double* h6, double& z, double& R);  // KILO.cc:195-209
 };

@@ -375,12 +375,22 @@ void VoxelMapManager::build_single_residual(pointWithVar& pv, const VoxelOctoTre
                               (plane.center_[1] - p_w[1]) * (plane.center_[1] - p_w[1]) +
                               (plane.center_[2] - p_w[2]) * (plane.center_[2] - p_w[2]);
         float range_dis = std::sqrt(dis_to_center - dis_to_plane * dis_to_plane);
+        if (gate_margin_probe_) {   // test diagnostic only, see the header
+            const double thr = radius_k * plane.radius_;
+            const double m = std::fabs((double)range_dis - thr) / thr;
+            if (m < gate_margin_probe_[0]) gate_margin_probe_[0] = m;
+        }
 
         if (range_dis <= radius_k * plane.radius_) {
             Mat<1, 6> J_nq;
             for (int c = 0; c < 3; ++c) J_nq(0, c) = p_w[c] - plane.center_[c], J_nq(0, 3 + c) = -plane.normal_[c];
             double sigma_l = ((J_nq * plane.plane_var_) * J_nq.T())(0, 0);
             sigma_l += ((plane.normal_.T() * pv.var) * plane.normal_)(0, 0);
+            if (gate_margin_probe_) {
+                const double thr = sigma_num * std::sqrt(sigma_l);
+                const double m = std::fabs((double)dis_to_plane - thr) / thr;
+                if (m < gate_margin_probe_[1]) gate_margin_probe_[1] = m;
+            }
             if (dis_to_plane < sigma_num * std::sqrt(sigma_l)) {
                 is_success = true;
                 double this_prob = 1.0 / (std::sqrt(sigma_l)) * std::exp(-0.5 * dis_to_plane * dis_to_plane / sigma_l);

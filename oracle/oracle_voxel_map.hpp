@@ -133,6 +133,11 @@ class VoxelMapManager {
     Vec3 last_slide_position = Vec3::Zero();
     bool mapSliding();                                                              // voxel_map.cc:552-569
     int clearMemOutOfMap(int x_max, int x_min, int y_max, int y_min, int z_max, int z_min);  // voxel_map.cc:571-594
+
+    // TEST DIAGNOSTIC (not in the reference): when set, build_single_residual records the smallest relative distance of
+    // any gate it evaluates from its threshold - [0] the range gate (float, voxel_map.cc:379-381), [1] the sigma gate
+    // (:388) - so that a parity test can show that a decision flip sits within rounding of a threshold.
+    double* gate_margin_probe_ = nullptr;
 };
 
 extern int voxel_plane_id;  // voxel_map.h:39

@@ -501,8 +501,8 @@ def test_config3_full_size(big):
         po, _ = o.process_scan(pts, tb)
         pg, wg = g.process_scan(pts, tb, want_world=True)
         assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (5, 5)
-        # decision parity at full size: a flipped gate changes the count
-        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (po.n_effect, pg.n_effect)
+        # decision parity at full size: match counts are integer work - exact
+        assert int(po.n_effect) == int(pg.n_effect), (po.n_effect, pg.n_effect)
         xo, Po = o.get_state()
         xg, Pg = g.get_state()
         assert np.abs(xo[9:12] - xg[9:12]).max() < 1e-6, np.abs(xo[9:12] - xg[9:12]).max()
@@ -517,7 +517,7 @@ def test_config3_full_size(big):
 def test_config3_51_buckets_full_size(big):
     """SURVEY 8(d) config 3, the reference's own time quantisation: a 100 000-point scan in 51 two-ms bins (lidar_processing.cc:48)
     = 51 predict / residual / update / re-project / insert cycles of ~2 000 points each (the variant bench.py times as
-    extra.stream51_*), against the oracle's bucket loop: identical bucket / update counts, match counts within 2, pose to 1e-6,
+    extra.stream51_*), against the oracle's bucket loop: identical bucket / update / match counts, all 36 state entries to 1e-6,
     the same set of voxels afterwards."""
     scene, o, g, t0 = big
     for k in range(2):
@@ -531,20 +531,20 @@ def test_config3_51_buckets_full_size(big):
         po, _ = o.process_scan(pts, tb)
         pg, _ = g.process_scan(pts, tb)
         assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (51, 51), (po.n_buckets, po.n_updates, pg.n_buckets, pg.n_updates)
-        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (po.n_effect, pg.n_effect)
+        assert int(po.n_effect) == int(pg.n_effect), (po.n_effect, pg.n_effect)
         assert po.n_effect > 30000
         xo, _ = o.get_state()
         xg, _ = g.get_state()
-        assert np.abs(xo[:12] - xg[:12]).max() < 1e-6, np.abs(xo[:12] - xg[:12]).max()
-        assert np.allclose(xo, xg, rtol=1e-4, atol=1e-4), np.abs(xo - xg).max()
+        # every block of the state - rotation, position, velocity, biases, gravity, IMU states, kinematic states - at 1e-6
+        assert np.abs(xo - xg).max() < 1e-6, (np.abs(xo - xg).max(), int(np.abs(xo - xg).argmax()))
     assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
 
 
 def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
     """16 consecutive 100 k-point scans (5 buckets each) with map insert on a moving trajectory: the map keeps growing,
     leaves refit / freeze / get cut, point blocks are recycled, the generic insert fallback and the long-list replay get
-    their share.  Match counts within 2 per scan (measured: identical), positions to 1e-6 (measured: 1e-8),
-    the same map at the end, no pool overflow."""
+    their share.  Identical match counts on every scan, positions to 1e-6 (measured: 1e-8), the same map at the end, no pool
+    overflow."""
     o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
     g = hip_lib.LegKiloHip(scene.cfg())
     t0 = 8.0
@@ -558,13 +558,14 @@ def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
         po, _ = o.process_scan(pts, tb)
         pg, _ = g.process_scan(pts, tb)
         assert (po.n_buckets, po.n_updates) == (pg.n_buckets, pg.n_updates) == (5, 5), k
-        assert abs(int(po.n_effect) - int(pg.n_effect)) <= 2, (k, po.n_effect, pg.n_effect)
+        assert int(po.n_effect) == int(pg.n_effect), (k, po.n_effect, pg.n_effect)
         xo, _ = o.get_state()
         xg, _ = g.get_state()
         worst = max(worst, float(np.abs(xo[9:12] - xg[9:12]).max()))
         assert np.allclose(xo[:12], xg[:12], rtol=1e-6, atol=1e-6), (k, np.abs(xo[:12] - xg[:12]).max())   # rotation, position
-        # velocity / bias / IMU states are driven by large process noise and amplify 1e-9 differences: measured <= 1.5e-6
-        assert np.allclose(xo, xg, rtol=1e-4, atol=1e-4), (k, np.abs(xo - xg).max())
+        # velocity / bias / IMU states are driven by large process noise and amplify 1e-9 differences over the 16-scan closed
+        # loop (DESIGN "Closed-loop sensitivity"): measured <= 1.5e-6, asserted at 1e-5
+        assert np.abs(xo - xg).max() < 1e-5, (k, np.abs(xo - xg).max(), int(np.abs(xo - xg).argmax()))
     assert worst < 1e-6, worst
     so, sg = scenes.canon_map(o.map_export()), scenes.canon_map(g.map_export())
     assert set(so) == set(sg)
@@ -590,8 +591,16 @@ def test_config2_full_size_residuals(big, hip_lib):
     ho, zo, Ro, vo = o.residuals(xb)
     hg, zg, Rg, vg = g2.residuals(xb)
     assert vo.sum() > 20000
-    # bit-exact decisions except where a gate sits within fp64 rounding of its threshold
-    assert int((vo != vg).sum()) <= 1, int((vo != vg).sum())
+    # decisions are exact.  The ONE allowance: a point whose gate sits within rounding of its threshold (the device
+    # evaluates the 3-sigma gate squared and sigma_l in closed form - DESIGN section 4 - so d vs sigma_num * sqrt(sigma_l) can fall
+    # on the other side when the two are equal to ~1e-12).  Such a point is named, its margins on the oracle's side are printed, and
+    # the margin must be at rounding level; anything else fails.
+    flips = np.flatnonzero(vo != vg)
+    for i in flips:
+        v, marg = o.residual_margins(xb[i])
+        print(f"config2 flip: point {int(i)} oracle valid {int(vo[i])} hip valid {int(vg[i])} margins range/sigma/key {marg}")
+        assert min(marg[0], marg[1]) < 1e-9 or marg[2] < 1e-9, (int(i), marg)
+    assert len(flips) <= 1, flips
     both_v = (vo & vg).astype(np.uint8)
     scenes.rows_close(hg, zg, Rg, ho, zo, Ro, both_v, rtol=1e-9)
     g2.close()
