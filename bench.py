@@ -545,6 +545,8 @@ def main():
         extra["stream51_ms_per_scan"] = round(s51_s * 1e3, 3)
         extra["stream51_scans_per_s"] = round(1.0 / s51_s, 1)
         extra["stream51_buckets"] = int(len(dt51))
+        sb, stl, srd = g.stream_stats()
+        extra["stream_pipeline_stats"] = {"pipelined_buckets": sb, "tiles_verified": stl, "tiles_evaluated_again": srd}
 
     if rank == 0 and args.cpu_sample > 0 and world_size == 1:
         # ---- CPU baseline + in-line parity check: the oracle (port), 1 pinned thread, a bounded sample of the SAME batch on the

@@ -32,9 +32,9 @@ struct ProfEntry {
 };
 
 struct lk_handle {
-    lk_config cfg;
-    LkParams pr;
-    LkMap map;
+    lk_config cfg = {};
+    LkParams pr = {};
+    LkMap map = {};
     hipStream_t stream = nullptr;
     static constexpr int kMaxGroups = 4;
     hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
@@ -60,10 +60,21 @@ struct lk_handle {
     void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev (device copy, pinned staging copy)
     void* h_rag = nullptr;
     size_t rag_cap = 0;
+    // pipelined stream path ("spec"): the insert of bucket k on its own stream beside predict + residual of bucket k+1 (enqueue_bucket)
+    hipStream_t ins = nullptr;
+    hipEvent_t ev_U[2] = {}, ev_D[2] = {}, ev_I = nullptr;
+    unsigned int epoch = 16;      // bucket sequence number: stamps of LkMap::dirty / newroot, value of spec[LK_SPEC_DONE]
+    unsigned int spec_base = 16;  // first epoch of the open window (stamps below it belong to inserts that were joined)
+    bool spec_open = false;       // inserts may still be running on `ins`
+    bool spec_enable = true;      // LEGKILO_SPEC=0: the sequential order on one stream (A/B)
+    LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
+    int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
+    uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0;
+    unsigned int spec_redo_seen = 0;
     double acc_norm = 1.0;
     bool q_diag = true;        // d_Q holds a diagonal matrix (zero-initialised; lk_set_Q re-checks)
     // frozen-map grid of batch replay (LkMap::grid): valid until the map changes
-    LkMap fmap;                // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
+    LkMap fmap = {};           // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
     size_t grid_cap = 0;       // grid cells allocated behind the max_nodes match records of map.match
     bool grid_valid = false;   // the grid describes the current map
     bool grid_enable = true;   // LEGKILO_GRID=0 keeps batch replay on the hash table (A/B)
@@ -147,7 +158,7 @@ static int check_map_errors(lk_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ctr[LK_CTR_ERR]) {
         char buf[160];
-        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch)",
+        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch, 32 insert-stream wait timed out)",
                  ctr[LK_CTR_ERR]);
         return fail(h, LK_ERR_CAPACITY, buf);
     }
@@ -261,6 +272,23 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     HIPCHK(h, hipMalloc(&m.gidx, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.free_list, sizeof(int) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&m.freed_next, sizeof(int) * (size_t)m.max_blocks));
+    HIPCHK(h, hipMalloc(&m.dirty, sizeof(unsigned int) * (size_t)m.max_nodes));
+    HIPCHK(h, hipMemsetAsync(m.dirty, 0, sizeof(unsigned int) * (size_t)m.max_nodes, h->stream));
+    HIPCHK(h, hipMalloc(&m.newroot, sizeof(unsigned int) * (size_t)(LK_NEWROOT_MASK + 1)));
+    HIPCHK(h, hipMemsetAsync(m.newroot, 0, sizeof(unsigned int) * (size_t)(LK_NEWROOT_MASK + 1), h->stream));
+    HIPCHK(h, hipMalloc(&m.spec, sizeof(unsigned int) * LK_SPEC_WORDS));
+    HIPCHK(h, hipMemsetAsync(m.spec, 0, sizeof(unsigned int) * LK_SPEC_WORDS, h->stream));
+    m.epoch = 0;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->ins, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_U[i], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_D[i], hipEventDisableTiming));
+    }
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_I, hipEventDisableTiming));
+    if (const char* e = getenv("LEGKILO_SPEC")) h->spec_enable = atoi(e) != 0;
+    HIPCHK(h, hipMalloc(&h->d_snap, sizeof(LkFilter) * 2));
+    HIPCHK(h, hipMemsetAsync(h->d_snap, 0, sizeof(LkFilter) * 2, h->stream));
+    HIPCHK(h, hipMalloc(&h->d_ids, sizeof(int2) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&h->d_filters, sizeof(LkFilter) * (size_t)cfg->n_slots));
     HIPCHK(h, hipMemsetAsync(h->d_filters, 0, sizeof(LkFilter) * (size_t)cfg->n_slots, h->stream));
     HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * 900));
@@ -285,11 +313,13 @@ void lk_destroy(lk_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device_id);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->ins) hipStreamSynchronize(h->ins);
     for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)   // an asynchronous batch may still be running on a side stream
         if (h->side[i]) hipStreamSynchronize(h->side[i]);
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
-                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp};
+                    h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp,
+                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -300,6 +330,12 @@ void lk_destroy(lk_handle* h) {
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_U[i]) hipEventDestroy(h->ev_U[i]);
+        if (h->ev_D[i]) hipEventDestroy(h->ev_D[i]);
+    }
+    if (h->ev_I) hipEventDestroy(h->ev_I);
+    if (h->ins) hipStreamDestroy(h->ins);
     for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
@@ -308,10 +344,15 @@ void lk_destroy(lk_handle* h) {
     delete h;
 }
 
+static int spec_join(lk_handle* h);
 #define CHECK_H(h)                                                         \
     do {                                                                   \
         if (!(h)) return fail(nullptr, LK_ERR_INVALID, "null handle");     \
         hipSetDevice((h)->cfg.device_id);                                  \
+        if ((h)->spec_open) {                                              \
+            int rcj_ = spec_join(h);                                       \
+            if (rcj_ != LK_OK) return rcj_;                                \
+        }                                                                  \
     } while (0)
 #define CHECK_SLOT(h, s)                                                                  \
     do {                                                                                  \
@@ -779,6 +820,89 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
     dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, 2);
 }
 
+// ------------------------------------------------------------------ pipelined stream path
+// A bucket's insert (re-projection + root hashing, light / group / apply / fallback passes) only feeds the NEXT bucket's matching,
+// and only through the planes of the root voxels it refits, cuts or creates - with time buckets = azimuth sectors of a spinning
+// LiDAR, a handful of voxels at the sector border.  So the insert of bucket k runs on its own HIP stream (`ins`), reading the
+// posterior from a snapshot, while the main stream goes on with predict(k+1) and a SPECULATIVE residual pass (k+1) that also
+// records which two roots every point looked at.  The insert stamps what it may change (LkMap::dirty / newroot, final once its
+// light pass has run: event D); lk_verify_kernel then keeps the partial record of every tile that looked at unstamped roots only -
+// by construction computed from data no insert touched - and re-evaluates the other tiles once the insert has completed
+// (spec[LK_SPEC_DONE]; the verify waves wait on the device, bounded).  update(k+1) therefore sees exactly the sums the sequential
+// order gives; what is gone from the critical chain is the insert:
+//   main:  predict(k+1) -> residual_spec(k+1) -> [D_k] verify(k+1) -> update(k+1) + snapshot -> [U_k+1]
+//   ins :  begin(k+1) | [U_k] re-project(k) -> light(k) -> [D_k] group(k) -> apply(k) -> fallback(k) (+ DONE = epoch k)
+// Stamps carry the bucket's epoch; verify(e) treats stamps >= e - 2 as suspect (the residual pass of e may have overlapped the tail
+// of insert e - 2; inserts <= e - 3 had completed before it started: D_(e-2) follows them on `ins`).
+static int spec_join(lk_handle* h) {
+    if (!h->spec_open) return LK_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_I, 0));   // everything enqueued on the main stream from here on follows the inserts
+    h->spec_open = false;
+    h->spec_base = h->epoch + 1;
+    return LK_OK;
+}
+static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool xid) {
+    const int nblk = (n + LK_PB - 1) / LK_PB;
+    const int nblk_r = (n + LK_RB - 1) / LK_RB;
+    if (h->epoch >= 0xfffffff0u) {   // stamps are compared as plain unsigned numbers: start over long before they could wrap
+        int rc = spec_join(h);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemsetAsync(h->map.dirty, 0, sizeof(unsigned int) * (size_t)h->map.max_nodes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->map.newroot, 0, sizeof(unsigned int) * (size_t)(LK_NEWROOT_MASK + 1), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->map.spec, 0, sizeof(unsigned int) * LK_SPEC_WORDS, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->epoch = 16, h->spec_base = 17;
+    }
+    const unsigned int e = ++h->epoch;
+    const bool first = !h->spec_open;            // nothing in flight: no verify needed for this bucket
+    LkMap m = h->map;
+    m.epoch = e;
+    LkFilter* snap = h->d_snap + (e & 1u);
+    if (first) {   // the insert stream follows whatever the main stream did to the map before
+        HIPCHK(h, hipEventRecord(h->ev_I, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_I, 0));
+    }
+    // insert stream, ahead of the posterior: the bucket's pool bookkeeping
+    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->ins, m);
+    // main stream
+    hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t);
+    ResidualOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.world = d_world;
+    ro.ids = h->d_ids;
+    if (first) {
+        const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
+        hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
+                           h->part_stride, ro, (size_t)0);
+    } else {
+        const auto res_kernel = xid ? lk_residual_kernel<false, 0, true, true> : lk_residual_kernel<false, 0, false, true>;
+        hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
+                           h->part_stride, ro, (size_t)0);
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_D[(e - 1) & 1u], 0));
+        const unsigned int from = std::max(e - 2, h->spec_base);
+        const auto ver_kernel = xid ? lk_verify_kernel<true> : lk_verify_kernel<false>;
+        hipLaunchKernelGGL(ver_kernel, dim3(nblk_r), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, n, h->d_partials, ro, from, e - 1);
+    }
+    hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_partials, nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, snap);
+    HIPCHK(h, hipEventRecord(h->ev_U[e & 1u], h->stream));
+    // insert stream: the bucket's insert, from the snapshot of its posterior
+    HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_U[e & 1u], 0));
+    hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->ins, m, h->pr, snap, d_pts, n, d_world, 1);
+    hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->ins, m, h->pr, snap, d_pts, n);
+    HIPCHK(h, hipEventRecord(h->ev_D[e & 1u], h->ins));
+    const int grid = std::min(std::max((n + 3) / 4, 1), 512);
+    hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    HIPCHK(h, hipEventRecord(h->ev_I, h->ins));
+    HIPCHK(h, hipGetLastError());
+    h->spec_open = true;
+    h->spec_buckets += 1;
+    if (!first) h->spec_tiles += (uint64_t)nblk_r;
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
@@ -786,6 +910,14 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     if (do_insert) h->grid_valid = false;   // the map changes: batch replay rebuilds its root grid
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
+    if (do_insert && h->spec_enable && !h->profiling && n > LK_SMALL_MAX) {
+        static const bool xid_en = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+        return enqueue_bucket_spec(h, d_pts, n, t, d_world, h->pr.ext_identity && xid_en);
+    }
+    if (h->spec_open) {   // a bucket on the sequential path follows the inserts in flight
+        int rcj = spec_join(h);
+        if (rcj) return rcj;
+    }
 #ifdef LK_DEBUG_PHASES
     if (n <= LK_SMALL_MAX && do_insert) {
         static unsigned long long* dbg = nullptr;
@@ -1431,6 +1563,7 @@ int lk_update_points(lk_handle* h, double t, const float* xyz_body, size_t n, fl
     if (rc) return rc;
     rc = enqueue_bucket(h, h->d_scan, (int)n, t, h->d_world, true);
     if (rc) return rc;
+    if ((rc = spec_join(h))) return rc;
     std::vector<float> w(4 * n);
     int lastN = 0;
     HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1522,6 +1655,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
         if (rc) return rc;
         idx_i = idx_j;
     }
+    if ((rc = spec_join(h))) return rc;   // the last buckets' inserts (pipelined stream path) precede the read-backs below
     std::vector<float> w;
     if (xyz_world_out) {
         w.resize(4 * n);
@@ -1552,6 +1686,7 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
         rc = enqueue_bucket(h, d_pts + bucket_off[b], nb, t_begin + bucket_dt[b], nullptr, true);
         if (rc) return rc;
     }
+    if ((rc = spec_join(h))) return rc;
     lk_pose pose;
     rc = fetch_poses(h, &pose, 1);
     if (rc) return rc;
@@ -2253,6 +2388,39 @@ int lk_synchronize(lk_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
         if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));  // double-buffered async batches live there
+    return LK_OK;
+}
+int lk_stream_pipeline(lk_handle* h, int on) {
+    CHECK_H(h);   // joins the inserts in flight
+    h->spec_enable = on != 0;
+    return LK_OK;
+}
+int lk_stream_stats(lk_handle* h, uint64_t* out4) {
+    CHECK_H(h);
+    if (!out4) return fail(h, LK_ERR_INVALID, "out4 is null");
+#ifdef LK_DEBUG_INS
+    {
+        unsigned long long hb[16];
+        unsigned int ctr[LK_CTR_COUNT];
+        hipStreamSynchronize(h->stream);
+        hipMemcpyFromSymbol(hb, HIP_SYMBOL(lk_ins_dbg), sizeof(hb));
+        hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost);
+        const char* names[8] = {"desc+node", "points", "simulate", "stores", "eigen", "plane_var", "commit", "tail"};
+        fprintf(stderr, "[ins] %llu groups, %llu fitted; per group (us):", hb[15], hb[14]);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f;", names[k], (double)hb[k] / (double)(hb[15] ? hb[15] : 1) * 0.01);
+        fprintf(stderr, "\n[ins] plane_var: %.0f shader cycles and %.2f us per fit -> %.2f GHz", (double)hb[12] / (double)(hb[14] ? hb[14] : 1),
+                (double)hb[13] / (double)(hb[14] ? hb[14] : 1) * 0.01, (double)hb[12] / ((double)hb[13] * 10.0 + 1e-9));
+        fprintf(stderr, "\n[ins] last bucket: touched %u heavy %u groups %u gidx %u fallback %u\n", ctr[LK_CTR_TOUCHED], ctr[LK_CTR_HEAVY],
+                ctr[LK_CTR_GROUPS], ctr[LK_CTR_GIDX], ctr[LK_CTR_FALLBACK]);
+    }
+#endif
+    unsigned int redo = 0;
+    HIPCHK(h, hipMemcpyAsync(&redo, h->map.counters + LK_CTR_SPEC_REDO, sizeof(redo), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (redo < h->spec_redo_seen) h->spec_redo_seen = 0;          // the device word is reset with the pools (map import)
+    h->spec_redo_total += (uint64_t)(redo - h->spec_redo_seen);
+    h->spec_redo_seen = redo;
+    out4[0] = h->spec_buckets, out4[1] = h->spec_tiles, out4[2] = h->spec_redo_total, out4[3] = 0;
     return LK_OK;
 }
 void* lk_stream(lk_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -35,10 +35,12 @@
 #define LK_E_BLOCKS_FULL 4u
 #define LK_E_SCRATCH_FULL 8u
 #define LK_E_BAD_BLOB 16u
+#define LK_E_SPEC_TIMEOUT 32u   // a verify wave of the pipelined stream path gave up waiting for the insert stream (bounded spin)
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,
        LK_CTR_HEAVY = 6, LK_CTR_FREE = 7 /* signed: blocks poppable this bucket */, LK_CTR_FREED = 8 /* blocks retired
        during this bucket */, LK_CTR_GROUPS = 9 /* leaf groups of this bucket */, LK_CTR_GIDX = 10 /* their indices */, LK_CTR_FALLBACK = 11 /* groups handed to the generic code */,
+       LK_CTR_SPEC_REDO = 12 /* cumulative: tiles the verify pass of the pipelined stream path evaluated again */,
        LK_CTR_COUNT = 16 };
 
 struct LkFilter {
@@ -118,6 +120,15 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int* free_list;              // point blocks that may be re-allocated during this bucket
     int* freed_next;             // point blocks retired during this bucket (allocatable from the next bucket on)
     unsigned int hash_mask, max_nodes, max_blocks, max_scan;
+    // Pipelined stream path (legkilo_hip.hip, "spec"): the insert of bucket k runs on its own HIP stream while bucket k+1's
+    // predict + residual pass run; whatever the insert may change under the residual pass is stamped with the bucket's epoch:
+    //   dirty[node]   root voxels (layer-0 node ids) whose subtree's planes may change: new roots, roots on the heavy list
+    //   newroot[h]    h = lk_hash3(key) & LK_NEWROOT_MASK of a root CREATED by the insert (a lookup that found nothing has no id)
+    //   spec[LK_SPEC_DONE]  epoch of the last insert that has completed (written by its last workgroup)
+    unsigned int* dirty;
+    unsigned int* newroot;
+    unsigned int* spec;
+    unsigned int epoch;          // epoch of the bucket whose insert this launch belongs to (0 outside the stream path)
     // Frozen-map acceleration structure of batch replay (frozen_map(), legkilo_hip.hip): the root voxels' match records in a
     // DENSE 3-D array over the bounding box of the root keys, so that the per-point chain scan point -> hash slot -> record
     // loses its middle trip (key -> cell index is arithmetic).  The cells live in the SAME array as the nodes' match records,
@@ -128,6 +139,8 @@ struct LkMap {                   // device pointers of one voxel map, passed by 
     int gmin[3], gdim[3];
     int grid_on;
 };
+#define LK_NEWROOT_MASK 16383u
+enum { LK_SPEC_DONE = 0, LK_SPEC_TICKET = 1, LK_SPEC_DECIDED = 2, LK_SPEC_TICKET2 = 3, LK_SPEC_WORDS = 16 };
 #define LK_GRID_EMPTY 0xffffffffu
 // A grid cell of a root that is NOT a plane is a list header: flags carries LK_GRID_LIST, the first 8 bytes (center[0]) hold
 // {first, count}: the plane nodes of the root's subtree in the pre-order of build_single_residual (voxel_map.cc:415-421),

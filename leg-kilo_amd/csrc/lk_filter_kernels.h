@@ -346,14 +346,8 @@ __device__ void dev_update_from_totals(LkFilter* f, FilterSmem& sm, double* tot,
 // reduce the per-wave partial records (fixed order -> deterministic) and update; partials: [nblk][LK_NPART] per slot.
 // do_predict != 0 (batch replay on a frozen map, where nothing reads the state between update(k) and predict(k+1)):
 // the predict of the NEXT bucket (time t_next) runs in the same launch.
-__global__ void __launch_bounds__(LK_FB)
-    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
-                     const double* __restrict__ Q, double t_next, int do_predict) {
-    __shared__ FilterSmem sm;
-    __shared__ double red[8][LK_NPART];
-    __shared__ double tot[LK_NPART];
-    LkFilter* f = &filters[blockIdx.x];
-    const double* part = partials + (size_t)blockIdx.x * slot_stride;
+__device__ __forceinline__ void dev_update_reduce(LkFilter* f, const double* __restrict__ part, int nblk, double t, const double* __restrict__ Q,
+                                                  double t_next, int do_predict, FilterSmem& sm, double (*red)[LK_NPART], double* tot) {
     const int tid = threadIdx.x;
     {
         const int j = tid % LK_NPART, g = tid / LK_NPART;  // 8 groups x 32 components
@@ -381,6 +375,33 @@ __global__ void __launch_bounds__(LK_FB)
         __syncthreads();  // f->x, f->P, f->last_update_t written above are re-read by dev_predict
         dev_predict(f, Q, t_next, sm);
     }
+}
+__global__ void __launch_bounds__(LK_FB)
+    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
+                     const double* __restrict__ Q, double t_next, int do_predict) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[8][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    dev_update_reduce(&filters[blockIdx.x], partials + (size_t)blockIdx.x * slot_stride, nblk, t, Q, t_next, do_predict, sm, red, tot);
+}
+// What the insert of a bucket needs of the posterior (load_bucket_const: R, p, the rotation / position blocks of P - all in rows
+// 0..5 of P - and `updated`), copied aside: in the pipelined stream path the insert runs on its own HIP stream while the main
+// stream already propagates filters[0] to the next bucket.
+__device__ __forceinline__ void dev_snapshot_posterior(const LkFilter* f, LkFilter* snap) {
+    __syncthreads();   // the update's global writes (this workgroup's) are visible to all its threads
+    const int tid = threadIdx.x;
+    if (tid < LK_STATE_DOUBLES) snap->x[tid] = f->x[tid];
+    if (tid < 180) snap->P[tid] = f->P[tid];
+    if (tid == 0) snap->updated = f->updated, snap->last_N = f->last_N;
+}
+// lk_update_kernel of the stream path (slot 0) + the posterior's snapshot for the insert stream
+__global__ void __launch_bounds__(LK_FB)
+    lk_update_snap_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, double t, const double* __restrict__ Q, LkFilter* snap) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[8][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    dev_update_reduce(&filters[0], partials, nblk, t, Q, 0.0, 0, sm, red, tot);
+    dev_snapshot_posterior(&filters[0], snap);
 }
 
 // ---- lk_update_kernel for batch replay as ONE WAVE per filter slot, in the resource footprint of a residual workgroup

@@ -16,6 +16,7 @@
 // writes, wave_fence() orders them before the other lanes' reads (same CU, workgroup scope).
 #pragma once
 #include "lk_device.h"
+#include "lk_eig3.h"
 
 #define LK_MB 256  // threads per block in the per-root kernels (4 waves = 4 roots in flight)
 
@@ -33,6 +34,48 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
+// Sums of N per-lane values over the wave, all N results in every lane - like N calls of wave_sum, but as a TRANSPOSE-REDUCE: at
+// the xor step m a lane keeps one half of its values and adds the partner's copy of that half (low lanes the first half, high lanes
+// the second), so the count halves with every step: ceil(N/2) + ceil(N/4) + ... exchanges instead of 6 N (N = 21: 24 instead of
+// 126; N = 9: 13 instead of 54), after which lane L holds the complete sum of ONE component, and 2 N v_readlane gather them.
+// The summation order differs from wave_sum's butterfly (a different, equally valid rounding of the same sum).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double* v) {
+    const int lane = threadIdx.x & 63;
+    constexpr int H5 = (N + 1) / 2, H4 = (H5 + 1) / 2, H3 = (H4 + 1) / 2, H2 = (H3 + 1) / 2, H1 = (H2 + 1) / 2, H0 = (H1 + 1) / 2;
+    auto step = [&](const int n, const int half, const int mask) {
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const double a = v[j];                              // first half  [0, half)
+            const double b = (half + j < n) ? v[half + j] : 0.0;   // second half [half, n), zero-padded
+            const double send = hi ? a : b, keep = hi ? b : a;
+            v[j] = keep + __shfl_xor(send, mask, LK_WAVE);
+        }
+    };
+    step(N, H5, 32);
+    step(H5, H4, 16);
+    step(H4, H3, 8);
+    step(H3, H2, 4);
+    step(H2, H1, 2);
+    step(H1, H0, 1);
+    // component c sits in v[0] of the lane whose bits select it: bit 5 adds H5, bit 4 adds H4, ... (compile-time per c)
+    double r[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        int rem = c, src = 0;
+        if (rem >= H5) rem -= H5, src |= 32;
+        if (rem >= H4) rem -= H4, src |= 16;
+        if (rem >= H3) rem -= H3, src |= 8;
+        if (rem >= H2) rem -= H2, src |= 4;
+        if (rem >= H1) rem -= H1, src |= 2;
+        if (rem >= H0) rem -= H0, src |= 1;
+        r[c] = lane_bcast_u(v[0], src);
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) v[c] = r[c];
+}
+
 struct PtU {  // one point, uniform across the wave
     double pw[3];
     double var[6];
@@ -46,8 +89,17 @@ __device__ __forceinline__ void load_pt(const lk_pt_rec* base, const int* idx, i
     for (int c = 0; c < 6; ++c) var[c] = r->var[c];
 }
 
-// symmetric 3x3 Jacobi eigen-solver; evecs columns = eigenvectors (stand-in for EigenSolver, voxel_map.cc:55)
+// symmetric 3x3 eigen-solver; evecs columns = eigenvectors (stand-in for EigenSolver, voxel_map.cc:55).  Default: the closed form
+// of lk_eig3.h (one plane fit is the serial work of one wave: ~0.5 us instead of the 3.8 us of 6-7 Jacobi sweeps); -DLK_EIG_JACOBI=1
+// keeps the cyclic Jacobi iteration the oracle runs (A/B).
+#ifndef LK_EIG_JACOBI
+#define LK_EIG_JACOBI 0
+#endif
 __device__ __forceinline__ void eig_sym3_dev(const double* Ain, double* ev, double* V) {
+#if !LK_EIG_JACOBI
+    lk_eig_sym3(Ain, ev, V);
+    return;
+#endif
     double a[3][3] = {{Ain[0], Ain[1], Ain[2]}, {Ain[1], Ain[3], Ain[4]}, {Ain[2], Ain[4], Ain[5]}};
     double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -232,8 +284,7 @@ __device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool activ
             s[3] += pw[0] * pw[0], s[4] += pw[0] * pw[1], s[5] += pw[0] * pw[2];
             s[6] += pw[1] * pw[1], s[7] += pw[1] * pw[2], s[8] += pw[2] * pw[2];
         }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) s[q] = wave_sum(s[q]);
+        wave_sum_n<9>(s);
     }
     const double n = (double)count;
     PlaneFit f;
@@ -318,31 +369,45 @@ __device__ __forceinline__ void plane_var_regs(const PlaneFit& f, const double* 
 #pragma unroll
             for (int cc = r; cc < 6; ++cc) acc[k++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
     }
-#pragma unroll
-    for (int q = 0; q < 21; ++q) acc[q] = wave_sum(acc[q]);
+    wave_sum_n<21>(acc);
 }
-// lane 0 writes the plane (and its compact match copy) exactly like the tail of dev_init_plane
+// lane 0 writes the plane and its compact match copy, both from registers (the match record is derived from the values, not read
+// back from the plane record just stored).  No fence: nothing in the apply pass reads a plane it has committed.
 __device__ __forceinline__ void plane_commit(lk_plane_rec* pl, lk_match_rec* mr, const PlaneFit& f, const double* acc, int count) {
     if ((threadIdx.x & 63) == 0) {
         pl->points_size = count;
         if (f.is_plane) {
+            lk_plane_rec t;   // in registers
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pl->center[k] = f.c[k], pl->normal[k] = f.vmin[k];
+            for (int k = 0; k < 3; ++k) t.center[k] = f.c[k], t.normal[k] = f.vmin[k];
 #pragma unroll
-            for (int q = 0; q < 21; ++q) pl->plane_var[q] = acc[q];
+            for (int q = 0; q < 21; ++q) t.plane_var[q] = acc[q];
+            t.radius = (float)sqrt(f.emax);
+            t.d = (float)(-(f.vmin[0] * f.c[0] + f.vmin[1] * f.c[1] + f.vmin[2] * f.c[2]));
+            t.flags = LK_PLANE_IS_PLANE | LK_PLANE_IS_INIT;
+            lk_match_rec m;
+            lk_derive_match(&t, &m);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pl->center[k] = t.center[k], pl->normal[k] = t.normal[k];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) pl->plane_var[q] = t.plane_var[q];
             pl->min_eigen_value = (float)f.emin;
             pl->mid_eigen_value = (float)f.emid;
             pl->max_eigen_value = (float)f.emax;
-            pl->radius = (float)sqrt(f.emax);
-            pl->d = (float)(-(f.vmin[0] * f.c[0] + f.vmin[1] * f.c[1] + f.vmin[2] * f.c[2]));
-            pl->flags = LK_PLANE_IS_PLANE | LK_PLANE_IS_INIT;
-            lk_derive_match(pl, mr);
+            pl->radius = t.radius;
+            pl->d = t.d;
+            pl->flags = t.flags;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mr->center[k] = m.center[k], mr->normal[k] = m.normal[k], mr->w[k] = m.w[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mr->s11[k] = m.s11[k];
+            mr->d = m.d, mr->radius = m.radius, mr->flags = m.flags, mr->pad_ = 0, mr->s22 = m.s22;
         } else {
-            pl->flags = pl->flags & ~LK_PLANE_IS_PLANE;
-            mr->flags = pl->flags;
+            const unsigned int fl = pl->flags & ~LK_PLANE_IS_PLANE;
+            pl->flags = fl;
+            mr->flags = fl;
         }
     }
-    wave_fence();
 }
 
 // ---- node helpers (wave-uniform; lane 0 writes)
@@ -418,11 +483,11 @@ __device__ __forceinline__ NodeRegs node_load(const lk_node_rec* nd) {
     r.layer = bcast0(nd->layer), r.state = (unsigned int)bcast0((int)nd->state);
     return r;
 }
-__device__ __forceinline__ void node_store(lk_node_rec* nd, const NodeRegs& r) {
+__device__ __forceinline__ void node_store(lk_node_rec* nd, const NodeRegs& r, const bool fence = true) {
     if ((threadIdx.x & 63) == 0) {
         nd->npts = r.npts, nd->new_points = r.new_points, nd->block = r.block, nd->state = r.state;
     }
-    wave_fence();
+    if (fence) wave_fence();   // fence = false: nothing in this wave reads the record again (end of a group of the apply pass)
 }
 // temp_points_.push_back(pv)
 __device__ __forceinline__ void node_push(const LkMap& m, NodeRegs& r, const PtU& pt) {
@@ -577,6 +642,13 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
 //                            the per-point state machine as the fallback.  A root with six leaf groups is six work
 //                            items running side by side; before the split the slowest root (4-6 groups one after the
 //                            other, 80-150 k cycles against a mean of 36 k) set the kernel's duration.
+#ifdef LK_DEBUG_INS
+// DEBUG BUILD ONLY (-DLK_DEBUG_INS): 100 MHz stamps per phase of the apply pass, summed over all groups; [15] = groups
+__device__ unsigned long long lk_ins_dbg[16];
+#define INS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&lk_ins_dbg[k], t1_ - t0_); t0_ = t1_; } while (0)
+#else
+#define INS_STAMP(k) do { } while (0)
+#endif
 struct LkGroup {       // 32 B
     int leaf;          // target leaf, or -1: child `oct` of `parent` has to be created first
     int parent, oct;
@@ -749,6 +821,10 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
         }
     };
     for (int t = wave; t < n_groups; t += nwaves) {
+#ifdef LK_DEBUG_INS
+        unsigned long long t0_ = wall_clock64();
+        if (lane == 0) atomicAdd(&lk_ins_dbg[15], 1ull);
+#endif
         const int4 d0 = reinterpret_cast<const int4*>(&groups[t])[0], d1 = reinterpret_cast<const int4*>(&groups[t])[1];
         const int Tn = bcast0(d0.x), Tp = bcast0(d0.y), To = bcast0(d0.z), off = bcast0(d0.w), g = bcast0(d1.x),
                   kind = bcast0(d1.y), root = bcast0(d1.z);
@@ -770,6 +846,7 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
         const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
         const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
         const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
+        INS_STAMP(0);   // descriptor + node record
         if (!uninit && !live && (lplane || maxnp)) continue;  // frozen leaf ignores its points
         int consumed = 0;
         bool need_init = false;
@@ -793,6 +870,7 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
                     for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
                 }
             }
+            INS_STAMP(1);   // block points + the group's points derived
             const int thr = pr.layer_init_num[L];
             int cur = n0, newp = r.new_points;
             int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
@@ -840,6 +918,7 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
                     if (cur > pr.max_points_num) frozen = true, stop = true;
                 }
             }
+            INS_STAMP(2);   // event simulation
             // ---- commit points, counters, one full fit
             if (cur > n0 && r.block < 0) r.block = alloc_block(map);
             if (lane >= n0 && lane < cur) {
@@ -852,7 +931,7 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
             r.npts = cur;
             if (general_init) {
                 r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
-                node_store(ln, r);
+                node_store(ln, r, false);
                 need_init = true;    // the generic code cuts the voxel: lk_insert_fallback_kernel
             } else {
                 r.new_points = newp;
@@ -862,19 +941,33 @@ __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParam
                     double s9[9];   // the last event tested exactly these fit_count points
 #pragma unroll
                     for (int q = 0; q < 9; ++q) s9[q] = fit.s9[q];
+                    INS_STAMP(3);   // point stores
                     fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold, s9);
+                    INS_STAMP(4);   // eigen-decomposition
                     fit.is_plane = decided;  // control flow above already followed the event's decision
                     double acc21[21];
+#ifdef LK_DEBUG_INS
+                    const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
+#endif
                     if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
+#ifdef LK_DEBUG_INS
+                    if (lane == 0) atomicAdd(&lk_ins_dbg[12], clock64() - c0_), atomicAdd(&lk_ins_dbg[13], wall_clock64() - w0_);
+#endif
+                    INS_STAMP(5);   // plane_var
                     plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
+                    INS_STAMP(6);   // commit
+#ifdef LK_DEBUG_INS
+                    if (lane == 0) atomicAdd(&lk_ins_dbg[14], 1ull);
+#endif
                     r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
                     if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
                 }
                 if (frozen) node_freeze(map, r);
-                node_store(ln, r);
+                node_store(ln, r, false);
                 if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
             }
         }
+        INS_STAMP(7);   // node store, tail
         // ---------------- a cut and / or whatever is left of the group: the generic state machine, in its own kernel
         if (need_init || consumed < g) defer(LkGroup{leaf, -1, need_init ? 1 : 0, off + consumed, g - consumed, 2, root, L});
     }
@@ -962,6 +1055,19 @@ __global__ void __launch_bounds__(LK_MB)
     lk_insert_fallback_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                            const lk_pt_rec* __restrict__ pv, int n) {
     dev_insert_fallback<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+    // last kernel of a bucket's insert: its last workgroup publishes the bucket's epoch (pipelined stream path: what a verify wave
+    // with suspect points waits for, lk_verify_kernel)
+    if (map.epoch != 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned int t = atomicAdd(&map.spec[LK_SPEC_TICKET], 1u);
+            if (t == gridDim.x - 1) {
+                map.spec[LK_SPEC_TICKET] = 0;
+                __hip_atomic_store(&map.spec[LK_SPEC_DONE], map.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // Light pre-pass of the insert: ONE THREAD per touched root.  Most touched roots only need their few new points
@@ -990,6 +1096,7 @@ __device__ __forceinline__ void dev_insert_light_root(const LkMap& map, const Lk
     if (!light) {
         unsigned int hpos = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
         map.heavy[hpos] = root;
+        map.dirty[root] = map.epoch;   // pipelined stream path: a plane of this root's subtree may change in this bucket (LkMap::dirty)
         return;
     }
     int i0, i1, i2, i3, i4, i5, i6, i7;

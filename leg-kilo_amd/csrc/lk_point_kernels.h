@@ -254,7 +254,20 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
     double* R;
     unsigned char* valid;
     float* world;          // n x 4 (x y z intensity), cloud_down_world
+    int2* ids;             // SPEC instantiations only: per point {home, neighbour} root code of the lookups (spec_code)
 };
+// What a speculative residual pass (the pipelined stream path) remembers of a point's two root lookups, so that the verify pass
+// can tell whether an insert that ran beside it may have changed the point's result: a root id (>= 0), or - the lookup found no
+// root - the complement of the key's slot in LkMap::newroot, or LK_SPEC_NONE when no lookup was made.
+#define LK_SPEC_NONE ((int)0x80000000)
+__device__ __forceinline__ int spec_code(int root, const int* key) {
+    return root >= 0 ? root : ~(int)(lk_hash3(key[0], key[1], key[2]) & LK_NEWROOT_MASK);
+}
+__device__ __forceinline__ bool spec_suspect(const LkMap& m, int code, unsigned int from) {
+    if (code == LK_SPEC_NONE) return false;
+    const unsigned int stamp = code >= 0 ? m.dirty[code] : m.newroot[~code];
+    return stamp >= from;
+}
 
 // LDS row record of one point: h(6), z, 1/R, R   (9 doubles; stride 9 keeps 64-bit LDS reads conflict-free
 // for the access pattern of the reduction: lanes of one half-wave read the SAME row, i.e. broadcasts)
@@ -273,7 +286,7 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
 // SHORT (the small-bucket kernels, where a tile usually holds a handful of points): the sums run over the rows that hold points,
 // rounded up to eight - the rows behind them are zero rows, and fma(0, 0, acc) == acc for every acc this loop can hold (it starts
 // at +0 and can never become -0), so the bits are those of the full loop.
-template <bool EMIT_ROWS, int GRID = 2, bool XID = false, bool SHORT = false>
+template <bool EMIT_ROWS, int GRID = 2, bool XID = false, bool SHORT = false, bool SPEC = false>
 __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams& pr, const BucketConst& bc,
                                                 const float4* __restrict__ spts, int i, int n, double* rows, int lane,
                                                 const ResidualOut& out, size_t out_base) {
@@ -293,6 +306,8 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             int key[3];
             key_trunc(g.p_w, pr, loc, key);
             root = find_root<GRID>(map, key[0], key[1], key[2]);  // KILO.cc:149
+            // stored at once (not carried through the match): registers set this kernel's occupancy
+            if (SPEC) out.ids[out_base + i] = make_int2(spec_code(root, key), LK_SPEC_NONE);
         }
         // K2: home voxel first (the root's 144-B record is fetched in one round trip inside match_root)
         bool success = false;
@@ -309,7 +324,10 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             key_trunc(g.p_w, pr, loc, key);
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
-            if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = find_root<GRID>(map, near[0], near[1], near[2]);
+            if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) {
+                nroot = find_root<GRID>(map, near[0], near[1], near[2]);
+                if (SPEC) out.ids[out_base + i].y = spec_code(nroot, near);
+            }
             if (nroot >= 0) {
                 if (grid_cell) match_flat<XID>(map, nroot, g, bc, pr, success, prob, best);
                 else match_root<XID>(map, nroot, false, g, bc, pr, success, prob, best);
@@ -430,7 +448,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
 }
 
 // One partial record per WAVE -> lk_update_kernel adds them in a fixed order (deterministic).
-template <bool EMIT_ROWS, int GRID = 0, bool XID = false>
+template <bool EMIT_ROWS, int GRID = 0, bool XID = false, bool SPEC = false>
 __global__ void LK_RES_BOUNDS
     lk_residual_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                        size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride,
@@ -442,12 +460,53 @@ __global__ void LK_RES_BOUNDS
     const int lane = tid & 63, wv = tid >> 6;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
-    const double acc = residual_tile<EMIT_ROWS, GRID, XID>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
+    const double acc = residual_tile<EMIT_ROWS, GRID, XID, false, SPEC>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
                                                 blockIdx.x * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
     if (lane < LK_NPART) {
         const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
         partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
     }
+}
+
+// ---------------------------------------------------------------- pipelined stream path: verify pass
+// The stream path runs the insert of bucket k on its own HIP stream while bucket k+1's predict + residual pass (SPEC
+// instantiation: it also stores each point's two root codes) run on the main stream.  An insert changes what a point's match can
+// see only inside the subtrees of the roots it stamps (LkMap::dirty / newroot).  This pass runs when those stamps are final: a tile
+// none of whose points looked at a stamped root keeps its speculative partial record - it was computed from data no insert touched
+// - and any other tile waits until the insert has completed (LK_SPEC_DONE, bounded spin) and is evaluated again, from scratch.
+// The result is what the sequential order predict -> residual would have produced after the insert: same code, same bits.
+__device__ __forceinline__ void spec_wait(const LkMap& m, int word, unsigned int need) {
+    if (need != 0 && (threadIdx.x & 63) == 0) {
+        const unsigned long long t0 = wall_clock64();   // 100 MHz constant clock
+        while (__hip_atomic_load(&m.spec[word], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 20000000ull) {   // 0.2 s: the insert stream is not making progress - fail the call, never hang
+                atomicOr(&m.counters[LK_CTR_ERR], LK_E_SPEC_TIMEOUT);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <bool XID>
+__global__ void LK_RES_BOUNDS
+    lk_verify_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n,
+                     double* __restrict__ partials, ResidualOut out, unsigned int dirty_from, unsigned int need_done) {
+    __shared__ double stage[64 * LK_ROW2];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * LK_RB + lane;
+    bool susp = false;
+    if (i < n) {
+        const int2 c = out.ids[i];
+        susp = spec_suspect(map, c.x, dirty_from) || spec_suspect(map, c.y, dirty_from);
+    }
+    if (__ballot(susp) == 0ull) return;
+    if (lane == 0) atomicAdd(&map.counters[LK_CTR_SPEC_REDO], 1u);
+    spec_wait(map, LK_SPEC_DONE, need_done);
+    BucketConst bc;
+    load_bucket_const<false>(&filters[0], pr, bc);
+    const double acc = residual_tile<false, 0, XID>(map, pr, bc, reinterpret_cast<const float4*>(pts), i, n, stage, lane, out, (size_t)0);
+    if (lane < LK_NPART) partials[(size_t)blockIdx.x * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
 }
 
 // Ragged batch: bucket b of every scan that has one.  grid = (waves of the LARGEST bucket b, scans); a workgroup beyond
@@ -523,6 +582,10 @@ __device__ __forceinline__ int root_find_or_create(const LkMap& m, const LkParam
                 nd->pad_[0] = 0;  // list count
                 m.planes[id].flags = 0;
                 m.match[id].flags = 0;
+                // pipelined stream path: a residual pass that runs beside this insert may see the key absent or present - both the
+                // key (for lookups that found nothing) and the new root id are stamped with the insert's epoch (LkMap::dirty)
+                m.dirty[id] = m.epoch;
+                m.newroot[lk_hash3(key[0], key[1], key[2]) & LK_NEWROOT_MASK] = m.epoch;
                 slotw[4 * s + 0] = key[0];
                 slotw[4 * s + 1] = key[1];
                 slotw[4 * s + 2] = key[2];

@@ -196,6 +196,31 @@ def compare_maps(blob_a, blob_b, rtol=1e-6, ptol=1e-9):
     return stats
 
 
+def maps_identical(blob_a, blob_b):
+    """Two exports hold the SAME map bit for bit (node ids may differ: roots are created by racing threads): same voxels, same
+    tree shape, counters, state bits, plane records and stored points."""
+    A, B = canon_map(blob_a), canon_map(blob_b)
+    assert set(A) == set(B), ("root key sets differ", len(A), len(B))
+
+    def same(a, b, where):
+        for f in ("layer", "npts", "new_points", "is_plane", "state", "quater"):
+            assert a[f] == b[f], (where, f, a[f], b[f])
+        assert np.array_equal(a["center"], b["center"]), (where, "center")
+        if a["is_plane"]:
+            for f in ("center", "normal", "d", "radius", "flags", "points_size", "plane_var", "min_ev", "mid_ev", "max_ev"):
+                assert np.array_equal(a["plane"][f], b["plane"][f]), (where, "plane", f)
+        assert (a["pts"] is None) == (b["pts"] is None), (where, "points presence")
+        if a["pts"] is not None:
+            assert np.array_equal(a["pts"]["pw"], b["pts"]["pw"]) and np.array_equal(a["pts"]["var"], b["pts"]["var"]), (where, "points")
+        assert set(a["children"]) == set(b["children"]), (where, "children")
+        for o in a["children"]:
+            same(a["children"][o], b["children"][o], where + (o,))
+
+    for k in A:
+        same(A[k], B[k], (k,))
+    return len(A)
+
+
 def rows_close(h6a, za, Ra, h6b, zb, Rb, valid, rtol=1e-9):
     """Compare observation rows up to the per-row sign of the plane normal."""
     v = valid.astype(bool)

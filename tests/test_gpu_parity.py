@@ -575,6 +575,49 @@ def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
     o.close()
 
 
+def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
+    """The pipelined stream path (insert of bucket k on its own stream beside predict + residual of bucket k+1, verify pass,
+    legkilo_hip.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
+    sectors but a random partition of the whole scan, so every bucket's insert initialises / refits / cuts planes of root voxels
+    that the next bucket's points match - on a young map (sparse first frame), where most leaves are still live.  The verify
+    pass must find those tiles and evaluate them again after the insert: counts identical to the oracle on every scan, every state
+    entry to 1e-6, the same map - and bit for bit the state and map of the same library with the pipeline switched off."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    g_seq = hip_lib.LegKiloHip(scene.cfg())
+    g_seq.stream_pipeline(False)
+    t0 = 11.0
+    for obj in (o, g, g_seq):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, dense=20000)
+    rng = np.random.default_rng(424242)
+    for k in range(3):
+        tb = t0 + 0.1 * k
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=9100 + k, seed_noise=9200 + k)
+        curv = pts["curvature"].copy()
+        pts = pts[rng.permutation(len(pts))]     # the same five time stamps, now scattered over the whole scan
+        pts["curvature"] = curv
+        po, _ = o.process_scan(pts, tb)
+        pg, _ = g.process_scan(pts, tb)
+        ps, _ = g_seq.process_scan(pts, tb)
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (pg.n_buckets, pg.n_updates, int(pg.n_effect)) == (5, 5, int(ps.n_effect)), \
+            (k, po.n_effect, pg.n_effect, ps.n_effect)
+        xo, _ = o.get_state()
+        xg, Pg = g.get_state()
+        xs, Ps = g_seq.get_state()
+        assert np.abs(xo - xg).max() < 1e-6, (k, np.abs(xo - xg).max())
+        assert np.array_equal(xg, xs) and np.array_equal(Pg, Ps), (k, np.abs(xg - xs).max())
+    n_buckets, n_tiles, n_redo = g.stream_stats()
+    assert n_buckets == 15 and n_tiles == 3 * 4 * 313, (n_buckets, n_tiles)   # the first bucket of a scan has nothing to verify
+    assert n_redo > 100, n_redo           # the conflicts were really there ...
+    assert g_seq.stream_stats()[0] == 0   # ... and the reference run really was sequential
+    assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
+    scenes.maps_identical(g.map_export(), g_seq.map_export())
+    print("forced conflicts: tiles verified", n_tiles, "evaluated again", n_redo)
+    for obj in (g, g_seq, o):
+        obj.close()
+
+
 def test_config2_full_size_residuals(big, hip_lib):
     """Config 2: 100 000 points, one state, residual rows only, against the map the ORACLE built (SURVEY.md 8d:
     'map pre-built by replaying warm-up scans through the oracle') - isolates K1+K2 at full size."""
