@@ -268,7 +268,7 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     HIPCHK(h, hipMalloc(&m.next, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.slots, sizeof(int) * (size_t)LK_SLOTS * (size_t)m.max_nodes));
     HIPCHK(h, hipMalloc(&m.scratch, sizeof(int) * (size_t)m.max_scan));
-    HIPCHK(h, hipMalloc(&m.groups, sizeof(int) * 8 * 2 * (size_t)m.max_scan));
+    HIPCHK(h, hipMalloc(&m.groups, sizeof(LkGroup) * 2 * (size_t)m.max_scan));   // leaf-group descriptors, then the fallback items
     HIPCHK(h, hipMalloc(&m.gidx, sizeof(int) * (size_t)m.max_scan));
     HIPCHK(h, hipMalloc(&m.free_list, sizeof(int) * (size_t)m.max_blocks));
     HIPCHK(h, hipMalloc(&m.freed_next, sizeof(int) * (size_t)m.max_blocks));
@@ -616,82 +616,7 @@ __global__ void __launch_bounds__(LK_WAVE)
         for (int i = lane; i < n; i += LK_WAVE) dev_reproject_point(map, pr, filters, pts, world, reproject == 2 ? 1 : 0, i);
     }
 }
-// Tiny buckets: the light insert (one thread per touched root) and the group pass (one wave per root on the work list) of the
-// per-root insert as ONE single-workgroup launch - the same dev_insert_light_root / dev_insert_group as the two kernels it replaces,
-// which decide per root, so the result does not depend on which wave handles a root.
-__global__ void __launch_bounds__(LK_MB)
-    lk_insert_light_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, int n) {
-    const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int r = threadIdx.x; r < n_touched; r += LK_MB) dev_insert_light_root(map, pr, filters, pts, r);
-    __threadfence();
-    __syncthreads();
-    dev_insert_group<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
-}
 extern "C" {
-
-#ifdef LK_DEBUG_PHASES
-// DEBUG BUILD ONLY (-DLK_DEBUG_PHASES): the whole small bucket in one workgroup with cycle stamps per phase, to see where a
-// bucket's ~30 us go.  dbg[0..9] accumulate s_memtime deltas (100 MHz constant clock), dbg[15] counts buckets.
-__device__ __forceinline__ void phase_fence() {
-    __threadfence();
-    __syncthreads();
-}
-__global__ void __launch_bounds__(LK_FB)
-    lk_small_bucket_dbg_kernel(LkMap map, LkParams pr, LkFilter* filters, const double* __restrict__ Q, double t,
-                               const lk_point* __restrict__ pts, int n, float* world, int do_insert, unsigned long long* dbg) {
-    __shared__ FilterSmem sm;
-    __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
-    __shared__ double red[LK_FB / LK_WAVE][LK_NPART];
-    __shared__ double tot[LK_NPART];
-    LkFilter* f = &filters[0];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long t0 = wall_clock64(), t1;
-#define STAMP(k) do { __syncthreads(); t1 = wall_clock64(); if (tid == 0) dbg[k] += t1 - t0; t0 = t1; } while (0)
-    dev_bucket_begin(map);
-    STAMP(0);
-    dev_predict(f, Q, t, sm);
-    STAMP(1);
-    {
-        BucketConst bc;
-        load_bucket_const<false>(f, pr, bc);
-        ResidualOut ro;
-        ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = world;
-        double acc = 0.0;
-        for (int base = wv * LK_WAVE; base < n; base += LK_FB) {
-            __builtin_amdgcn_wave_barrier();
-            acc += residual_tile<false>(map, pr, bc, reinterpret_cast<const float4*>(pts), base + lane, n, &rows[wv][0], lane, ro, (size_t)0);
-        }
-        if (lane < LK_NPART) red[wv][lane] = (lane < 29) ? acc : 0.0;
-    }
-    __syncthreads();
-    if (tid < LK_NPART) {
-        double s = 0.0;
-        for (int w = 0; w < LK_FB / LK_WAVE; ++w) s += red[w][tid];
-        tot[tid] = s;
-    }
-    STAMP(2);
-    dev_update_from_totals(f, sm, tot, t);
-    STAMP(3);
-    phase_fence();
-    STAMP(4);
-    for (int i = tid; i < n; i += LK_FB) dev_reproject_point(map, pr, filters, pts, world, do_insert, i);
-    STAMP(5);
-    phase_fence();
-    {
-        const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int r = tid; r < n_touched; r += LK_FB) dev_insert_light_root(map, pr, filters, pts, r);
-    }
-    STAMP(6);
-    phase_fence();
-    dev_insert_group<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, wv, LK_FB / LK_WAVE);
-    STAMP(7);
-    phase_fence();
-    dev_insert_apply<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, wv, LK_FB / LK_WAVE);
-    STAMP(8);
-    if (tid == 0) dbg[15] += 1;
-#undef STAMP
-}
-#endif
 
 // Ragged batch of SMALL buckets (a real scan: 2 ms time bins of tens of points): the whole bucket chain of a scan - predict,
 // residual tiles, update, predict, ... - as ONE WAVE in one launch.  State and covariance stay in LDS from the first
@@ -889,10 +814,9 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
     // insert stream: the bucket's insert, from the snapshot of its posterior
     HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_U[e & 1u], 0));
     hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->ins, m, h->pr, snap, d_pts, n, d_world, 1);
-    hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->ins, m, h->pr, snap, d_pts, n);
-    HIPCHK(h, hipEventRecord(h->ev_D[e & 1u], h->ins));
     const int grid = std::min(std::max((n + 3) / 4, 1), 512);
-    hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    HIPCHK(h, hipEventRecord(h->ev_D[e & 1u], h->ins));   // the stamps are final: new roots (re-projection), roots whose planes may change (root pass)
     hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
     hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
     HIPCHK(h, hipEventRecord(h->ev_I, h->ins));
@@ -918,29 +842,6 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         int rcj = spec_join(h);
         if (rcj) return rcj;
     }
-#ifdef LK_DEBUG_PHASES
-    if (n <= LK_SMALL_MAX && do_insert) {
-        static unsigned long long* dbg = nullptr;
-        if (!dbg) {
-            hipMalloc(&dbg, 16 * sizeof(unsigned long long));
-            hipMemset(dbg, 0, 16 * sizeof(unsigned long long));
-        }
-        hipLaunchKernelGGL(lk_small_bucket_dbg_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters, h->d_Q, t, d_pts, n, d_world, 1, dbg);
-        LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                        h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
-        static int calls = 0;
-        if (++calls % 3000 == 0) {
-            unsigned long long hb[16];
-            hipStreamSynchronize(h->stream);
-            hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
-            const char* names[9] = {"bucket_begin", "predict", "residual", "update", "fence", "reproject", "light", "group", "apply"};
-            fprintf(stderr, "[phases] %llu buckets:", hb[15]);
-            for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.2f us;", names[k], (double)hb[k] / (double)hb[15] * 0.01);
-            fprintf(stderr, "\n");
-        }
-        return LK_OK;
-    }
-#endif
     // the stream path's residual code specialised for ext_R == I like the batch kernel (LEGKILO_XID=0: generic)
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const bool xid = h->pr.ext_identity && xid_enable;
@@ -974,19 +875,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
                                                   h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
     if (do_insert) {
-        if (fuse)
-            LAUNCH(h, "insert_light_group", hipLaunchKernelGGL(lk_insert_light_group_kernel, dim3(1), dim3(LK_MB), 0, h->stream, m, h->pr,
-                                                               h->d_filters, d_pts, n));
-        else
-            LAUNCH(h, "insert_light", hipLaunchKernelGGL(lk_insert_light_kernel, dim3(nblk), dim3(256), 0, h->stream, m, h->pr,
-                                                         h->d_filters, d_pts, n));
-        // ordered part: group pass (one wave per root, light), apply pass (one wave per leaf group; 2 resident waves
-        // per SIMD at 206 VGPRs: 512 blocks x 4 waves is exactly one resident round on 256 CUs), then the generic
-        // fallback for the few groups that need it; all loops are grid-stride and read their work counts on the device
+        // one wave per touched root (append / group / apply of single-group roots), then one wave per emitted leaf group (2 resident
+        // waves per SIMD at ~200 VGPRs: 512 blocks x 4 waves is one resident round on 256 CUs), then the generic fallback for the few
+        // groups that need it; all loops are grid-stride and read their work counts on the device
         int grid = std::min(std::max((n + 3) / 4, 1), 512);
-        if (!fuse)
-            LAUNCH(h, "insert_group", hipLaunchKernelGGL(lk_insert_group_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                         h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+        LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                    h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
@@ -1158,8 +1052,8 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n) 
     const int nb = (int)((n + 255) / 256);
     LAUNCH(h, "queue_pv", hipLaunchKernelGGL(lk_queue_pv_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr, d_pv, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
-    LAUNCH(h, "insert_pv_group", hipLaunchKernelGGL(lk_insert_group_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                    h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
+    LAUNCH(h, "insert_pv_root", hipLaunchKernelGGL(lk_insert_root_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                   h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     LAUNCH(h, "insert_pv", hipLaunchKernelGGL(lk_insert_apply_kernel<true>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                               h->d_filters, (const lk_point*)nullptr, d_pv, (int)n));
     LAUNCH(h, "insert_pv_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<true>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
@@ -2398,6 +2292,24 @@ int lk_stream_pipeline(lk_handle* h, int on) {
 int lk_stream_stats(lk_handle* h, uint64_t* out4) {
     CHECK_H(h);
     if (!out4) return fail(h, LK_ERR_INVALID, "out4 is null");
+#ifdef LK_DEBUG_LI
+    {
+        unsigned long long hb[64];
+        hipStreamSynchronize(h->stream);
+        hipMemcpyFromSymbol(hb, HIP_SYMBOL(lk_li_dbg), sizeof(hb));
+        fprintf(stderr, "[li] %llu mismatches, %llu traced\n", hb[0], hb[60]);
+        for (int k = 0; k < 4 && k < (int)hb[60]; ++k) {
+            const unsigned long long* o = hb + 1 + 14 * k;
+            fprintf(stderr, "[tr] leaf %d root %d Tn %d Tp %d To %d g %d r.npts %d r.block %d layer %d newp %d state %llx consumed %d need_init %d off %d\n", (int)o[0], (int)o[1],
+                    (int)o[2], (int)o[3], (int)o[4], (int)o[5], (int)o[6], (int)o[7], (int)o[8], (int)o[9], o[10], (int)o[11], (int)o[12], (int)o[13]);
+        }
+        for (int k = 0; k < 4 && k < (int)hb[0]; ++k) {
+            const unsigned long long* o = hb + 1 + 14 * k;
+            fprintf(stderr, "[li] leaf %lld root %lld npts %d/%d newp %d/%d block %d/%d layer %lld/%lld state %llx/%llx plane %lld off %lld\n", (long long)o[0], (long long)o[1],
+                    (int)o[2], (int)o[3], (int)o[4], (int)o[5], (int)o[6], (int)o[7], (long long)o[8], (long long)o[9], o[10], o[11], (long long)o[12], (long long)o[13]);
+        }
+    }
+#endif
 #ifdef LK_DEBUG_INS
     {
         unsigned long long hb[16];

@@ -1,6 +1,6 @@
 // lk_map_kernels.h — voxel-map mutation: one WAVE (64 lanes) owns one root voxel.
 //
-//   lk_insert_group_kernel + lk_insert_apply_kernel
+//   lk_insert_root_kernel + lk_insert_apply_kernel
 //                         UpdateVoxelMap / UpdateOctoTree (voxel_map.cc:336-361, :185-241) for the points
 //                         the re-projection kernel queued on each touched root.  Points of one root are
 //                         replayed in input order (successive-minimum selection over the root's list);
@@ -19,6 +19,9 @@
 #include "lk_eig3.h"
 
 #define LK_MB 256  // threads per block in the per-root kernels (4 waves = 4 roots in flight)
+#ifndef LK_X_CHILD_CONST
+#define LK_X_CHILD_CONST 1   // apply_leaf: a child it has just created is known without reading it back (0: node_load, A/B)
+#endif
 
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -37,7 +40,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // Sums of N per-lane values over the wave, all N results in every lane - like N calls of wave_sum, but as a TRANSPOSE-REDUCE: at
 // the xor step m a lane keeps one half of its values and adds the partner's copy of that half (low lanes the first half, high lanes
 // the second), so the count halves with every step: ceil(N/2) + ceil(N/4) + ... exchanges instead of 6 N (N = 21: 24 instead of
-// 126; N = 9: 13 instead of 54), after which lane L holds the complete sum of ONE component, and 2 N v_readlane gather them.
+// 126; N = 9: 13 instead of 54), after which lane L holds the complete sum of ONE component, and N more shuffles gather them.
 // The summation order differs from wave_sum's butterfly (a different, equally valid rounding of the same sum).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double* v) {
@@ -70,7 +73,10 @@ __device__ __forceinline__ void wave_sum_n(double* v) {
         if (rem >= H2) rem -= H2, src |= 4;
         if (rem >= H1) rem -= H1, src |= 2;
         if (rem >= H0) rem -= H0, src |= 1;
-        r[c] = lane_bcast_u(v[0], src);
+        // gathered with ds_bpermute, not v_readlane: 2 N scalar results at once (N = 21: 42 SGPRs on top of a kernel that already
+        // spills scalars) gave wrong values in lk_insert_root_kernel - varying with unrelated code changes - while the vector form
+        // is stable (round 3, tools A/B: -DLK_READLANE=0 fixed every failing test)
+        r[c] = __shfl(v[0], src, LK_WAVE);
     }
 #pragma unroll
     for (int c = 0; c < N; ++c) v[c] = r[c];
@@ -625,45 +631,63 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
     }
 }
 
-// One wave per touched root: gather the root's queued point indices, replay them in input order.
-// FROM_PV = false: points are re-derived from the scan (lk_point) and the post-update state — the same
-//                  point_geom() call the re-projection kernel hashed them with (bit-identical);
+// ------------------------------------------------------------------ the ordered insert
+// FROM_PV = false: points are re-derived from the scan (lk_point) and the post-update state - the same inlined transform the
+//                  re-projection kernel hashed them with (bit-identical);
 // FROM_PV = true : points are caller-supplied pointWithVar records (VoxelMapManager::UpdateVoxelMap).
-// ------------------------------------------------------------------ the ordered insert, in two passes
-// Work unit = one LEAF GROUP: the points of this bucket that land in the same leaf (or in the same not-yet-existing
-// child) of one root voxel, in input order.  Groups of one root touch disjoint subtrees (distinct leaves; distinct
-// child slots of a parent), so they are independent; the order INSIDE a group is the input order, which the
-// reference's result depends on.
-//   lk_insert_group_kernel   one wave per root on the work list: sort the root's queued indices in registers, walk
-//                            every point (read-only) to its target, form the groups with ballots, and emit per group
-//                            a descriptor + its indices in order.  No octree state is written here (only the root's
-//                            bucket-local queue is reset).  Small and latency-light: ~40 VGPRs.
-//   lk_insert_apply_kernel   one wave per GROUP: the register simulation of voxel_map.cc:186-237 for that leaf, with
-//                            the per-point state machine as the fallback.  A root with six leaf groups is six work
-//                            items running side by side; before the split the slowest root (4-6 groups one after the
-//                            other, 80-150 k cycles against a mean of 36 k) set the kernel's duration.
+// Work unit = one LEAF GROUP: the points of this bucket that land in the same leaf (or in the same not-yet-existing child) of one
+// root voxel, in input order.  Groups of one root touch disjoint subtrees (distinct leaves; distinct child slots of a parent), so
+// they are independent; the order INSIDE a group is the input order, which the reference's result depends on.
+//   lk_insert_root_kernel    one WAVE per touched root.  A root that only needs its few points appended (an un-initialised root
+//                            that stays below layer_init_num, a plane root that reaches neither its 6th new point - refit,
+//                            voxel_map.cc:195 - nor max_points_num - freeze, :199) is finished at once, one lane per point.
+//                            Otherwise the wave sorts the root's queued indices in registers, walks every point (read-only) to
+//                            its target and forms the groups with ballots.  ONE group (98 % of the roots): the wave applies it
+//                            right away - the points, the leaf's counters and its block id are already in registers, so nothing
+//                            is handed over through memory.  Several groups: one descriptor per group + its indices are emitted.
+//   lk_insert_apply_kernel   one wave per EMITTED group: the same register simulation of voxel_map.cc:186-237 (apply_leaf).  A root
+//                            with six leaf groups is six work items side by side; replayed one after the other by the root's wave
+//                            they set the kernel's duration (80-150 k cycles against a mean of 36 k).
+//   lk_insert_fallback_kernel  the generic per-point state machine for what the simulation hands over (cuts, leftovers, long lists).
+// Round 3: the root kernel replaces three launches (a thread-per-root light pass, a group pass, an apply pass that re-read
+// descriptor, indices, node record and scan points of every group): the insert of a bucket is a chain of dependent memory round
+// trips at a few waves per CU, and each hand-over through memory was another two or three of them.
 #ifdef LK_DEBUG_INS
-// DEBUG BUILD ONLY (-DLK_DEBUG_INS): 100 MHz stamps per phase of the apply pass, summed over all groups; [15] = groups
+// DEBUG BUILD ONLY (-DLK_DEBUG_INS): 100 MHz stamps per phase of apply_leaf, summed over all groups; [15] = groups
 __device__ unsigned long long lk_ins_dbg[16];
 #define INS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&lk_ins_dbg[k], t1_ - t0_); t0_ = t1_; } while (0)
 #else
 #define INS_STAMP(k) do { } while (0)
 #endif
-struct LkGroup {       // 32 B
+#ifdef LK_DEBUG_LI
+__device__ unsigned long long lk_li_dbg[64];
+#endif
+struct LkGroup {       // 64 B
     int leaf;          // target leaf, or -1: child `oct` of `parent` has to be created first
     int parent, oct;
     int off, count;    // indices map.gidx[off .. off+count) in input order; LONG: map.scratch[off .. off+count) unsorted
-    int kind;          // 0 = leaf group, 1 = LONG (a root with more than 64 queued points: per-point replay)
-    int root, pad;
+    int kind;          // 0 = leaf group, 1 = LONG (a root with more than 64 queued points: per-point replay), 2 = fallback item
+    int root, pad;     // kind 2: pad = layer of the leaf
+    // the leaf as the group pass saw it (leaf >= 0).  Nothing else writes the leaf before its group is applied: groups are disjoint
+    int npts, new_points, block, layer;
+    unsigned int state;
+    int is_plane, pad2[2];
+};
+static_assert(sizeof(LkGroup) == 64, "group descriptor must be 64 B");
+struct LeafInfo {
+    int npts, new_points, block, layer;
+    unsigned int state;
+    int is_plane;
 };
 
 template <bool FROM_PV>
 __device__ __forceinline__ void insert_point_pw(const LkParams& pr, const BucketConst& bc, const lk_point* __restrict__ pts,
-                                                const lk_pt_rec* __restrict__ pv, int idx, double* pw) {
+                                                const lk_pt_rec* __restrict__ pv, int idx, double* pw, float4& p4) {
     if (FROM_PV) {
         pw[0] = pv[idx].pw[0], pw[1] = pv[idx].pw[1], pw[2] = pv[idx].pw[2];
     } else {  // the same inlined transform as everywhere else (identical bits)
         const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+        p4 = p;
         V3 pb = V3{(double)p.x, (double)p.y, (double)p.z};
         V3 e = mat3_mul_v(pr.ext_R, pb);
         V3 pi = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
@@ -671,75 +695,311 @@ __device__ __forceinline__ void insert_point_pw(const LkParams& pr, const Bucket
         pw[0] = w.x + bc.p[0], pw[1] = w.y + bc.p[1], pw[2] = w.z + bc.p[2];
     }
 }
+__device__ __forceinline__ void geom_to_pt(const PointGeom& g, PtU& pt) {
+    pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
+    pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
+    pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
+}
+// groups that need the generic per-point code are queued behind the descriptors (kind 1: whole long list; kind 2: leaf `leaf`,
+// optional init_octo_tree (oct != 0, layer in pad), then gidx[off .. off+count) one by one)
+__device__ __forceinline__ void insert_defer(const LkMap& map, int leaf, int do_init, int off, int count, int kind, int root, int layer) {
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int q = atomicAdd(&map.counters[LK_CTR_FALLBACK], 1u);
+        if (q < map.max_scan) {
+            LkGroup d;
+            d.leaf = leaf, d.parent = -1, d.oct = do_init, d.off = off, d.count = count, d.kind = kind, d.root = root, d.pad = layer;
+            d.npts = d.new_points = d.block = d.layer = 0, d.state = 0, d.is_plane = 0, d.pad2[0] = d.pad2[1] = 0;
+            reinterpret_cast<LkGroup*>(map.groups)[map.max_scan + q] = d;
+        } else {
+            atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+        }
+    }
+}
 
-template <bool FROM_PV>
-__device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                           const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
+// ONE leaf group: the leaf `Tn` (or child `To` of `Tp`, created here) receives its g points in input order - the register
+// simulation of voxel_map.cc:186-237.  Lane L holds node point L: existing points from the leaf's block, then the group's points in
+// order, fetched through point_at(rr, valid, pt) (called by ALL lanes: it may shuffle).  Only the first gs points fit in the wave;
+// that is always enough to reach the freeze of a leaf (npts <= max_points_num + 1 <= 64), after which the rest of the group is
+// ignored anyway; in the other cases the remainder goes to the per-point state machine (lk_insert_fallback_kernel), for which
+// store_idx(base) must first put the group's indices into map.gidx[base .. base + g) when `off` < 0 (they are not there yet).
+template <typename PointAt, typename StoreIdx>
+__device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr, const int Tn, const int Tp, const int To, const int g,
+                                           const int root, const LeafInfo& li, int off, PointAt point_at, StoreIdx store_idx) {
     const int lane = threadIdx.x & 63;
-    // scan points: only the roots the light pre-pass could not finish; pointWithVar input: every touched root
-    const int n_touched = (int)map.counters[FROM_PV ? LK_CTR_TOUCHED : LK_CTR_HEAVY];
-    const int* worklist = FROM_PV ? map.touched : map.heavy;
+#ifdef LK_DEBUG_INS
+    unsigned long long t0_ = wall_clock64();
+    if (lane == 0) atomicAdd(&lk_ins_dbg[15], 1ull);
+#endif
+    int leaf = Tn;
+    NodeRegs r;
+    r.npts = li.npts, r.new_points = li.new_points, r.block = li.block, r.layer = li.layer, r.state = li.state;
+    bool lplane = li.is_plane != 0;
+    if (leaf < 0) {  // voxel_map.cc:214-222: first point of a new octant creates the child
+        const lk_node_rec* pn = &map.nodes[Tp];
+        double pc[3] = {pn->voxel_center[0], pn->voxel_center[1], pn->voxel_center[2]};
+        const int pl = bcast0(pn->layer);
+        leaf = create_child(map, Tp, To, pc, pn->quater_length, pl);
+#if LK_X_CHILD_CONST
+        r.npts = 0, r.new_points = 0, r.block = -1, r.layer = pl + 1, r.state = LK_NODE_UPDATE_ENABLE;
+#else
+        r = node_load(&map.nodes[leaf]);
+#endif
+        lplane = false;
+    }
+    lk_node_rec* ln = &map.nodes[leaf];
+#ifdef LK_DEBUG_LI
+    if (Tn >= 0) {   // DEBUG BUILD ONLY: the leaf info handed over against the record in memory
+        NodeRegs q = node_load(ln);
+        const int qpl = (bcast0((int)map.planes[leaf].flags) & (int)LK_PLANE_IS_PLANE) != 0;
+        if (lane == 0 && (q.npts != r.npts || q.new_points != r.new_points || q.block != r.block || q.layer != r.layer || q.state != r.state || qpl != (int)lplane)) {
+            const unsigned long long k = atomicAdd(&lk_li_dbg[0], 1ull);
+            if (k < 4) {
+                unsigned long long* o = &lk_li_dbg[1 + 14 * k];
+                o[0] = leaf, o[1] = root, o[2] = (unsigned)r.npts, o[3] = (unsigned)q.npts, o[4] = (unsigned)r.new_points, o[5] = (unsigned)q.new_points, o[6] = (unsigned)r.block, o[7] = (unsigned)q.block;
+                o[8] = r.layer, o[9] = q.layer, o[10] = r.state, o[11] = q.state, o[12] = lplane, o[13] = off;
+            }
+        }
+    }
+#endif
+    const int L = r.layer;
+    const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
+    const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
+    const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
+    INS_STAMP(0);
+    if (!uninit && !live && (lplane || maxnp)) return;  // frozen leaf ignores its points
+    int consumed = 0;
+    bool need_init = false;
+    if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts < LK_WAVE) {
+        const int n0 = r.npts;
+        const int gs = min(g, LK_WAVE - n0);
+        double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
+        if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
+        {
+            const int rr = lane - n0;
+            const bool valid = rr >= 0 && rr < gs;
+            PtU pt;
+            point_at(valid ? rr : 0, valid, pt);
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ppw[c] = pt.pw[c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
+            }
+        }
+        INS_STAMP(1);
+        const int thr = pr.layer_init_num[L];
+        int cur = n0, newp = r.new_points;
+        int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
+        bool frozen = false, general_init = false, stop = false, fitted = false, flipped_to_tree = false;
+        PlaneFit fit;
+        fit.is_plane = lplane;
+        int fit_count = 0;
+        while (consumed < gs && !stop) {
+            const int rem = gs - consumed;
+            if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
+                const int k = max(min(rem, thr + 1 - cur), 1);
+                cur += k, newp += k, consumed += k;
+                if (cur > thr) {
+                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                    fit_count = cur, fitted = true, newp = 0;
+                    if (fit.is_plane) {
+                        mode = 1;
+                        if (cur > pr.max_points_num) frozen = true, stop = true;
+                    } else if (L >= pr.max_layer) {
+                        mode = 2;  // cut_octo_tree returns at once at max_layer (:140-143)
+                    } else {
+                        general_init = true, stop = true;  // the generic code cuts the voxel
+                    }
+                }
+            } else if (mode == 1) {  // voxel_map.cc:191-204
+                const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
+                cur += k, newp += k, consumed += k;
+                if (newp > 5) {
+                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                    fit_count = cur, fitted = true, newp = 0;
+                    if (!fit.is_plane) {
+                        if (L < pr.max_layer) flipped_to_tree = true, stop = true;
+                        else mode = 2;
+                    }
+                }
+                if (cur >= pr.max_points_num) frozen = true, stop = true;
+            } else {  // voxel_map.cc:224-237
+                const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
+                cur += k, newp += k, consumed += k;
+                if (newp > 5) {
+                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                    fit_count = cur, fitted = true, newp = 0;
+                    if (fit.is_plane) mode = 1;
+                }
+                if (cur > pr.max_points_num) frozen = true, stop = true;
+            }
+        }
+        INS_STAMP(2);
+        // ---- commit points, counters, one full fit
+        if (cur > n0 && r.block < 0) r.block = alloc_block(map);
+        if (lane >= n0 && lane < cur) {
+            lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dst->var[c] = pvar[c];
+        }
+        r.npts = cur;
+        if (general_init) {
+            r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
+            node_store(ln, r, false);
+            need_init = true;    // the generic code cuts the voxel: lk_insert_fallback_kernel
+        } else {
+            r.new_points = newp;
+            if (fitted) {
+                // the one full fit of this leaf in this bucket: the state of its LAST refit event
+                const bool decided = fit.is_plane;
+                double s9[9];   // the last event tested exactly these fit_count points
+#pragma unroll
+                for (int q = 0; q < 9; ++q) s9[q] = fit.s9[q];
+                INS_STAMP(3);
+                fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold, s9);
+                INS_STAMP(4);
+                fit.is_plane = decided;  // control flow above already followed the event's decision
+                double acc21[21];
+                if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
+                INS_STAMP(5);
+                plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
+                INS_STAMP(6);
+#ifdef LK_DEBUG_INS
+                if (lane == 0) atomicAdd(&lk_ins_dbg[14], 1ull);
+#endif
+                r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
+                if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
+            }
+            if (frozen) node_freeze(map, r);
+            node_store(ln, r, false);
+            if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
+        }
+    }
+#ifdef LK_DEBUG_LI
+    if (lane == 0 && map.nodes[root].key[0] == 11 && map.nodes[root].key[1] == 10 && map.nodes[root].key[2] == 5) {
+        const unsigned long long k = atomicAdd(&lk_li_dbg[60], 1ull);
+        if (k < 4) {
+            unsigned long long* o = &lk_li_dbg[1 + 14 * k];
+            o[0] = leaf, o[1] = root, o[2] = (unsigned)Tn, o[3] = (unsigned)Tp, o[4] = (unsigned)To, o[5] = (unsigned)g, o[6] = (unsigned)r.npts, o[7] = (unsigned)r.block;
+            o[8] = r.layer, o[9] = r.new_points, o[10] = r.state, o[11] = consumed, o[12] = need_init, o[13] = off;
+        }
+    }
+#endif
+    INS_STAMP(7);
+    // ---------------- a cut and / or whatever is left of the group: the generic state machine, in its own kernel
+    if (need_init || consumed < g) {
+        if (off < 0) {
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&map.counters[LK_CTR_GIDX], (unsigned int)g);
+            base = bcast0(base);
+            if (base + g > (int)map.max_scan) {
+                if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+                return;
+            }
+            store_idx(base);
+            off = base;
+        }
+        insert_defer(map, leaf, need_init ? 1 : 0, off + consumed, g - consumed, 2, root, L);
+    }
+}
+
+// One wave per touched root (see the comment block above).
+template <bool FROM_PV>
+__device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                                                const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
     LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
     BucketConst bc;
-    if (!FROM_PV) load_bucket_const<false>(&filters[0], pr, bc);
+    if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
     for (int t = wave; t < n_touched; t += nwaves) {
-        const int root = bcast0(worklist[t]);
+        const int root = bcast0(map.touched[t]);
         lk_node_rec* nd = &map.nodes[root];
+        // one batch of loads: the root's record, its plane flags, its slot line
         const int m = bcast0((int)nd->pad_[0]);
+        const unsigned int rst = (unsigned int)bcast0((int)nd->state), rpf = (unsigned int)bcast0((int)map.planes[root].flags);
+        const int rnpts = bcast0(nd->npts), rnewp = bcast0(nd->new_points), rblock = bcast0(nd->block), rlayer = bcast0(nd->layer);
+        int cur_list = bcast0(nd->list_head);
+        const int slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
+        if (lane == 0) nd->pad_[0] = 0, nd->list_head = -1;   // the root's bucket-local queue is consumed
+        // ---- light root: append only (one lane per point, input order = ascending index)
+        bool light = false;
+        if (!FROM_PV && m <= 8) {
+            if (!(rst & LK_NODE_INIT_OCTO))
+                light = (rnpts + m <= pr.layer_init_num[0]) && (rnpts + m <= LK_BLOCK_PTS);
+            else if ((rpf & LK_PLANE_IS_PLANE) && (rst & LK_NODE_UPDATE_ENABLE))
+                light = (rnewp + m <= 5) && (rnpts + m < pr.max_points_num);
+        }
+        if (light) {
+            const int idx = (lane < m) ? slot_idx : 0x7fffffff;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += (j < m && __builtin_amdgcn_readlane(idx, j) < idx) ? 1 : 0;
+            int block = rblock;
+            if (block < 0) block = alloc_block(map);
+            if (lane < m) {
+                const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+                const PointGeom gm = point_geom(p.x, p.y, p.z, bc, pr);
+                lk_pt_rec* dst = &map.blocks[block].pts[rnpts + rank];
+                dst->pw[0] = gm.p_w.x, dst->pw[1] = gm.p_w.y, dst->pw[2] = gm.p_w.z;
+                dst->var[0] = gm.var.xx, dst->var[1] = gm.var.xy, dst->var[2] = gm.var.xz;
+                dst->var[3] = gm.var.yy, dst->var[4] = gm.var.yz, dst->var[5] = gm.var.zz;
+            }
+            if (lane == 0) nd->npts = rnpts + m, nd->new_points = rnewp + m, nd->block = block;
+            continue;
+        }
+        if (lane == 0) map.dirty[root] = map.epoch;   // pipelined stream path: a plane of this root's subtree may change in this bucket (LkMap::dirty)
+        // ---- the root's indices
         int base = 0;
         const bool in_slots = m <= LK_SLOTS;  // the common case: every queued index sits in the root's slot line
-        if (in_slots) {
-            if (lane == 0) nd->pad_[0] = 0;
-        } else {
-            int cur = bcast0(nd->list_head);
-            if (lane == 0) {
-                nd->list_head = -1;
-                nd->pad_[0] = 0;
-                base = (int)atomicAdd(&map.counters[LK_CTR_SCRATCH], (unsigned int)m);
-            }
+        if (!in_slots) {
+            if (lane == 0) base = (int)atomicAdd(&map.counters[LK_CTR_SCRATCH], (unsigned int)m);
             base = bcast0(base);
             if (base + m > (int)map.max_scan) {
                 if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
                 continue;
             }
-            // unordered indices -> scratch: the slot line with one coalesced read, the overflow by walking the list
-            if (lane < LK_SLOTS) map.scratch[base + lane] = map.slots[(size_t)root * LK_SLOTS + lane];
-            for (int k = LK_SLOTS; k < m && cur >= 0; ++k) {
-                if (lane == 0) map.scratch[base + k] = cur;
-                cur = bcast0(map.next[cur]);
+            // unordered indices -> scratch: the slot line with one coalesced store, the overflow by walking the list
+            if (lane < LK_SLOTS) map.scratch[base + lane] = slot_idx;
+            for (int k = LK_SLOTS; k < m && cur_list >= 0; ++k) {
+                if (lane == 0) map.scratch[base + k] = cur_list;
+                cur_list = bcast0(map.next[cur_list]);
             }
             wave_fence();
         }
         if (m > LK_WAVE) {  // very long list: handed over whole
-            if (lane == 0) {
-                const unsigned int g = atomicAdd(&map.counters[LK_CTR_GROUPS], 1u);
-                if (g < map.max_scan) groups[g] = LkGroup{root, -1, 0, base, m, 1, root, 0};
-                else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
-            }
+            insert_defer(map, root, 0, base, m, 1, root, 0);
             continue;
         }
         // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
-        const int myidx = (lane < m) ? (in_slots ? map.slots[(size_t)root * LK_SLOTS + lane] : map.scratch[base + lane]) : 0x7fffffff;
+        const int myidx = (lane < m) ? (in_slots ? slot_idx : map.scratch[base + lane]) : 0x7fffffff;
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
         const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
         const bool mine = lane < m;
-        // every lane walks (read-only) to the node its point would be pushed into: down through initialised
-        // non-planar nodes below max_layer (voxel_map.cc:205-223); these never change again, so the walk is exact
-        // for the whole bucket.  tnode < 0: child `toct` of `tparent` does not exist.
+        // every lane walks (read-only) to the node its point would be pushed into: down through initialised non-planar nodes
+        // below max_layer (voxel_map.cc:205-223); these never change again, so the walk is exact for the whole bucket.
+        // tnode < 0: child `toct` of `tparent` does not exist.  The target's counters come along (its record is being read anyway).
         int tnode = -1, tparent = -1, toct = 0;
+        int t_npts = 0, t_newp = 0, t_block = -1, t_layer = 0, t_plane = 0;
+        unsigned int t_state = 0;
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mine) {
             double pw[3];
-            insert_point_pw<FROM_PV>(pr, bc, pts, pv, sidx, pw);
+            insert_point_pw<FROM_PV>(pr, bc, pts, pv, sidx, pw, p4);
             int node = root;
+            unsigned int st = rst, pf = rpf;
+            int npts = rnpts, newp = rnewp, block = rblock, layer = rlayer;
             for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
-                const lk_node_rec* nr = &map.nodes[node];
-                const unsigned int st = nr->state;
-                const bool pl = (map.planes[node].flags & LK_PLANE_IS_PLANE) != 0;
-                if (!(st & LK_NODE_INIT_OCTO) || pl || nr->layer >= pr.max_layer) {
+                const bool pl = (pf & LK_PLANE_IS_PLANE) != 0;
+                if (!(st & LK_NODE_INIT_OCTO) || pl || layer >= pr.max_layer) {
                     tnode = node;
+                    t_npts = npts, t_newp = newp, t_block = block, t_layer = layer, t_state = st, t_plane = pl ? 1 : 0;
                     break;
                 }
+                const lk_node_rec* nr = &map.nodes[node];
                 const int oct = octant_of(pw, nr->voxel_center);
                 const int child = nr->child[oct];
                 if (child < 0) {
@@ -747,11 +1007,18 @@ __device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParam
                     break;
                 }
                 node = child;
-                tnode = node;
+                const lk_node_rec* cr = &map.nodes[child];
+                st = cr->state, npts = cr->npts, newp = cr->new_points, block = cr->block, layer = cr->layer;
+                pf = map.planes[child].flags;
+                if (depth == LK_MAX_LAYER) {   // cannot happen (layer <= max_layer <= LK_MAX_LAYER stops the walk above); kept total
+                    tnode = node;
+                    t_npts = npts, t_newp = newp, t_block = block, t_layer = layer, t_state = st, t_plane = (pf & LK_PLANE_IS_PLANE) ? 1 : 0;
+                }
             }
         }
-        // one descriptor per distinct target; the group's indices in lane (= input) order
+        // one group per distinct target
         int ngroups = 0;
+        unsigned long long first_grp = 0ull;
         {
             unsigned long long todo = __ballot(mine);
             while (todo) {
@@ -759,10 +1026,37 @@ __device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParam
                 const int Tn = __builtin_amdgcn_readlane(tnode, leader), Tp = __builtin_amdgcn_readlane(tparent, leader),
                           To = __builtin_amdgcn_readlane(toct, leader);
                 const unsigned long long grp = __ballot(mine && tnode == Tn && tparent == Tp && toct == To) & todo;
+                if (ngroups == 0) first_grp = grp;
                 todo &= ~grp;
                 ++ngroups;
             }
         }
+#ifndef LK_X_NOINLINE
+#define LK_X_NOINLINE 0   // debug / A-B only: 1 = every root hands its groups to lk_insert_apply_kernel
+#endif
+        if (ngroups == 1 && !LK_X_NOINLINE) {
+            // ---- the whole root is one leaf group: applied here, from registers (lane j holds the j-th point)
+            LeafInfo li;
+            li.npts = __builtin_amdgcn_readlane(t_npts, 0), li.new_points = __builtin_amdgcn_readlane(t_newp, 0);
+            li.block = __builtin_amdgcn_readlane(t_block, 0), li.layer = __builtin_amdgcn_readlane(t_layer, 0);
+            li.state = (unsigned int)__builtin_amdgcn_readlane((int)t_state, 0), li.is_plane = __builtin_amdgcn_readlane(t_plane, 0);
+            const int Tn = __builtin_amdgcn_readlane(tnode, 0), Tp = __builtin_amdgcn_readlane(tparent, 0), To = __builtin_amdgcn_readlane(toct, 0);
+            auto point_at = [&](int rr, bool valid, PtU& pt) {
+                if (FROM_PV) {
+                    const int idx = __shfl(sidx, rr, LK_WAVE);
+                    if (valid) load_pt(pv, nullptr, idx, pt.pw, pt.var);
+                } else {
+                    const float qx = __shfl(p4.x, rr, LK_WAVE), qy = __shfl(p4.y, rr, LK_WAVE), qz = __shfl(p4.z, rr, LK_WAVE);
+                    if (valid) geom_to_pt(point_geom(qx, qy, qz, bc, pr), pt);
+                }
+            };
+            auto store_idx = [&](int gbase) {
+                if (lane < m) map.gidx[gbase + lane] = sidx;
+            };
+            apply_leaf(map, pr, Tn, Tp, To, m, root, li, -1, point_at, store_idx);
+            continue;
+        }
+        // ---- several groups: one descriptor per group, the group's indices in lane (= input) order
         int gbase = 0, ibase = 0;
         if (lane == 0) {
             gbase = (int)atomicAdd(&map.counters[LK_CTR_GROUPS], (unsigned int)ngroups);
@@ -784,7 +1078,13 @@ __device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParam
                 todo &= ~grp;
                 const int g = __popcll(grp);
                 if ((grp >> lane) & 1ull) map.gidx[off + __popcll(grp & ((1ull << lane) - 1ull))] = sidx;
-                if (lane == 0) groups[gbase + gi] = LkGroup{Tn, Tp, To, off, g, 0, root, 0};
+                LkGroup d;
+                d.leaf = Tn, d.parent = Tp, d.oct = To, d.off = off, d.count = g, d.kind = 0, d.root = root, d.pad = 0;
+                d.npts = __builtin_amdgcn_readlane(t_npts, leader), d.new_points = __builtin_amdgcn_readlane(t_newp, leader);
+                d.block = __builtin_amdgcn_readlane(t_block, leader), d.layer = __builtin_amdgcn_readlane(t_layer, leader);
+                d.state = (unsigned int)__builtin_amdgcn_readlane((int)t_state, leader), d.is_plane = __builtin_amdgcn_readlane(t_plane, leader);
+                d.pad2[0] = d.pad2[1] = 0;
+                if (lane == 0) groups[gbase + gi] = d;
                 off += g;
                 ++gi;
             }
@@ -792,184 +1092,36 @@ __device__ __forceinline__ void dev_insert_group(const LkMap& map, const LkParam
     }
 }
 
+// One wave per emitted group (roots with several leaf groups).
 template <bool FROM_PV>
 __device__ __forceinline__ void dev_insert_apply(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                            const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
     const int lane = threadIdx.x & 63;
     const int n_groups = (int)min(map.counters[LK_CTR_GROUPS], map.max_scan);
+    if (n_groups == 0) return;
     const LkGroup* groups = reinterpret_cast<const LkGroup*>(map.groups);
     BucketConst bc;
     if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
-    auto point_of = [&](int idx, PtU& pt) {
-        if (FROM_PV) {
-            load_pt(pv, nullptr, idx, pt.pw, pt.var);
-        } else {
-            const float4 p = reinterpret_cast<const float4*>(pts)[idx];
-            PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
-            pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
-            pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
-            pt.var[3] = g.var.yy, pt.var[4] = g.var.yz, pt.var[5] = g.var.zz;
-        }
-    };
-    // groups that need the generic per-point code are queued behind the descriptors of this pass (kind 1: whole long
-    // list; kind 2: leaf `leaf`, optional init_octo_tree (oct != 0, layer in pad), then gidx[off .. off+count) one by one)
-    auto defer = [&](const LkGroup& d) {
-        if (lane == 0) {
-            const unsigned int q = atomicAdd(&map.counters[LK_CTR_FALLBACK], 1u);
-            if (q < map.max_scan) reinterpret_cast<LkGroup*>(map.groups)[map.max_scan + q] = d;
-            else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
-        }
-    };
     for (int t = wave; t < n_groups; t += nwaves) {
-#ifdef LK_DEBUG_INS
-        unsigned long long t0_ = wall_clock64();
-        if (lane == 0) atomicAdd(&lk_ins_dbg[15], 1ull);
-#endif
-        const int4 d0 = reinterpret_cast<const int4*>(&groups[t])[0], d1 = reinterpret_cast<const int4*>(&groups[t])[1];
-        const int Tn = bcast0(d0.x), Tp = bcast0(d0.y), To = bcast0(d0.z), off = bcast0(d0.w), g = bcast0(d1.x),
-                  kind = bcast0(d1.y), root = bcast0(d1.z);
-        if (kind == 1) {  // very long list: the per-point replay of lk_insert_fallback_kernel
-            defer(LkGroup{root, -1, 0, off, g, 1, root, 0});
-            continue;
-        }
-        int leaf = Tn;
-        if (leaf < 0) {  // voxel_map.cc:214-222: first point of a new octant creates the child
-            const lk_node_rec* pn = &map.nodes[Tp];
-            double pc[3] = {pn->voxel_center[0], pn->voxel_center[1], pn->voxel_center[2]};
-            leaf = create_child(map, Tp, To, pc, pn->quater_length, bcast0(pn->layer));
-        }
-        // ---------------- one leaf, its points = gidx[off .. off+g) in input order
-        lk_node_rec* ln = &map.nodes[leaf];
-        NodeRegs r = node_load(ln);
-        const bool lplane = (bcast0((int)map.planes[leaf].flags) & (int)LK_PLANE_IS_PLANE) != 0;
-        const int L = r.layer;
-        const bool uninit = !(r.state & LK_NODE_INIT_OCTO);
-        const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
-        const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
-        INS_STAMP(0);   // descriptor + node record
-        if (!uninit && !live && (lplane || maxnp)) continue;  // frozen leaf ignores its points
-        int consumed = 0;
-        bool need_init = false;
-        if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts < LK_WAVE) {
-            // lane Ln holds node point Ln: existing points from the block, then the group's points in order.  Only the
-            // first gs points fit in the wave; that is always enough to reach the freeze of a leaf (npts <=
-            // max_points_num + 1 <= 64), after which the rest of the group is ignored anyway; in the other cases the
-            // remainder goes through the per-point state machine below.
-            const int n0 = r.npts;
-            const int gs = min(g, LK_WAVE - n0);
-            double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
-            if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
-            {
-                const int rr = lane - n0;
-                if (rr >= 0 && rr < gs) {
-                    PtU pt;
-                    point_of(map.gidx[off + rr], pt);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) ppw[c] = pt.pw[c];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) pvar[c] = pt.var[c];
+        const int4* dq = reinterpret_cast<const int4*>(&groups[t]);
+        const int4 d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+        const int Tn = bcast0(d0.x), Tp = bcast0(d0.y), To = bcast0(d0.z), off = bcast0(d0.w), g = bcast0(d1.x), root = bcast0(d1.z);
+        LeafInfo li;
+        li.npts = bcast0(d2.x), li.new_points = bcast0(d2.y), li.block = bcast0(d2.z), li.layer = bcast0(d2.w);
+        li.state = (unsigned int)bcast0(d3.x), li.is_plane = bcast0(d3.y);
+        auto point_at = [&](int rr, bool valid, PtU& pt) {
+            if (valid) {
+                const int idx = map.gidx[off + rr];
+                if (FROM_PV) {
+                    load_pt(pv, nullptr, idx, pt.pw, pt.var);
+                } else {
+                    const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+                    geom_to_pt(point_geom(p.x, p.y, p.z, bc, pr), pt);
                 }
             }
-            INS_STAMP(1);   // block points + the group's points derived
-            const int thr = pr.layer_init_num[L];
-            int cur = n0, newp = r.new_points;
-            int mode = uninit ? 0 : (lplane ? 1 : 2);  // 0 un-initialised, 1 plane, 2 non-planar max-layer leaf
-            bool frozen = false, general_init = false, stop = false, fitted = false, flipped_to_tree = false;
-            PlaneFit fit;
-            fit.is_plane = lplane;
-            int fit_count = 0;
-            while (consumed < gs && !stop) {
-                const int rem = gs - consumed;
-                if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
-                    const int k = max(min(rem, thr + 1 - cur), 1);
-                    cur += k, newp += k, consumed += k;
-                    if (cur > thr) {
-                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                        fit_count = cur, fitted = true, newp = 0;
-                        if (fit.is_plane) {
-                            mode = 1;
-                            if (cur > pr.max_points_num) frozen = true, stop = true;
-                        } else if (L >= pr.max_layer) {
-                            mode = 2;  // cut_octo_tree returns at once at max_layer (:140-143)
-                        } else {
-                            general_init = true, stop = true;  // the generic code cuts the voxel
-                        }
-                    }
-                } else if (mode == 1) {  // voxel_map.cc:191-204
-                    const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
-                    cur += k, newp += k, consumed += k;
-                    if (newp > 5) {
-                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                        fit_count = cur, fitted = true, newp = 0;
-                        if (!fit.is_plane) {
-                            if (L < pr.max_layer) flipped_to_tree = true, stop = true;
-                            else mode = 2;
-                        }
-                    }
-                    if (cur >= pr.max_points_num) frozen = true, stop = true;
-                } else {  // voxel_map.cc:224-237
-                    const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
-                    cur += k, newp += k, consumed += k;
-                    if (newp > 5) {
-                        fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                        fit_count = cur, fitted = true, newp = 0;
-                        if (fit.is_plane) mode = 1;
-                    }
-                    if (cur > pr.max_points_num) frozen = true, stop = true;
-                }
-            }
-            INS_STAMP(2);   // event simulation
-            // ---- commit points, counters, one full fit
-            if (cur > n0 && r.block < 0) r.block = alloc_block(map);
-            if (lane >= n0 && lane < cur) {
-                lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) dst->var[c] = pvar[c];
-            }
-            r.npts = cur;
-            if (general_init) {
-                r.new_points = cur;  // as counted by the pushes; init_octo_tree resets it
-                node_store(ln, r, false);
-                need_init = true;    // the generic code cuts the voxel: lk_insert_fallback_kernel
-            } else {
-                r.new_points = newp;
-                if (fitted) {
-                    // the one full fit of this leaf in this bucket: the state of its LAST refit event
-                    const bool decided = fit.is_plane;
-                    double s9[9];   // the last event tested exactly these fit_count points
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) s9[q] = fit.s9[q];
-                    INS_STAMP(3);   // point stores
-                    fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold, s9);
-                    INS_STAMP(4);   // eigen-decomposition
-                    fit.is_plane = decided;  // control flow above already followed the event's decision
-                    double acc21[21];
-#ifdef LK_DEBUG_INS
-                    const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
-#endif
-                    if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
-#ifdef LK_DEBUG_INS
-                    if (lane == 0) atomicAdd(&lk_ins_dbg[12], clock64() - c0_), atomicAdd(&lk_ins_dbg[13], wall_clock64() - w0_);
-#endif
-                    INS_STAMP(5);   // plane_var
-                    plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
-                    INS_STAMP(6);   // commit
-#ifdef LK_DEBUG_INS
-                    if (lane == 0) atomicAdd(&lk_ins_dbg[14], 1ull);
-#endif
-                    r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
-                    if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
-                }
-                if (frozen) node_freeze(map, r);
-                node_store(ln, r, false);
-                if (frozen && !flipped_to_tree) consumed = g;  // a frozen leaf ignores the rest of its points
-            }
-        }
-        INS_STAMP(7);   // node store, tail
-        // ---------------- a cut and / or whatever is left of the group: the generic state machine, in its own kernel
-        if (need_init || consumed < g) defer(LkGroup{leaf, -1, need_init ? 1 : 0, off + consumed, g - consumed, 2, root, L});
+        };
+        auto store_idx = [&](int) {};
+        apply_leaf(map, pr, Tn, Tp, To, g, root, li, off, point_at, store_idx);
     }
 }
 
@@ -1040,9 +1192,9 @@ __device__ __forceinline__ void dev_insert_fallback(const LkMap& map, const LkPa
 
 template <bool FROM_PV>
 __global__ void __launch_bounds__(LK_MB)
-    lk_insert_group_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                           const lk_pt_rec* __restrict__ pv, int n) {
-    dev_insert_group<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+    lk_insert_root_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
+                          const lk_pt_rec* __restrict__ pv, int n) {
+    dev_insert_root<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
 template <bool FROM_PV>
 __global__ void __launch_bounds__(LK_MB)
@@ -1068,83 +1220,6 @@ __global__ void __launch_bounds__(LK_MB)
             }
         }
     }
-}
-
-// Light pre-pass of the insert: ONE THREAD per touched root.  Most touched roots only need their few new points
-// appended — an un-initialised root that stays at <= layer_init_num points, or a plane root that reaches neither
-// its 6th new point (refit, voxel_map.cc:195) nor max_points_num (freeze, :199).  Those are finished here, in input
-// order (8-input sorting network on the list indices); every other root is queued for the group / apply passes.
-__device__ __forceinline__ void cswap(int& a, int& b) {
-    int lo = a < b ? a : b, hi = a < b ? b : a;
-    a = lo, b = hi;
-}
-__device__ __forceinline__ void dev_insert_light_root(const LkMap& map, const LkParams& pr, const LkFilter* __restrict__ filters,
-                                                      const lk_point* __restrict__ pts, const int t) {
-    const int root = map.touched[t];
-    lk_node_rec* nd = &map.nodes[root];
-    const int m = (int)nd->pad_[0];
-    const unsigned int st = nd->state, pf = map.planes[root].flags;
-    int npts = nd->npts;
-    const int newp = nd->new_points;
-    bool light = false;
-    if (m <= 8) {
-        if (!(st & LK_NODE_INIT_OCTO))
-            light = (npts + m <= pr.layer_init_num[0]) && (npts + m <= LK_BLOCK_PTS);
-        else if ((pf & LK_PLANE_IS_PLANE) && (st & LK_NODE_UPDATE_ENABLE))
-            light = (newp + m <= 5) && (npts + m < pr.max_points_num);
-    }
-    if (!light) {
-        unsigned int hpos = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
-        map.heavy[hpos] = root;
-        map.dirty[root] = map.epoch;   // pipelined stream path: a plane of this root's subtree may change in this bucket (LkMap::dirty)
-        return;
-    }
-    int i0, i1, i2, i3, i4, i5, i6, i7;
-    {
-        const int BIG = 0x7fffffff;
-        const int* sl = &map.slots[(size_t)root * LK_SLOTS];  // m <= 8 < LK_SLOTS: everything is in the slot line
-        i0 = (m > 0) ? sl[0] : BIG;
-        i1 = (m > 1) ? sl[1] : BIG;
-        i2 = (m > 2) ? sl[2] : BIG;
-        i3 = (m > 3) ? sl[3] : BIG;
-        i4 = (m > 4) ? sl[4] : BIG;
-        i5 = (m > 5) ? sl[5] : BIG;
-        i6 = (m > 6) ? sl[6] : BIG;
-        i7 = (m > 7) ? sl[7] : BIG;
-    }
-    // Batcher odd-even merge sort, 8 inputs (19 compare-exchanges): input order = ascending bucket index
-    cswap(i0, i1); cswap(i2, i3); cswap(i4, i5); cswap(i6, i7);
-    cswap(i0, i2); cswap(i1, i3); cswap(i4, i6); cswap(i5, i7);
-    cswap(i1, i2); cswap(i5, i6);
-    cswap(i0, i4); cswap(i1, i5); cswap(i2, i6); cswap(i3, i7);
-    cswap(i2, i4); cswap(i3, i5);
-    cswap(i1, i2); cswap(i3, i4); cswap(i5, i6);
-    nd->list_head = -1;
-    nd->pad_[0] = 0;
-    int block = nd->block;
-    if (block < 0) block = pop_or_bump_block(map);
-    BucketConst bc;
-    load_bucket_const(&filters[0], pr, bc);
-#pragma unroll 1
-    for (int k = 0; k < m; ++k) {
-        const int idx = (k == 0) ? i0 : (k == 1) ? i1 : (k == 2) ? i2 : (k == 3) ? i3 : (k == 4) ? i4 : (k == 5) ? i5 : (k == 6) ? i6 : i7;
-        const float4 p = reinterpret_cast<const float4*>(pts)[idx];
-        const PointGeom g = point_geom(p.x, p.y, p.z, bc, pr);
-        lk_pt_rec* dst = &map.blocks[block].pts[npts];
-        dst->pw[0] = g.p_w.x, dst->pw[1] = g.p_w.y, dst->pw[2] = g.p_w.z;
-        dst->var[0] = g.var.xx, dst->var[1] = g.var.xy, dst->var[2] = g.var.xz;
-        dst->var[3] = g.var.yy, dst->var[4] = g.var.yz, dst->var[5] = g.var.zz;
-        ++npts;
-    }
-    nd->npts = npts;
-    nd->new_points = newp + m;
-    nd->block = block;
-}
-__global__ void __launch_bounds__(256)
-    lk_insert_light_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int)map.counters[LK_CTR_TOUCHED]) return;
-    dev_insert_light_root(map, pr, filters, pts, t);
 }
 
 // hashing half of UpdateVoxelMap for caller-supplied pointWithVar records
