@@ -353,8 +353,8 @@ int lk_device_free(lk_handle* h, void* d_ptr);
 int lk_memcpy_h2d(lk_handle* h, void* d_dst, const void* src, size_t bytes);
 int lk_memcpy_d2h(lk_handle* h, void* dst, const void* d_src, size_t bytes);
 int lk_synchronize(lk_handle* h);
-/* Pipelined stream path ("insert off the critical chain"): with the pipeline on (default; LEGKILO_SPEC=0 or
- * on = 0 selects the sequential order on one stream) the map insert of bucket k (KILO.cc:216-233) runs on a second HIP stream beside
+/* Pipelined stream path ("insert off the critical chain"): with the pipeline on (on = 1 or LEGKILO_SPEC=1; the
+ * default is the sequential order on one stream, which measures faster) the map insert of bucket k (KILO.cc:216-233) runs on a second HIP stream beside
  * the predict + residual pass of bucket k+1, and a verify pass re-evaluates the tiles whose points looked at a root voxel the
  * insert stamped.  Results are those of the sequential order.  lk_stream_stats: out4 = { buckets that went through the
  * pipeline, their residual tiles, tiles the verify pass evaluated again, 0 } since lk_create. */

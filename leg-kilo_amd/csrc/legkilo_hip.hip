@@ -66,7 +66,7 @@ struct lk_handle {
     unsigned int epoch = 16;      // bucket sequence number: stamps of LkMap::dirty / newroot, value of spec[LK_SPEC_DONE]
     unsigned int spec_base = 16;  // first epoch of the open window (stamps below it belong to inserts that were joined)
     bool spec_open = false;       // inserts may still be running on `ins`
-    bool spec_enable = true;      // LEGKILO_SPEC=0: the sequential order on one stream (A/B)
+    bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
     int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
     uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0;
@@ -506,6 +506,24 @@ int lk_update_by_kin_imu(lk_handle* h, uint32_t slot, const double* ki_h, const 
     return LK_OK;
 }
 
+// lk_update_kernel of the stream path (slot 0), followed in the same single-workgroup launch by the posterior's snapshot for the
+// insert (dev_snapshot_posterior), the insert's pool bookkeeping (do_predict >= 0; the pipelined path does it on its insert stream)
+// and - do_predict == 1 - the predict to the next bucket's time.
+__global__ void __launch_bounds__(LK_FB)
+    lk_update_snap_kernel(LkMap map, LkFilter* filters, const double* __restrict__ partials, int nblk, double t, const double* __restrict__ Q,
+                          double t_next, int do_predict, LkFilter* snap) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[8][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    dev_update_reduce(&filters[0], partials, nblk, t, Q, 0.0, 0, sm, red, tot);
+    dev_snapshot_posterior(&filters[0], snap);
+    if (do_predict >= 0) dev_bucket_begin(map);
+    if (do_predict == 1) {
+        __syncthreads();  // f->x, f->P, f->last_update_t written by the update are re-read by dev_predict
+        dev_predict(&filters[0], Q, t_next, sm);
+    }
+}
+
 // lk_bucket_begin_kernel + lk_predict_kernel in one launch (on a single dependent stream every kernel boundary costs
 // ~8-10 us; the two pieces touch disjoint data)
 static_assert(LK_FB == 256, "dev_bucket_begin strides by 256 threads");
@@ -809,7 +827,7 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
         const auto ver_kernel = xid ? lk_verify_kernel<true> : lk_verify_kernel<false>;
         hipLaunchKernelGGL(ver_kernel, dim3(nblk_r), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, n, h->d_partials, ro, from, e - 1);
     }
-    hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_partials, nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, snap);
+    hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials, nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, 0.0, -1, snap);
     HIPCHK(h, hipEventRecord(h->ev_U[e & 1u], h->stream));
     // insert stream: the bucket's insert, from the snapshot of its posterior
     HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_U[e & 1u], 0));
@@ -829,12 +847,18 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
 
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
-static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert) {
+// t_next: time of the NEXT bucket if the caller knows that it follows directly (no IMU / kinematic message in between) and is itself
+// a large bucket - its predict then runs in this bucket's launch (`*pre_predicted` tells the next call) -, NaN otherwise.
+static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert, double t_next = NAN,
+                          bool* pre_predicted = nullptr) {
     const LkMap& m = h->map;
+    const bool was_pre = pre_predicted && *pre_predicted;   // filters[0] already stands at this bucket's time
+    if (pre_predicted) *pre_predicted = false;
     if (do_insert) h->grid_valid = false;   // the map changes: batch replay rebuilds its root grid
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
-    if (do_insert && h->spec_enable && !h->profiling && n > LK_SMALL_MAX) {
+    const LkFilter* ins_filters = h->d_filters;   // what the insert reads the posterior from (large buckets: its snapshot)
+    if (do_insert && h->spec_enable && !h->profiling && n > LK_SMALL_MAX && !was_pre) {
         static const bool xid_en = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
         return enqueue_bucket_spec(h, d_pts, n, t, d_world, h->pr.ext_identity && xid_en);
     }
@@ -859,32 +883,37 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         LAUNCH(h, "small_bucket", hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->pr, h->d_filters,
                                                      h->d_Q, t, d_pts, n, d_world, fuse && (d_world || do_insert) ? (do_insert ? 2 : 1) : 0));
     } else {
-        // one single-workgroup launch: the bucket's pool bookkeeping (independent of the filter) + the predict
-        LAUNCH(h, "predict", hipLaunchKernelGGL(lk_begin_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_Q, t));
+        // residual pass, then ONE single-workgroup launch for everything else on the filter side: the fixed-order sum of the tiles'
+        // partial records + the update, the posterior's snapshot for the insert, the insert's pool bookkeeping and - t_next known -
+        // the next bucket's predict.  (The same work in the LAST wave of the residual launch - a ticket per wave, the one-wave
+        // filter cores - measured slower: 38-57 us for the launch against 16 + 12, profiles/r03e_timeline_fused_last_wave_update_rejected.txt.)
+        if (!was_pre) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
         ResidualOut ro;
         memset(&ro, 0, sizeof(ro));
         ro.world = d_world;
+        const bool fuse_next = pre_predicted != nullptr && t_next == t_next;
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
-        LAUNCH(h, "residual",
-               hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters,
-                                  d_pts, (size_t)0, n, h->d_partials, h->part_stride, ro, (size_t)0));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters,
-                                               h->d_partials, nblk_r * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 0));
+        LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
+                                                 h->d_partials, h->part_stride, ro, (size_t)0));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
+                                               nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, fuse_next ? t_next : 0.0, fuse_next ? 1 : 0, h->d_snap));
+        if (fuse_next) *pre_predicted = true;
+        ins_filters = h->d_snap;
     }
     if ((d_world || do_insert) && !fuse)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
-                                                  h->d_filters, d_pts, n, d_world, do_insert ? 1 : 0));
+                                                  ins_filters, d_pts, n, d_world, do_insert ? 1 : 0));
     if (do_insert) {
         // one wave per touched root (append / group / apply of single-group roots), then one wave per emitted leaf group (2 resident
         // waves per SIMD at ~200 VGPRs: 512 blocks x 4 waves is one resident round on 256 CUs), then the generic fallback for the few
         // groups that need it; all loops are grid-stride and read their work counts on the device
         int grid = std::min(std::max((n + 3) / 4, 1), 512);
         LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                    h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+                                                    ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                               h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+                                               ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
-                                                        h->map, h->pr, h->d_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+                                                        h->map, h->pr, ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
     }
     return LK_OK;
 }
@@ -1532,6 +1561,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
     if (rc) return rc;
     size_t qi = 0, qk = 0;
     size_t idx_i = 0;
+    bool pre_predicted = false;
     while (idx_i < n) {  // KILO.cc:375-395
         double cur_point_time = t_begin + pts[idx_i].curvature;
         size_t idx_j = idx_i + 1;
@@ -1544,8 +1574,17 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
             if ((rc = enqueue_kin(h, &kins[qk]))) return rc;
             ++qk;
         }
+        // the next bucket's predict rides in this bucket's launch when nothing lies in between and both are large buckets
+        double t_next = NAN;
+        if (idx_j < n) {
+            size_t idx_k = idx_j + 1;
+            while (idx_k < n && pts[idx_j].curvature == pts[idx_k].curvature) idx_k++;
+            const double tn = t_begin + pts[idx_j].curvature;
+            const bool msg_between = (qi < n_imu && imus[qi].stamp < tn) || (qk < n_kin && kins[qk].time_stamp < tn);
+            if (!msg_between && idx_k - idx_j > LK_SMALL_MAX && idx_j - idx_i > LK_SMALL_MAX) t_next = tn;
+        }
         rc = enqueue_bucket(h, d_pts + idx_i, (int)(idx_j - idx_i), cur_point_time,
-                            xyz_world_out ? h->d_world + 4 * idx_i : nullptr, true);
+                            xyz_world_out ? h->d_world + 4 * idx_i : nullptr, true, t_next, &pre_predicted);
         if (rc) return rc;
         idx_i = idx_j;
     }
@@ -1574,10 +1613,13 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
+    bool pre_predicted = false;
     for (size_t b = 0; b < n_buckets; ++b) {
         int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
         if (nb <= 0) continue;
-        rc = enqueue_bucket(h, d_pts + bucket_off[b], nb, t_begin + bucket_dt[b], nullptr, true);
+        double t_next = NAN;
+        if (b + 1 < n_buckets && nb > LK_SMALL_MAX && (int)(bucket_off[b + 2] - bucket_off[b + 1]) > LK_SMALL_MAX) t_next = t_begin + bucket_dt[b + 1];
+        rc = enqueue_bucket(h, d_pts + bucket_off[b], nb, t_begin + bucket_dt[b], nullptr, true, t_next, &pre_predicted);
         if (rc) return rc;
     }
     if ((rc = spec_join(h))) return rc;

@@ -394,16 +394,6 @@ __device__ __forceinline__ void dev_snapshot_posterior(const LkFilter* f, LkFilt
     if (tid < 180) snap->P[tid] = f->P[tid];
     if (tid == 0) snap->updated = f->updated, snap->last_N = f->last_N;
 }
-// lk_update_kernel of the stream path (slot 0) + the posterior's snapshot for the insert stream
-__global__ void __launch_bounds__(LK_FB)
-    lk_update_snap_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, double t, const double* __restrict__ Q, LkFilter* snap) {
-    __shared__ FilterSmem sm;
-    __shared__ double red[8][LK_NPART];
-    __shared__ double tot[LK_NPART];
-    dev_update_reduce(&filters[0], partials, nblk, t, Q, 0.0, 0, sm, red, tot);
-    dev_snapshot_posterior(&filters[0], snap);
-}
-
 // ---- lk_update_kernel for batch replay as ONE WAVE per filter slot, in the resource footprint of a residual workgroup
 // (64 threads, 7 680 B of LDS, <= 96 VGPRs).  A 256-thread update workgroup needs 40 KB of LDS and four wave slots at
 // once; on a CU saturated with residual workgroups of another stream those never become free together, so the update of

@@ -585,6 +585,7 @@ def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
     o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
     g = hip_lib.LegKiloHip(scene.cfg())
     g_seq = hip_lib.LegKiloHip(scene.cfg())
+    g.stream_pipeline(True)        # off by default (the sequential order measures faster)
     g_seq.stream_pipeline(False)
     t0 = 11.0
     for obj in (o, g, g_seq):
