@@ -272,7 +272,11 @@ def main():
             _, s2 = replay.broadcast_map(g, dist, rank, world_size, dev, src=0, algo="scatter_allgather")
             bcast2_ms = s2 * 1e3
         except Exception as e:  # noqa: BLE001
-            warnings.append(f"scatter_allgather map broadcast FAILED on this backend: {type(e).__name__}: {str(e)[:160]}")
+            msg = f"scatter_allgather map broadcast FAILED on backend {dist.get_backend()}: {type(e).__name__}: {str(e)[:160]}"
+            if dist.get_backend() == "nccl":   # the real transport (RCCL over xGMI): never fall back silently - fail the run
+                print(msg, file=sys.stderr, flush=True)
+                raise
+            warnings.append(msg)
     n_roots, n_nodes, n_blocks = g.map_stats()
     map_build_s = time.time() - t_map0
     # the checker replays against EXACTLY this snapshot: exported now, before the stream extras (which insert) touch the map
@@ -340,6 +344,13 @@ def main():
 
     # ---- sustained run (>= 1 s of back-to-back steps; same loop, not the graded number)
     extra = {}
+    # untimed: SURVEY 8(e)'s full per-scan result record - state 36 + covariance 900 - of the last batch in slots [0, S), gathered on
+    # the device by one kernel (lk_batch_get_states_dev) and, for N > 1, all-gathered device to device over RCCL
+    xs_all, Ps_all = replay.gather_state_records(dist, g, 0, S, world_size, dev)
+    extra["state_records_gathered"] = int(xs_all.shape[0])
+    extra["state_record_bytes_per_scan"] = 936 * 8
+    extra["state_records_cov_finite"] = bool(torch.isfinite(Ps_all).all().item())
+    del xs_all, Ps_all
     if args.sustained_s > 0:
         n_sus = max(4, int(math.ceil(args.sustained_s * 1e3 / ms_per_step)))
         sync_all()
@@ -352,6 +363,29 @@ def main():
         extra["sustained_scans_per_s"] = round((args.total_scans if strong else S * world_size) * n_sus / sus, 1)
         extra["sustained_steps"] = n_sus
         extra["sustained_seconds"] = round(sus, 3)
+
+    # ---- the strong-scaling shard on ONE GPU: BASELINE config 5 at N = 8 gives every GPU 128 of the 1024 scans.  The same loop with
+    # 128-scan batches (three in flight, rotating over three slot ranges / streams) - what a GPU of the 8-GPU run executes per step.
+    if S >= 128:
+        S8 = 128
+
+        def step8(k):
+            g.batch_replay_async_dev(d_batch.data_ptr(), (k % 3) * S8, S8, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(), d_P900=d_P.data_ptr(),
+                                     host_out_ptr=ring[k % ring_rows].data_ptr())
+        n8 = 8 * max(args.steps, 10)
+        for k in range(max(args.warmup, 6)):
+            step8(k)
+        sync_all()
+        ts = time.perf_counter()
+        for k in range(n8):
+            step8(k)
+        sync_all()
+        t8 = (time.perf_counter() - ts) / n8
+        extra["shard128_ms_per_step"] = round(t8 * 1e3, 4)
+        extra["shard128_ps_per_point"] = round(t8 * 1e12 / (S8 * N_PTS), 2)
+        extra["shard128_scans_per_s"] = round(S8 / t8, 1)
+        extra["shard128_vs_full_batch_ps_ratio"] = round((t8 / (S8 * N_PTS)) / (elapsed / args.steps / (S * N_PTS)), 3)
+        extra["shard128_note"] = "128-scan batches = one GPU's share of config 5 at N = 8, three batches in flight on one GPU"
 
     if args.step_sweep:   # diagnostic: fixed cost (ramp + drain) vs per-step cost of a timed region, elapsed(K) = a + b K
         sweep = {}

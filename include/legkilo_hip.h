@@ -300,12 +300,22 @@ int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, siz
 int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P900, size_t n_scans);
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
+/* Bulk read-out of the filters a batch replay left in slots [first_slot, first_slot + n): state (n x 36: rot 9, pos, vel, ba, bw,
+ * grav, imu_a, imu_w, bv, contact) and covariance (n x 900, row-major) - what ESKF::state() / cov() and getRotCov / getPosCov /
+ * getVelCov (blocks (0,0), (3,3), (6,6) of P, eskf.h:46-109) give per filter, for all of them with ONE gather kernel instead of one
+ * lk_get_state round trip per slot.  Either pointer may be NULL.  _dev: device pointers, asynchronous on the handle's stream (after
+ * everything the batch entries enqueued); the host variant synchronises.  Per scan this is SURVEY 8(e)'s result record: pose, P, and
+ * the counters of lk_pose. */
+int lk_batch_get_states_dev(lk_handle* h, uint32_t first_slot, size_t n, double* d_x36, double* d_P900);
+int lk_batch_get_states(lk_handle* h, uint32_t first_slot, size_t n, double* x36, double* P900);
 /* Asynchronous, double-buffered variant: the batch uses filter slots [first_slot, first_slot + n_scans); batches whose
  * slot ranges rotate (first_slot = 0, n_scans, [2 n_scans,] 0, ...) run on up to three streams, so the latency-bound update / predict
  * kernels of one batch overlap the residual launches of the others.  d_x36 / d_P900 (device, n_scans x 36 / 900; both NULL =
  * keep the slots' state) arm the priors on the batch's own stream; the poses are copied into host_out (n_scans records;
  * PINNED host memory for a truly asynchronous copy; may be NULL).  Nothing synchronises: lk_synchronize() completes all
- * enqueued batches.  Buffers must stay valid / untouched until then. */
+ * enqueued batches.  Buffers must stay valid / untouched until then.  first_slot must be a multiple of n_scans (LK_ERR_INVALID
+ * otherwise): the stream a batch runs on is a function of its slot range, so equal-sized ranges never overlap partially; a call
+ * with a different n_scans than the batches still in flight first drains them. */
 int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t first_slot, size_t n_scans, size_t n_pts, double t_begin,
                               const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, const double* d_x36,
                               const double* d_P900, lk_pose* host_out);

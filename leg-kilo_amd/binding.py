@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_stats",
 ]
 
@@ -308,6 +308,17 @@ class LegKiloHip:
     def batch_set_priors_dev(self, d_x36, d_P900, n_scans):
         """Priors already in HBM (device pointers to n_scans x 36 and n_scans x 900 doubles); asynchronous."""
         self._chk(self.L.lk_batch_set_priors_dev(self.h, C.c_void_p(d_x36), C.c_void_p(d_P900), C.c_size_t(n_scans)))
+
+    def batch_get_states(self, first_slot, n, want_P=True):
+        """State [n, 36] and covariance [n, 30, 30] of the filter slots first_slot .. first_slot + n (one gather kernel)."""
+        x = np.zeros((n, 36))
+        P = np.zeros((n, 900)) if want_P else None
+        self._chk(self.L.lk_batch_get_states(self.h, C.c_uint32(first_slot), C.c_size_t(n), _p(x), _p(P)))
+        return x, (P.reshape(n, 30, 30) if want_P else None)
+
+    def batch_get_states_dev(self, first_slot, n, d_x36, d_P900):
+        """The same into device buffers (pointers or 0), asynchronous on the handle's stream."""
+        self._chk(self.L.lk_batch_get_states_dev(self.h, C.c_uint32(first_slot), C.c_size_t(n), C.c_void_p(d_x36 or None), C.c_void_p(d_P900 or None)))
 
     def batch_replay_dev(self, d_pts, n_scans, n_pts, t_begin, bucket_off, bucket_dt, want_poses=True):
         off = np.ascontiguousarray(bucket_off, dtype=np.uint32)

@@ -40,6 +40,7 @@ struct lk_handle {
     hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
     int replay_groups = 3;
+    size_t async_n = 0;           // n_scans of the asynchronous batches that may be in flight (0: none since the last lk_synchronize)
     bool wave_update = true;  // batch replay: single-wave update kernel (LEGKILO_UPDATE_CLASSIC=1 selects the 256-thread one)
     double last_slide_position[3] = {0.0, 0.0, 0.0};  // voxel_map.h:201
     unsigned int hash_cap = 0;
@@ -1812,6 +1813,47 @@ int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P
     return LK_OK;
 }
 
+// one workgroup per slot: state and covariance of a filter slot into dense [n][36] / [n][900] arrays
+__global__ void __launch_bounds__(256) lk_states_gather_kernel(const LkFilter* __restrict__ filters, double* __restrict__ x36, double* __restrict__ P900) {
+    const LkFilter* f = &filters[blockIdx.x];
+    if (x36 && threadIdx.x < LK_STATE_DOUBLES) x36[(size_t)blockIdx.x * LK_STATE_DOUBLES + threadIdx.x] = f->x[threadIdx.x];
+    if (P900)
+        for (int e = threadIdx.x; e < 900; e += 256) P900[(size_t)blockIdx.x * 900 + e] = f->P[e];
+}
+static int join_side_streams(lk_handle* h) {   // the asynchronous batch entry may still be running on a side stream
+    for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
+        if (h->side[i]) {
+            HIPCHK(h, hipEventRecord(h->ev_join[i], h->side[i]));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+        }
+    return LK_OK;
+}
+int lk_batch_get_states_dev(lk_handle* h, uint32_t first_slot, size_t n, double* d_x36, double* d_P900) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if ((size_t)first_slot + n > (size_t)h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot range exceeds n_slots");
+    int rc = join_side_streams(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk_states_gather_kernel, dim3((unsigned int)n), dim3(256), 0, h->stream, h->d_filters + first_slot, d_x36, d_P900);
+    HIPCHK(h, hipGetLastError());
+    return LK_OK;
+}
+int lk_batch_get_states(lk_handle* h, uint32_t first_slot, size_t n, double* x36, double* P900) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if ((size_t)first_slot + n > (size_t)h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot range exceeds n_slots");
+    DevTemps tmp;
+    double *d_x = nullptr, *d_P = nullptr;
+    if (x36) HIPCHK(h, tmp.alloc(&d_x, sizeof(double) * LK_STATE_DOUBLES * n));
+    if (P900) HIPCHK(h, tmp.alloc(&d_P, sizeof(double) * 900 * n));
+    int rc = lk_batch_get_states_dev(h, first_slot, n, d_x, d_P);
+    if (rc) return rc;
+    if (x36) HIPCHK(h, hipMemcpyAsync(x36, d_x, sizeof(double) * LK_STATE_DOUBLES * n, hipMemcpyDeviceToHost, h->stream));
+    if (P900) HIPCHK(h, hipMemcpyAsync(P900, d_P, sizeof(double) * 900 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
 __global__ void lk_set_times_kernel(LkFilter* filters, int n, double t) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n) filters[s].last_predict_t = t, filters[s].last_update_t = t;
@@ -2220,6 +2262,16 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     }
     // batches on slot ranges 0, n, 2n, ... rotate over up to three streams (the handle's + two side streams): with three batches in
     // flight there is (almost) always a residual launch ready while the other two sit in their update / predict launches
+    // The stream is a function of (first_slot, n_scans): two batches in flight on overlapping slots are ordered only if they
+    // share it.  So first_slot must be a multiple of n_scans (slot ranges of one size never overlap partially), and when the batch
+    // size changes while batches may still be in flight the streams are drained first.
+    if (first_slot % (uint32_t)n_scans != 0) return fail(h, LK_ERR_INVALID, "first_slot must be a multiple of n_scans");
+    if (h->async_n != 0 && h->async_n != n_scans) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
+            if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));
+    }
+    h->async_n = n_scans;
     const uint32_t ring = (first_slot / (uint32_t)n_scans) % 3u;
     hipStream_t st = ring == 0 ? h->stream : h->side[ring - 1];
     LkFilter* fl = h->d_filters + first_slot;
@@ -2324,6 +2376,7 @@ int lk_synchronize(lk_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
         if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));  // double-buffered async batches live there
+    h->async_n = 0;
     return LK_OK;
 }
 int lk_stream_pipeline(lk_handle* h, int on) {

@@ -288,6 +288,7 @@ class KiloPath {
     }
     ESKF& eskf() { return *eskf_; }
     VoxelMapManager& map_manager() { return *map_manager_; }
+    Device& device() { return *dev_; }   // the lk_handle behind both mirrors (multi-GPU helpers: legkilo_rccl.hpp)
     void setTimes(double last_predict, double last_update) { dev_->check(lk_set_times(dev_->h(), 0, last_predict, last_update)); }
     void setAccNorm(double a) { dev_->check(lk_set_acc_norm(dev_->h(), a)); }
     double accNorm() const {

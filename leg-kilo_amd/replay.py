@@ -116,6 +116,33 @@ def gather_pose_bytes(dist, local_bytes, world, device):
     return torch.stack(out)
 
 
+def gather_state_records(dist, engine, first_slot, n_local, world, device):
+    """SURVEY 8(e)'s per-scan result record - state (36) and covariance (900: ESKF::cov(), getRotCov / getPosCov / getVelCov are its
+    blocks (0,0), (3,3), (6,6), eskf.h:46-109) - of the n_local scans a rank replayed in filter slots first_slot .. first_slot +
+    n_local, all-gathered in rank order: returns (x [n_total, 36], P [n_total, 900]).  Every rank must pass the same n_local
+    (bench: scans_per_gpu).  On a GPU the records never touch the host: one gather kernel (lk_batch_get_states_dev) fills two
+    device tensors and RCCL all-gathers them device to device; on the CPU (gloo tests) the engine's batch_get_states arrays are
+    all-gathered."""
+    import torch
+
+    if device.type == "cuda":
+        x = torch.empty((n_local, 36), dtype=torch.float64, device=device)
+        P = torch.empty((n_local, 900), dtype=torch.float64, device=device)
+        engine.batch_get_states_dev(first_slot, n_local, x.data_ptr(), P.data_ptr())
+        engine.synchronize()
+    else:
+        xh, Ph = engine.batch_get_states(first_slot, n_local)
+        x = torch.from_numpy(np.ascontiguousarray(xh, dtype=np.float64).reshape(n_local, 36))
+        P = torch.from_numpy(np.ascontiguousarray(Ph, dtype=np.float64).reshape(n_local, 900))
+    if world == 1:
+        return x, P
+    xo = torch.empty((world * n_local, 36), dtype=torch.float64, device=device)
+    Po = torch.empty((world * n_local, 900), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(xo, x)
+    dist.all_gather_into_tensor(Po, P)
+    return xo, Po
+
+
 def pose_rows(poses):
     """lk_pose records (a ctypes array, or any buffer / numpy array of abi.pose_dtype()) -> float64 rows
     [pos(3), vel(3), rot(9), n_effect, n_buckets, n_updates]; vectorised (a 1024-scan batch per step)."""

@@ -85,6 +85,18 @@ def test_host_mirror_compiles_against_the_c_abi():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+def test_host_rccl_example_compiles_against_rccl_and_the_c_abi():
+    """The C++ multi-GPU hook (host/legkilo_rccl.hpp: map broadcast over a caller-owned ncclComm_t, shard partition, all-gather of the
+    result records) and its one-process-all-GPUs example compile and link against rccl.h, the HIP runtime and the C-ABI."""
+    src = os.path.join(ROOT, "leg-kilo_amd", "host", "example_replay_rccl.cc")
+    exe = "/tmp/lk_host_rccl_example"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "leg-kilo_amd", "host"), src, "-o", exe, "-L", os.path.join(ROOT, "leg-kilo_amd"), "-llegkilo_hip",
+                        "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "leg-kilo_amd"),
+                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_ragged_tables_layout():
     """binding.ragged_tables flattens per-scan bucket tables into exactly what lk_batch_replay_ragged(_imu)_dev takes."""
     import lk_pkg

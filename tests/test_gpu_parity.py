@@ -692,15 +692,23 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     if S == 7:
         g.device_free(d_x)
         g.device_free(d_P)
+    # bulk read-out with covariance (lk_batch_get_states: one gather kernel) == the per-slot calls, bit for bit
+    Xall, Pall = g.batch_get_states(0, S)
     for s in range(S):
         o.set_state(xs[s], Ps[s])
         o.set_times(0.0, 0.0)
         po, _ = o.process_scan(scans[s], 0.0)
-        xo, _ = o.get_state()
-        xg, _ = g.get_state(slot=s)
+        xo, Po = o.get_state()
+        xg, Pg = g.get_state(slot=s)
         assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
         assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
         assert np.allclose(np.array(poses[s].pos), xo[9:12], atol=1e-8)
+        assert np.array_equal(Xall[s], xg) and np.array_equal(Pall[s], Pg), s
+        # the covariance a caller gets per scan (SURVEY 8e record; getRotCov / getPosCov / getVelCov are its diagonal blocks)
+        assert np.abs(Pg - Po).max() <= 1e-6 * np.abs(Po).max(), (s, np.abs(Pg - Po).max() / np.abs(Po).max())
+        for b0 in (0, 3, 6):
+            blk_o, blk_g = Po[b0:b0 + 3, b0:b0 + 3], Pall[s][b0:b0 + 3, b0:b0 + 3]
+            assert np.abs(blk_g - blk_o).max() <= 1e-6 * np.abs(blk_o).max(), (s, b0)
     if S == 6:
         # the asynchronous, double-buffered entry: the same batch on slots [0, S) and on [S, 2S) (the second stream),
         # priors armed on the batch's own stream, poses copied to host memory on the stream; nothing synchronises until

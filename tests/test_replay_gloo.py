@@ -190,6 +190,48 @@ def _worker_same_rows(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class StubStateEngine:
+    """batch_get_states of a rank whose slots hold recognisable records."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def batch_get_states(self, first_slot, n):
+        x = np.array([[1000.0 * self.rank + first_slot + i + 0.001 * k for k in range(36)] for i in range(n)])
+        P = np.array([np.full(900, 10.0 * self.rank + first_slot + i) for i in range(n)])
+        return x, P.reshape(n, 30, 30)
+
+
+def _worker_states(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, P = replay.gather_state_records(dist, StubStateEngine(rank), 4, 3, world, torch.device("cpu"))
+    q.put((rank, x.numpy().copy(), P.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_gather_state_records_world2():
+    """The per-scan result record with covariance (state 36 + P 900), all-gathered in rank order on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_states, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (x, P) for r, x, P in (q.get(timeout=180) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        x, P = res[r]
+        assert x.shape == (6, 36) and P.shape == (6, 900)
+        for owner in (0, 1):
+            xe, Pe = StubStateEngine(owner).batch_get_states(4, 3)
+            assert np.array_equal(x[3 * owner:3 * owner + 3], xe) and np.array_equal(P[3 * owner:3 * owner + 3], Pe.reshape(3, 900))
+    x1, P1 = replay.gather_state_records(None, StubStateEngine(0), 4, 3, 1, torch.device("cpu"))
+    assert x1.shape == (3, 36) and P1.shape == (3, 900)
+
+
 def test_world1_and_world2_gather_identical_rows():
     """The same 8 scans replayed unsharded (N = 1) and sharded over 2 ranks (gloo): every rank ends up with the SAME 8 rows,
     bit for bit, in scan order - the property the multi-GPU bench relies on."""
