@@ -53,6 +53,20 @@ SIMDS, CLK_GHZ = 1024, 2.4
 N_PTS = 100_000
 N_BUCKETS = 5
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
+FP64_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: fp64 vector peak (the matrix rate is the same)
+COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
+KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
+
+
+def kernel_sources_sha16():
+    """Fingerprint of the batch residual kernel's sources: tools/collect_r03.py stores it beside the counters it collects, and the
+    bench line warns when the kernel has changed since (the counters then describe an older kernel)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "leg-kilo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 class Frozen:
@@ -418,7 +432,12 @@ def main():
             pmc = json.load(open(PMC_FILE))
         except Exception as e:  # noqa: BLE001
             warnings.append(f"profiles/latest_pmc.json unreadable: {e}")
+    if pmc and pmc.get("kernel_sources_sha16") != kernel_sources_sha16():
+        warnings.append(f"roofline counters (profiles/latest_pmc.json, tag {pmc.get('tag')}, commit {pmc.get('commit')}) were collected on a different "
+                        f"version of {', '.join(KERNEL_SOURCES)}: re-run tools/gpu_prof_r03.sh")
     hbm_bpp = pmc.get("hbm_bytes_per_point") if pmc else None
+    fp64_flops = pmc.get("fp64_flops_per_point") * pts_per_launch if pmc and pmc.get("fp64_flops_per_point") else None
+    fp64_tflops = fp64_flops / (launch_ms * 1e-3) / 1e12 if fp64_flops else None
     traffic = hbm_bpp * pts_per_launch if hbm_bpp else None
     hbm_GBs = traffic / (launch_ms * 1e-3) / 1e9 if traffic else None
     l2_GBs = pmc["tcc_req_per_point"] * 128.0 * pts_per_launch / (launch_ms * 1e-3) / 1e9 if pmc and pmc.get("tcc_req_per_point") else None
@@ -437,9 +456,15 @@ def main():
         "hbm_bytes_per_point_counters": hbm_bpp,
         "l2_GBs": None if l2_GBs is None else round(l2_GBs, 1), "l2_frac": None if l2_GBs is None else round(l2_GBs / L2_PEAK_GBS, 4),
         "valu_issue_frac": None if valu_frac is None else round(valu_frac, 3),
+        # the roofline the kernel lives on: fp64 vector FLOP/s (counter-derived: 2 FMA + ADD + MUL + TRANS wave instructions x 64 lanes)
+        "fp64_flops": None if fp64_flops is None else round(fp64_flops), "fp64_TFLOPs": None if fp64_tflops is None else round(fp64_tflops, 2),
+        "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS, "fp64_frac": None if fp64_tflops is None else round(fp64_tflops / FP64_PEAK_TFLOPS, 4),
+        "fp64_flops_per_point": pmc.get("fp64_flops_per_point") if pmc else None,
+        "compulsory_bytes_per_point": COMPULSORY_BYTES_PER_POINT,
+        "traffic_over_compulsory": None if hbm_bpp is None else round(hbm_bpp / COMPULSORY_BYTES_PER_POINT, 3),
         "valu_insts_per_wave": pmc.get("valu_insts_per_wave") if pmc else None,
         "mfma_f64_ops": pmc.get("mfma_f64_ops") if pmc else None,
-        "pmc_source": None if not pmc else f"profiles/latest_pmc.json (tag {pmc.get('tag')}, {pmc.get('slots')} slots x {pmc.get('unique_scans')} unique scans)",
+        "pmc_source": None if not pmc else f"profiles/latest_pmc.json (tag {pmc.get('tag')}, commit {pmc.get('commit')}, {pmc.get('slots')} slots x {pmc.get('unique_scans')} unique scans)",
         "launch_ms": round(launch_ms, 4), "launch_ms_source": f"timed region: ms_per_step / {N_BUCKETS} residual launches",
         "launch_ms_single_stream_events": round(ev_res_ms, 4), "launches_event_pass": n_res,
         "points_per_launch": pts_per_launch, "ps_per_point": round(launch_ms * 1e9 / pts_per_launch, 2),
