@@ -922,7 +922,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
 // The map as the batch-replay kernels see it: with the dense root grid when it can be built (LkMap::grid).  The grid is derived
 // from the hash table + match records and rebuilt when the map has changed since (every mutating entry clears grid_valid);
 // building it is two small kernels + a memset, synchronised once - it happens per map snapshot, not per batch.
-static constexpr size_t kGridMaxCells = (size_t)1 << 24;   // 16 Mi cells x 144 B = 2.4 GB (record indices stay 32-bit byte offsets); larger boxes stay on the hash
+static constexpr size_t kGridMaxCells = (size_t)1 << 24;   // 16 Mi cells x 144 B = 2.4 GB of grid at most (record INDICES are 32-bit, addressing is 64-bit); larger boxes stay on the hash
 static int frozen_map(lk_handle* h, LkMap* out) {
     *out = h->map;
     out->grid_on = 0;
@@ -970,13 +970,16 @@ static int frozen_map(lk_handle* h, LkMap* out) {
                 HIPCHK(h, hipMemsetAsync(fm.match + fm.grid_base, 0xff, cells * sizeof(lk_match_rec), h->stream));
                 // the lists (every non-root node at most once) live behind the allocated cells
                 const unsigned int cand0 = (unsigned int)((size_t)h->map.max_nodes + h->grid_cap);
-                unsigned int* cursor = reinterpret_cast<unsigned int*>(h->d_grid_mm + 6);
-                HIPCHK(h, hipMemcpyAsync(cursor, &cand0, sizeof(cand0), hipMemcpyHostToDevice, h->stream));
+                unsigned int* cursor = reinterpret_cast<unsigned int*>(h->d_grid_mm + 6);   // [0] next free list record, [1] overflow flag
+                const unsigned int cur0[2] = {cand0, 0u};
+                unsigned int cur1[2] = {0u, 0u};
+                HIPCHK(h, hipMemcpyAsync(cursor, cur0, sizeof(cur0), hipMemcpyHostToDevice, h->stream));
                 hipLaunchKernelGGL(lk_grid_fill_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, h->stream, fm, h->hash_cap, h->pr.max_layer,
                                    cursor, cand0 + h->map.max_nodes);
                 HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipMemcpyAsync(cur1, cursor, sizeof(cur1), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(h, hipStreamSynchronize(h->stream));   // the side streams of the replay entries may read it at once
-                fm.grid_on = 1;
+                fm.grid_on = cur1[1] ? 0 : 1;   // list region overflowed (a blob whose subtrees share nodes): this snapshot stays on the hash table
             }
         }
         h->fmap = fm;
@@ -2032,7 +2035,10 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
         if (nbs == 0) return fail(h, LK_ERR_INVALID, "a scan has no buckets");
         if (bo[0] != 0 || scan_off[s] + bo[nbs] != scan_off[s + 1]) return fail(h, LK_ERR_INVALID, "bucket offsets do not tile the scan");
         uint32_t c = 0;
+        const double* bt = bucket_dt + row_t;
         for (size_t b = 0; b < nbs; ++b) {
+            // the same ordering rule the device-built tables enforce (lk_rag_flag_kernel): time stamps finite and non-decreasing
+            if (!std::isfinite(bt[b]) || (b > 0 && bt[b] < bt[b - 1])) return fail(h, LK_ERR_INVALID, "bucket times must be finite and non-decreasing (KILO.cc:367-370 sorts the scan by time)");
             if (bo[b + 1] < bo[b]) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing");
             if ((size_t)(bo[b + 1] - bo[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
             c += bo[b + 1] > bo[b];

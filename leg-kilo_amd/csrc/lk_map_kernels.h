@@ -1467,7 +1467,11 @@ __global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned i
             if (pass == 1) {
                 if (count == 0) break;
                 first = atomicAdd(cursor, count);
-                if (first + count > cand_end) {   // cannot happen (sized for every non-root node); fail safe: no list
+                if (first + count > cand_end) {
+                    // The list region is sized for every non-root node once.  A map whose child links share nodes (only an imported
+                    // blob could: lk_map_import_dev range-checks ids, not the tree shape) can need more: flag it - frozen_map() then
+                    // keeps this snapshot on the hash table instead of silently matching against a root without candidates.
+                    atomicExch(cursor + 1, 1u);
                     count = 0;
                     break;
                 }

@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(256)
     const bool head = i == scan_off[s];
     const float cp = head ? c : pts[i - 1].curvature;
     flag[i] = (head || c != cp) ? 1u : 0u;
-    if (!(c >= cp)) stats[3] = 1u;   // out of time order (or NaN): the caller skipped the sort of KILO.cc:367
+    if (!(c >= cp) || !isfinite(c)) stats[3] = 1u;   // out of time order, NaN or +-inf (an infinite stamp would make the predict's dt infinite):
+                                                     // the caller skipped the sort of KILO.cc:367 or handed over a corrupt cloud
 }
 // stats: [0] total buckets B, [1] largest bucket (points), [2] most buckets in a scan, [3] 1: some scan is not sorted by time
 __global__ void __launch_bounds__(256)

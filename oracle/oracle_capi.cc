@@ -9,6 +9,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "export_blob.hpp"
 #include "oracle_kilo.hpp"
@@ -311,7 +313,7 @@ int lko_map_import(lko_handle* h, const void* blob, size_t bytes) {
     std::memcpy(&hd, blob, sizeof(hd));
     const size_t want = sizeof(hd) + (size_t)hd.n_roots * sizeof(lk_root_rec) + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
                         (size_t)hd.n_blocks * sizeof(lk_block_rec);
-    if (hd.magic != LK_BLOB_MAGIC || hd.block_pts != LK_BLOCK_PTS || hd.bytes != want || want > bytes) return -1;
+    if (hd.magic != LK_BLOB_MAGIC || hd.version != LK_ABI_VERSION || hd.block_pts != LK_BLOCK_PTS || hd.bytes != want || want > bytes) return -1;
     const char* p = (const char*)blob + sizeof(hd);
     const lk_root_rec* roots = (const lk_root_rec*)p;
     p += (size_t)hd.n_roots * sizeof(lk_root_rec);
@@ -320,14 +322,28 @@ int lko_map_import(lko_handle* h, const void* blob, size_t bytes) {
     const lk_plane_rec* planes = (const lk_plane_rec*)p;
     p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
     const lk_block_rec* blocks = (const lk_block_rec*)p;
+    // every id is checked BEFORE the oracle's own map is touched: a mismatched blob must fail, never leave a half-built map that a
+    // later "parity" comparison would silently run against
+    for (uint32_t r = 0; r < hd.n_roots; ++r)
+        if (roots[r].node < 0 || (uint32_t)roots[r].node >= hd.n_nodes) return -1;
+    for (uint32_t i = 0; i < hd.n_nodes; ++i) {
+        for (int c = 0; c < 8; ++c)
+            if (nodes[i].child[c] < -1 || (nodes[i].child[c] >= 0 && (uint32_t)nodes[i].child[c] >= hd.n_nodes)) return -1;
+        if (nodes[i].block < -1 || (nodes[i].block >= 0 && (uint32_t)nodes[i].block >= hd.n_blocks)) return -1;
+    }
+    std::vector<std::pair<Vec3i, VoxelOctoTree*>> built;
+    for (uint32_t r = 0; r < hd.n_roots; ++r) {
+        VoxelOctoTree* t = import_node(h->cfg, nodes, planes, blocks, hd.n_nodes, hd.n_blocks, roots[r].node, 0);
+        if (!t) {
+            for (auto& kv : built) delete kv.second;
+            return -1;
+        }
+        built.emplace_back(Vec3i{roots[r].key[0], roots[r].key[1], roots[r].key[2]}, t);
+    }
     auto& m = *h->kilo->map_manager_;
     for (auto& kv : m.voxel_map_) delete kv.second;
     m.voxel_map_.clear();
-    for (uint32_t r = 0; r < hd.n_roots; ++r) {
-        VoxelOctoTree* t = import_node(h->cfg, nodes, planes, blocks, hd.n_nodes, hd.n_blocks, roots[r].node, 0);
-        if (!t) return -1;
-        m.voxel_map_[Vec3i{roots[r].key[0], roots[r].key[1], roots[r].key[2]}] = t;
-    }
+    for (auto& kv : built) m.voxel_map_[kv.first] = kv.second;
     return 0;
 }
 

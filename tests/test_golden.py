@@ -75,19 +75,19 @@ def test_hip_reproduces_golden(hip_lib):
 
 
 @pytest.mark.gpu
-def test_host_mirror_example_runs(hip_lib, oracle_lib):
+def test_host_mirror_example_runs(hip_lib, oracle_lib, tmp_path):
     """The C++ mirror of the reference classes (leg-kilo_amd/host) drives the same library end to end, and what it computes -
     BuildVoxelMap, one predictUpdatePoint bucket, a two-scan recorded-run replay - equals the oracle on the SAME inputs (the
     example dumps its clouds and results): match count exact, state to 1e-7, replay poses to 1e-7."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = "/tmp/lk_host_example_gpu"
+    exe = str(tmp_path / "lk_host_example_gpu")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "leg-kilo_amd", "host"),
                         os.path.join(root, "leg-kilo_amd", "host", "example_kilo_path.cc"), "-o", exe, "-L", os.path.join(root, "leg-kilo_amd"),
                         "-llegkilo_hip", "-Wl,-rpath," + os.path.join(root, "leg-kilo_amd")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
-    dump = "/tmp/lk_host_example_dump.bin"
+    dump = str(tmp_path / "lk_host_example_dump.bin")   # per-test directory: parallel pytest workers do not collide
     r = subprocess.run([exe, dump], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1500:])
     from legkilo_amd import abi, config
