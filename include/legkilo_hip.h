@@ -369,6 +369,11 @@ int lk_synchronize(lk_handle* h);
  * insert stamped.  Results are those of the sequential order.  lk_stream_stats: out4 = { buckets that went through the
  * pipeline, their residual tiles, tiles the verify pass evaluated again, 0 } since lk_create. */
 int lk_stream_pipeline(lk_handle* h, int on);
+/* Scan-resident stream kernel: a scan whose time buckets all hold <= 512 points (the reference's own scan shape: 2 ms bins of a dozen
+ * points) runs its whole bucket loop - messages, predict, residual, update AND map insert (KILO.cc:375-395, :216-233) - as ONE launch
+ * of one resident workgroup instead of several launches per bucket (on by default; on = 0 or LEGKILO_RESIDENT=0: per-bucket
+ * launches).  Same device functions, identical results. */
+int lk_stream_resident(lk_handle* h, int on);
 int lk_stream_stats(lk_handle* h, uint64_t* out4);
 void* lk_stream(lk_handle* h);                                         /* the handle's hipStream_t */
 

@@ -67,6 +67,7 @@ struct lk_handle {
     unsigned int epoch = 16;      // bucket sequence number: stamps of LkMap::dirty / newroot, value of spec[LK_SPEC_DONE]
     unsigned int spec_base = 16;  // first epoch of the open window (stamps below it belong to inserts that were joined)
     bool spec_open = false;       // inserts may still be running on `ins`
+    bool resident_enable = true;  // scans of small buckets as one resident launch (lk_scan_stream_kernel); LEGKILO_RESIDENT=0 / lk_stream_resident(h, 0): per-bucket launches
     bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
     int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
@@ -287,6 +288,7 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_I, hipEventDisableTiming));
     if (const char* e = getenv("LEGKILO_SPEC")) h->spec_enable = atoi(e) != 0;
+    if (const char* e = getenv("LEGKILO_RESIDENT")) h->resident_enable = atoi(e) != 0;
     HIPCHK(h, hipMalloc(&h->d_snap, sizeof(LkFilter) * 2));
     HIPCHK(h, hipMemsetAsync(h->d_snap, 0, sizeof(LkFilter) * 2, h->stream));
     HIPCHK(h, hipMalloc(&h->d_ids, sizeof(int2) * (size_t)m.max_scan));
@@ -764,6 +766,197 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
     dev_scan_wave(map, pr, filters, pts, rg, Q, sm, rows, 2);
 }
 
+// ------------------------------------------------------------------ scan-resident stream kernel
+// A live scan of SMALL buckets (the reference's own shape: 2 ms time bins of a dozen points, hundreds per scan) as ONE launch of ONE
+// workgroup (a filter wave + an insert team of three waves) that stays resident for the whole bucket loop of KILO::process (KILO.cc:375-395):
+//   wave 0 (filter)  the chain of dev_scan_wave: the messages stamped before a bucket (predictUpdateImu / predictUpdateKinImu),
+//                    predict, the bucket's residual tiles, update - state and covariance stay in LDS for the whole scan (the one-wave
+//                    cores, MW = true: their barriers involve this wave only) - then the posterior's snapshot for the insert;
+//   waves 1-3        the map insert of every bucket from that snapshot (KILO.cc:216-233): pool bookkeeping, re-projection + root
+//   (insert team)    hashing, then the root pass / emitted groups / fallback items of the touched roots, the roots spread over the
+//                    team; its phases are separated by a barrier of the team alone (an LDS counter).
+// The two run as a PIPELINE: while wave 1 inserts bucket k, wave 0 already predicts and evaluates bucket k + 1 - speculatively,
+// remembering which two roots every point looked at (SPEC codes).  Wave 1 stamps what an insert may change BEFORE it changes it
+// (new roots in the re-projection; dev_stamp_dirty_roots: every touched root that is not a plain append) and says so
+// (f_decided); wave 0 then keeps its tile sums if no point looked at a stamped root - they were computed from data no insert
+// touched - and otherwise waits for the insert to finish (f_done) and evaluates the bucket's tiles again.  update(k + 1) therefore
+// sees exactly the sums of the sequential order: results are bit-identical to the per-bucket launches
+// (test_scan_resident_kernel_equals_per_bucket_launches).  Flags live in LDS; both waves sit on one CU, so workgroup-scope
+// fences order the global-memory traffic between them.  Measured per bucket before the pipeline (one workgroup doing both in
+// turn): predict 3.6 + tiles 3.4 + update 4.5 + snapshot 1.2 + re-projection 2.0 + insert 7.6 us = 23 us, the same as the per-bucket
+// launches (their floor was never the cost); with the two chains side by side the bucket costs the longer of them.
+// Host side: run_scan_resident().
+#define LK_RESIDENT_MAX 512   // largest bucket (points) the resident kernel takes (= LK_SMALL_MAX): its tiles run one after the other in wave 0
+}  // extern "C" (a kernel template follows)
+// LDS flags between the waves of the resident workgroup (macros on the __shared__ variables themselves: through a pointer parameter
+// the accesses became system-scope FLAT loads).  FLAG_WAIT: wave-uniform spin until the other side has posted `need`.
+#define FLAG_WAIT(flag, need)                                                                                               \
+    do {                                                                                                                    \
+        while (__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (need)) __builtin_amdgcn_s_sleep(1); \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                              \
+    } while (0)
+#define FLAG_POST(flag, value)                                                                                              \
+    do {                                                                                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* this wave's stores (global and LDS) are complete */        \
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&(flag), (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+    } while (0)
+// barrier among the LK_INS_WAVES insert waves only (a monotonic LDS counter; `phase` counts this wave's arrivals)
+#define LK_INS_WAVES 3
+#define TEAM_BARRIER(ctr, phase)                                                                                            \
+    do {                                                                                                                    \
+        ++(phase);                                                                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
+        while (__hip_atomic_load(&(ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < LK_INS_WAVES * (phase)) __builtin_amdgcn_s_sleep(1); \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                              \
+    } while (0)
+template <int MSG, bool XID>
+__global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
+    lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
+                          LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    __shared__ int f_post, f_decided, f_done;   // bucket index of: latest posterior snapshot / stamps final / insert complete
+    __shared__ int team_ctr;                    // arrivals at the insert team's barrier
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    LkFilter* f = &filters[0];
+    const int nbk = rag_nb(rg, 0);
+    if (nbk == 0) return;
+    const double* T = rag_t(rg, 0);
+    const unsigned long long* po = rag_pt_off(rg, 0);
+    if (tid == 0) f_post = -1, f_decided = -1, f_done = -1, team_ctr = 0;
+    __syncthreads();
+    if (wv >= 1) {
+        // ================================================================= insert team (waves 1 .. LK_INS_WAVES)
+        const int rank = wv - 1;
+        int phase = 0;
+        for (int b = 0; b < nbk; ++b) {
+            const unsigned long long base = po[b];
+            const int n = (int)(po[b + 1] - base);
+            LkMap m = map;
+            m.epoch = epoch0 + (unsigned int)b;
+            const LkFilter* sn = snap2 + (b & 1);
+            FLAG_WAIT(f_post, b);
+            if (rank == 0) dev_bucket_begin_wave(m);
+            TEAM_BARRIER(team_ctr, phase);
+            for (int i = rank * LK_WAVE + lane; i < n; i += LK_INS_WAVES * LK_WAVE) dev_reproject_point(m, pr, sn, pts + base, world ? world + 4 * base : nullptr, 1, i);
+            TEAM_BARRIER(team_ctr, phase);
+            const int n_touched = (int)__hip_atomic_load(&m.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rank == 0) {
+                if (n_touched > 0) dev_stamp_dirty_roots(m, pr, n_touched);
+                FLAG_POST(f_decided, b);
+            }
+            if (n_touched > 0) {
+                TEAM_BARRIER(team_ctr, phase);   // the stamping pass has read the roots' queues before the root pass resets them
+                dev_insert_root<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
+                TEAM_BARRIER(team_ctr, phase);
+                dev_insert_apply<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
+                TEAM_BARRIER(team_ctr, phase);
+                dev_insert_fallback<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
+            }
+            TEAM_BARRIER(team_ctr, phase);
+            if (rank == 0) FLAG_POST(f_done, b);
+        }
+        return;
+    }
+    // ===================================================================== filter wave
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+    if (lane < 36) sm.x[lane] = f->x[lane];
+    double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    unsigned long long n_effect = f->n_effect;
+    unsigned int n_updates = f->n_updates, n_buckets = f->n_buckets;
+    int last_N = f->last_N, updated = f->updated;
+    core_sync<true>();
+    unsigned int qi = 0, qn = 0;   // the scan's messages (KILO.cc:379-390: those stamped before the bucket come first)
+    if (MSG) qi = rg.imu_off[0], qn = rg.imu_off[1];
+    constexpr size_t mstride = MSG == 2 ? 33 : 7;
+    for (int b = 0; b < nbk;) {
+        const double tb_ = T[b];
+        const bool is_msg = MSG && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
+        const double t = is_msg ? rg.imu[mstride * (size_t)qi] : tb_;
+        wave_predict_core<true>(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
+        t_pred = t;
+        if (is_msg) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
+            const double* mm = rg.imu + mstride * (size_t)qi;
+            if (MSG == 2)
+                wave_kin_update_core<true>(sm, rows, mm, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
+            else
+                wave_imu_update_core<true>(sm, mm + 1, mm + 4, rg.acc_scale, rg.Rn, lane);
+            t_upd = t;  // KILO.cc:256 / :312
+            ++qi;
+            continue;
+        }
+        const unsigned long long base = po[b];
+        const int n = (int)(po[b + 1] - base);
+        BucketConst bc;   // load_bucket_const<false> from the LDS-resident state
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bc.R[i] = sm.x[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bc.p[i] = sm.x[9 + i];
+        {
+            const double* P = sm.P;
+            bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
+            bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
+        }
+        ResidualOut ro;
+        ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr;
+        ro.world = world ? world + 4 * base : nullptr;
+        ro.ids = ids + base;
+        // speculative pass (the insert of bucket b - 1, possibly the tail of b - 2, may be running beside it)
+        double totv = 0.0;  // tot[j] in lanes 0..31
+        for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
+            __builtin_amdgcn_wave_barrier();  // the previous tile's reads of the rows are complete
+            const double a = residual_tile<false, 0, XID, true, true>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
+            totv += (lane < 29) ? a : 0.0;
+        }
+        if (b > 0) {
+            FLAG_WAIT(f_decided, b - 1);   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
+            const unsigned int e_b = epoch0 + (unsigned int)b;
+            const unsigned int from = b >= 2 ? e_b - 2u : epoch0;
+            bool susp = false;
+            for (int i = lane; i < n; i += LK_WAVE) {
+                const int2 c = ro.ids[i];
+                susp = susp || spec_suspect(map, c.x, from) || spec_suspect(map, c.y, from);
+            }
+            if (__ballot(susp) != 0ull) {
+                FLAG_WAIT(f_done, b - 1);
+                if (lane == 0) atomicAdd(&map.counters[LK_CTR_SPEC_REDO], 1u);
+                totv = 0.0;
+                for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
+                    __builtin_amdgcn_wave_barrier();
+                    const double a = residual_tile<false, 0, XID, true, false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
+                    totv += (lane < 29) ? a : 0.0;
+                }
+            }
+        }
+        const int N = (int)(lane_bcast<28>(totv) + 0.5);
+        n_buckets += 1, last_N = N, updated = N > 0;
+        if (N > 0) {
+            n_updates += 1, n_effect += (unsigned long long)N;
+            t_upd = t;  // KILO.cc:212
+            wave_update_core<true>(sm, totv, N, lane);
+        }
+        core_sync<true>();
+        // the posterior for the insert (dev_snapshot_posterior's fields): the buffer of bucket b - 2 is free once that insert is done
+        if (b >= 2) FLAG_WAIT(f_done, b - 2);
+        {
+            LkFilter* sn = snap2 + (b & 1);
+            for (int e = lane; e < 180; e += LK_WAVE) sn->P[e] = sm.P[e];
+            if (lane < LK_STATE_DOUBLES) sn->x[lane] = sm.x[lane];
+            if (lane == 0) sn->updated = N > 0, sn->last_N = N;
+        }
+        FLAG_POST(f_post, b);
+        ++b;
+    }
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+    if (lane < 36) f->x[lane] = sm.x[lane];
+    if (lane == 0) {
+        f->last_update_t = t_upd, f->last_predict_t = t_pred;
+        f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
+    }
+}
+extern "C" {
+
 // ------------------------------------------------------------------ pipelined stream path
 // A bucket's insert (re-projection + root hashing, light / group / apply / fallback passes) only feeds the NEXT bucket's matching,
 // and only through the planes of the root voxels it refits, cuts or creates - with time buckets = azimuth sectors of a spinning
@@ -909,6 +1102,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         // waves per SIMD at ~200 VGPRs: 512 blocks x 4 waves is one resident round on 256 CUs), then the generic fallback for the few
         // groups that need it; all loops are grid-stride and read their work counts on the device
         int grid = std::min(std::max((n + 3) / 4, 1), 512);
+        static const bool small_insert = getenv("LEGKILO_SMALL_INSERT") == nullptr || atoi(getenv("LEGKILO_SMALL_INSERT")) != 0;
+        if (n <= LK_SMALL_MAX && small_insert) {   // small bucket: root pass + (in the last workgroup) apply + fallback as one launch
+            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_small_kernel, dim3(std::min(grid, 128)), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                        ins_filters, d_pts, n));
+            return LK_OK;
+        }
         LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                     ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
@@ -1559,10 +1758,109 @@ int lk_process_scan(lk_handle* h, const lk_point* pts, size_t n, double t_begin,
     return run_scan(h, pts, h->d_scan, n, t_begin, imus, n_imu, kins, n_kin, xyz_world_out, out);
 }
 
+// staging buffer of the ragged / resident tables (device copy + pinned host copy, grow-only); synchronises the stream: a previous
+// call's upload from the staging buffer must have completed before it is overwritten
+static int rag_reserve(lk_handle* h, size_t bytes) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (bytes <= h->rag_cap) return LK_OK;
+    if (h->d_rag) hipFree(h->d_rag), h->d_rag = nullptr;
+    if (h->h_rag) hipHostFree(h->h_rag), h->h_rag = nullptr;
+    h->rag_cap = 0;
+    HIPCHK(h, hipMalloc(&h->d_rag, bytes + bytes / 2));
+    HIPCHK(h, hipHostMalloc(&h->h_rag, bytes + bytes / 2, hipHostMallocDefault));
+    h->rag_cap = bytes + bytes / 2;
+    return LK_OK;
+}
+
+// The bucket loop of KILO::process for a scan of small buckets as ONE launch (lk_scan_stream_kernel).  bstart[k] / btime[k]: first
+// point and absolute time of bucket k (nb buckets, bstart[nb] = n); the messages are the scan's lk_imu or lk_kin_imu records.
+static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vector<unsigned long long>& bstart, const std::vector<double>& btime,
+                             const void* msgs, size_t n_msg, int msg_kind, float* d_world) {
+    const size_t nb = btime.size();
+    const size_t msg_bytes = msg_kind == 2 ? sizeof(lk_kin_imu) : sizeof(lk_imu);
+    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_im = o_t + 8 * nb, o_nb = o_im + msg_bytes * n_msg, o_io = o_nb + 8, bytes = o_io + 8;
+    int rc = rag_reserve(h, bytes);
+    if (rc) return rc;
+    unsigned char* stage = static_cast<unsigned char*>(h->h_rag);
+    memcpy(stage + o_po, bstart.data(), 8 * (nb + 1));
+    memcpy(stage + o_t, btime.data(), 8 * nb);
+    if (n_msg) memcpy(stage + o_im, msgs, msg_bytes * n_msg);
+    const unsigned int nbu[2] = {(unsigned int)nb, 0u}, io[2] = {0u, (unsigned int)n_msg};
+    memcpy(stage + o_nb, nbu, 8);
+    memcpy(stage + o_io, io, 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
+    LkRagged rg;
+    rg.pt_off = reinterpret_cast<const unsigned long long*>(dr + o_po);
+    rg.t = reinterpret_cast<const double*>(dr + o_t);
+    rg.nb = reinterpret_cast<const unsigned int*>(dr + o_nb);
+    rg.ldb = (int)nb;
+    rg.bstart = nullptr;
+    rg.imu_off = reinterpret_cast<const unsigned int*>(dr + o_io);
+    rg.imu = reinterpret_cast<const double*>(dr + o_im);
+    rg.msg_stride = (int)(msg_bytes / sizeof(double));
+    rg.kin_noise = h->cfg.kin_meas_noise;
+    rg.q_diag = h->q_diag ? 1 : 0;
+    rg.acc_scale = h->cfg.gravity / h->acc_norm;
+    imu_noise(h->cfg, rg.Rn);
+    h->grid_valid = false;   // the map changes
+    static const bool xid_en = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const bool xid = h->pr.ext_identity && xid_en;
+    if (h->epoch + (unsigned int)nb + 16u < h->epoch || h->epoch >= 0xf0000000u) {   // stamps are plain unsigned numbers: start over long before they wrap
+        HIPCHK(h, hipMemsetAsync(h->map.dirty, 0, sizeof(unsigned int) * (size_t)h->map.max_nodes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->map.newroot, 0, sizeof(unsigned int) * (size_t)(LK_NEWROOT_MASK + 1), h->stream));
+        h->epoch = 16, h->spec_base = 17;
+    }
+    const unsigned int epoch0 = h->epoch + 1u;
+    h->epoch += (unsigned int)nb;
+    h->spec_base = h->epoch + 1u;
+    void (*k)(LkMap, LkParams, LkFilter*, const lk_point*, LkRagged, const double*, LkFilter*, float*, int2*, unsigned int) =
+        msg_kind == 2 ? (xid ? lk_scan_stream_kernel<2, true> : lk_scan_stream_kernel<2, false>)
+      : msg_kind == 1 ? (xid ? lk_scan_stream_kernel<1, true> : lk_scan_stream_kernel<1, false>)
+                      : (xid ? lk_scan_stream_kernel<0, true> : lk_scan_stream_kernel<0, false>);
+    LAUNCH(h, "scan_stream", hipLaunchKernelGGL(k, dim3(1), dim3((1 + LK_INS_WAVES) * LK_WAVE), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
+                                                h->d_ids, epoch0));
+    return LK_OK;
+}
+// a scan is taken by the resident kernel when all its buckets are small (LEGKILO_RESIDENT=0: always per-bucket launches)
+static bool resident_enabled(const lk_handle* h) { return h->resident_enable && !h->profiling && !h->spec_enable; }
+
 static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n, double t_begin, const lk_imu* imus,
                     size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out) {
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
+    if (resident_enabled(h)) {
+        std::vector<unsigned long long> bstart;
+        std::vector<double> btime;
+        size_t biggest = 0;
+        for (size_t i = 0; i < n;) {   // runs of equal curvature = buckets (KILO.cc:375-378)
+            size_t j = i + 1;
+            while (j < n && pts[i].curvature == pts[j].curvature) j++;
+            bstart.push_back(i);
+            btime.push_back(t_begin + pts[i].curvature);
+            biggest = std::max(biggest, j - i);
+            i = j;
+        }
+        bstart.push_back(n);
+        if (biggest <= LK_RESIDENT_MAX) {
+            rc = run_scan_resident(h, d_pts, bstart, btime, n_kin ? (const void*)kins : (const void*)imus, n_kin ? n_kin : n_imu, n_kin ? 2 : (n_imu ? 1 : 0),
+                                   xyz_world_out ? h->d_world : nullptr);
+            if (rc) return rc;
+            std::vector<float> w;
+            if (xyz_world_out) {
+                w.resize(4 * n);
+                HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+            }
+            lk_pose pose;
+            if ((rc = fetch_poses(h, &pose, 1))) return rc;
+            if ((rc = check_map_errors(h))) return rc;
+            if (xyz_world_out)
+                for (size_t i = 0; i < n; ++i)
+                    for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+            if (out) *out = pose;
+            return LK_OK;
+        }
+    }
     size_t qi = 0, qk = 0;
     size_t idx_i = 0;
     bool pre_predicted = false;
@@ -1617,6 +1915,26 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
+    if (resident_enabled(h)) {
+        std::vector<unsigned long long> bstart;
+        std::vector<double> btime;
+        uint32_t biggest = 0;
+        for (size_t b = 0; b < n_buckets; ++b) {
+            if (bucket_off[b + 1] <= bucket_off[b]) continue;
+            bstart.push_back(bucket_off[b]);
+            btime.push_back(t_begin + bucket_dt[b]);
+            biggest = std::max(biggest, bucket_off[b + 1] - bucket_off[b]);
+        }
+        bstart.push_back(bucket_off[n_buckets]);
+        if (!btime.empty() && biggest <= LK_RESIDENT_MAX) {
+            if ((rc = run_scan_resident(h, d_pts, bstart, btime, nullptr, 0, 0, nullptr))) return rc;
+            lk_pose pose;
+            if ((rc = fetch_poses(h, &pose, 1))) return rc;
+            if ((rc = check_map_errors(h))) return rc;
+            if (out) *out = pose;
+            return LK_OK;
+        }
+    }
     bool pre_predicted = false;
     for (size_t b = 0; b < n_buckets; ++b) {
         int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
@@ -2388,6 +2706,11 @@ int lk_synchronize(lk_handle* h) {
 int lk_stream_pipeline(lk_handle* h, int on) {
     CHECK_H(h);   // joins the inserts in flight
     h->spec_enable = on != 0;
+    return LK_OK;
+}
+int lk_stream_resident(lk_handle* h, int on) {
+    CHECK_H(h);
+    h->resident_enable = on != 0;
     return LK_OK;
 }
 int lk_stream_stats(lk_handle* h, uint64_t* out4) {

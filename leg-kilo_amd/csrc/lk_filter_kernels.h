@@ -414,19 +414,33 @@ struct WaveSmem {
 };
 static_assert(sizeof(WaveSmem) == 7680, "one residual workgroup's worth of LDS");
 
+// Barrier of the one-wave filter cores.  They were written for single-wave workgroups, where __syncthreads() is the wave's own
+// barrier; MW = true lets ONE wave of a larger workgroup run them (the scan-resident stream kernel, legkilo_hip.hip): the LDS
+// traffic of one wave is ordered by a workgroup-scope fence + wave barrier, without involving the other waves.
+template <bool MW>
+__device__ __forceinline__ void core_sync() {
+    if (MW) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
 __device__ __forceinline__ int tri6(int i, int j) {  // index of (i,j) in the packed upper triangle of a 6x6
     int r = i < j ? i : j, c = i < j ? j : i;
     return r * 6 - r * (r - 1) / 2 + (c - r);
 }
 
 // The N > 0 branch of updateByPoints on LDS-resident state: tot[j] in lanes 0..31 of totv (see dev_update_wave).
+template <bool MW = false>
 __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int N, int lane) {
     if (N == 1) {  // eskf.cc:98-104
         double r = lane_bcast_u(totv, 27);
         double sc = r / (r + 0.0001);
         if (lane < 27) totv *= sc;
     }
-    __syncthreads();  // sm.P, sm.x loaded
+    core_sync<MW>();  // sm.P, sm.x loaded
     // -- augmented column of this lane: lanes 0..5 S[:,lane] = I + (A P)[:,lane]; lanes 6..35 G[:,lane-6]; lane 36 b
     const int pc = lane < 6 ? lane : (lane < 36 ? lane - 6 : 29);
     double col[6];
@@ -498,12 +512,12 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
                 for (int m = 0; m < 6; ++m) s += sm.P[i * 30 + m] * X[m];
                 nv[r] = sm.P[i * 30 + jc] - s;
             }
-            __syncthreads();
+            core_sync<MW>();
             if (lane < 60) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) sm.P[(i0 + r0 + r) * 30 + jc] = nv[r];
             }
-            __syncthreads();
+            core_sync<MW>();
         }
     }
     // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
@@ -522,6 +536,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
 // (ba + imu_a) and (bw + imu_w), i.e. P H^T = P[:,9:15] + P[:,18:24].  Same one-column-per-lane Gauss-Jordan as
 // wave_update_core (kept as a separate copy: that one is register-tuned for lk_update_wave_kernel's 96-VGPR budget);
 // sums in the order lk_imu_kernel takes them.  acc / gyr / Rn6 are wave-uniform.
+template <bool MW = false>
 __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double* acc, const double* gyr, double acc_scale,
                                                      const double* Rn6, int lane) {
     const double* x = sm.x;
@@ -596,12 +611,12 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
                 for (int m = 0; m < 6; ++m) s += pht(i, m) * X[m];
                 nv[r] = sm.P[i * 30 + jc] - s;
             }
-            __syncthreads();
+            core_sync<MW>();
             if (lane < 60) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) sm.P[(i0 + r0 + r) * 30 + jc] = nv[r];
             }
-            __syncthreads();
+            core_sync<MW>();
         }
     }
     const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
@@ -613,7 +628,7 @@ __device__ __forceinline__ void wave_imu_update_core(WaveSmem& sm, const double*
         for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
     }
     if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
-    __syncthreads();
+    core_sync<MW>();
 }
 
 // updateByKinImu (eskf.cc:137-145) with the rows of predictUpdateKinImu (KILO.cc:267-309) on LDS-resident, already propagated
@@ -633,6 +648,7 @@ struct KinScratch {
 };
 static_assert(sizeof(KinScratch) <= 64 * 15 * sizeof(double), "KinScratch must fit the residual rows' LDS region");
 
+template <bool MW = false>
 __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scratch, const double* __restrict__ msg, double acc_scale,
                                                      const double* Rn6, double kin_noise, int lane) {
     KinScratch& ks = *reinterpret_cast<KinScratch*>(scratch);
@@ -667,7 +683,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
         ks.z[r0 + 0] = -x[12] - Rw.x, ks.z[r0 + 1] = -x[13] - Rw.y, ks.z[r0 + 2] = -x[14] - Rw.z;
         ks.rd[r0 + 0] = kin_noise, ks.rd[r0 + 1] = kin_noise, ks.rd[r0 + 2] = kin_noise;
     }
-    __syncthreads();
+    core_sync<MW>();
     // -- P H^T, entry (i, m): dot of row i of P with row m of H over H's non-zero columns, ascending
     for (int e = lane; e < 30 * 18; e += LK_WAVE) {
         const int i = e / 18, m = e % 18;
@@ -691,7 +707,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
         }
         ks.pht[i * 18 + m] = s;
     }
-    __syncthreads();
+    core_sync<MW>();
     // -- this lane's column of [S | H P | z]
     double col[18];
     {
@@ -738,7 +754,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
 #pragma unroll
                 for (int i = 0; i < 18; ++i) ks.colk[i] = col[i];
             }
-            __syncthreads();
+            core_sync<MW>();
             int p = k;
             double best = fabs(ks.colk[k]);
 #pragma unroll
@@ -759,7 +775,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
                 const int src = lane == k ? p : (lane == p ? k : lane);
                 ks.fac[lane] = lane == k ? 0.0 : ks.colk[src] / ks.colk[p];
             }
-            __syncthreads();
+            core_sync<MW>();
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 if (i != k && i < M) col[i] -= ks.fac[i] * col[k];
@@ -797,7 +813,7 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
             }
         }
     }
-    __syncthreads();
+    core_sync<MW>();
     const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0) {
         double E[9], Rn[9];
@@ -807,10 +823,11 @@ __device__ __forceinline__ void wave_kin_update_core(WaveSmem& sm, double* scrat
         for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
     }
     if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
-    __syncthreads();
+    core_sync<MW>();
 }
 
 // ESKF::predict(dt_cov, false, true) then predict(dt, true, false) (KILO.cc:111-115) on LDS-resident state.
+template <bool MW = false>
 __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __restrict__ Q, double dt_cov, double dt, int lane,
                                                   const bool q_diag = false) {
     // The two rotations of a predict - Exp(-dt_cov w) for Fx (getFx, eskf.cc:74) and Exp(dt w) for the state (operator+=,
@@ -839,7 +856,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
             mat3_mul(x, E, Rn);
         }
     }
-    __syncthreads();
+    core_sync<MW>();
     const double* E = sm.fx;
     const double* B60 = sm.fx + 9;
     // Fx differs from I in three row blocks of different shape (eskf.cc:72-81): rows 0..2 = [E | dt I at col 21], rows 3..5 =
@@ -878,14 +895,14 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
                 nb[4 + q] = s;
             }
         }
-        __syncthreads();
+        core_sync<MW>();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = lane + 64 * q;
             if (e < 90) sm.P[e] = nb[q], sm.P[90 + e] = nb[2 + q], sm.P[180 + e] = nb[4 + q];
         }
     }
-    __syncthreads();
+    core_sync<MW>();
     if (!(LK_X_P & 2)) {  // columns 0..8 of B * Fx^T, in place: the same three shapes, 30 rows x 3 columns each
         double nc[6];
 #pragma unroll
@@ -919,7 +936,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
                 nc[4 + q] = s;
             }
         }
-        __syncthreads();
+        core_sync<MW>();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = lane + 64 * q;
@@ -929,7 +946,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
             }
         }
     }
-    __syncthreads();
+    core_sync<MW>();
     const double dt2 = dt_cov * dt_cov;
     if (LK_X_P & 4) {
     } else if (q_diag) {   // Q of initProcessCovQ (eskf.cc:47-62) is diagonal: the other 870 terms are + dt^2 * 0
@@ -942,7 +959,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
         for (int i = 0; i < 9; ++i) x[i] = Rn[i];
         for (int i = 0; i < 6; ++i) x[9 + i] += dpv[i];
     }
-    __syncthreads();
+    core_sync<MW>();
 }
 
 __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const double* __restrict__ part, int nblk, double t,

@@ -905,6 +905,15 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
     }
 }
 
+// Does a touched root only need its m queued points appended (no plane of its subtree can change in this bucket)?  An un-initialised
+// root that stays at <= layer_init_num points, or a plane root that reaches neither its 6th new point (refit, voxel_map.cc:195) nor
+// max_points_num (freeze, :199).
+__device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigned int st, unsigned int pf, int npts, int newp) {
+    if (m > 8) return false;
+    if (!(st & LK_NODE_INIT_OCTO)) return (npts + m <= pr.layer_init_num[0]) && (npts + m <= LK_BLOCK_PTS);
+    if ((pf & LK_PLANE_IS_PLANE) && (st & LK_NODE_UPDATE_ENABLE)) return (newp + m <= 5) && (npts + m < pr.max_points_num);
+    return false;
+}
 // One wave per touched root (see the comment block above).
 template <bool FROM_PV>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
@@ -925,13 +934,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         const int slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
         if (lane == 0) nd->pad_[0] = 0, nd->list_head = -1;   // the root's bucket-local queue is consumed
         // ---- light root: append only (one lane per point, input order = ascending index)
-        bool light = false;
-        if (!FROM_PV && m <= 8) {
-            if (!(rst & LK_NODE_INIT_OCTO))
-                light = (rnpts + m <= pr.layer_init_num[0]) && (rnpts + m <= LK_BLOCK_PTS);
-            else if ((rpf & LK_PLANE_IS_PLANE) && (rst & LK_NODE_UPDATE_ENABLE))
-                light = (rnewp + m <= 5) && (rnpts + m < pr.max_points_num);
-        }
+        const bool light = !FROM_PV && root_is_light(pr, m, rst, rpf, rnpts, rnewp);
         if (light) {
             const int idx = (lane < m) ? slot_idx : 0x7fffffff;
             int rank = 0;
@@ -1196,6 +1199,29 @@ __global__ void __launch_bounds__(LK_MB)
                           const lk_pt_rec* __restrict__ pv, int n) {
     dev_insert_root<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
+// Small buckets (the reference's 2 ms time bins hold tens of points): the whole ordered insert as ONE launch.  Every workgroup runs
+// the root pass over its share of the touched roots; the workgroup that finishes LAST (a ticket) then applies whatever leaf groups
+// the roots with several groups emitted and runs the generic fallback items - both usually none.  Two launches of ~5 us each saved
+// per bucket on a dependent chain of ~25 us; not for large buckets, where hundreds of emitted groups want hundreds of workgroups.
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_small_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, int n) {
+    __shared__ int is_last;
+    dev_insert_root<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(&map.spec[LK_SPEC_TICKET2], 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) map.spec[LK_SPEC_TICKET2] = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();   // acquire: the other workgroups' descriptors, items and tree updates
+    dev_insert_apply<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
+    __threadfence();
+    __syncthreads();
+    dev_insert_fallback<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
+}
 template <bool FROM_PV>
 __global__ void __launch_bounds__(LK_MB)
     lk_insert_apply_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
@@ -1406,6 +1432,43 @@ __device__ __forceinline__ void dev_bucket_begin(const LkMap& map) {
     }
 }
 __global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) { dev_bucket_begin(map); }
+// dev_bucket_begin for ONE WAVE of a larger workgroup (the scan-resident stream kernel's insert wave): no workgroup barrier
+__device__ __forceinline__ void dev_bucket_begin_wave(const LkMap& map) {
+    const int lane = threadIdx.x & 63;
+    int base = 0, nfreed = 0;
+    if (lane == 0) {
+        const int fc = (int)map.counters[LK_CTR_FREE];
+        base = fc > 0 ? fc : 0;
+        const unsigned int nf = map.counters[LK_CTR_FREED];
+        nfreed = (int)(nf < map.max_blocks ? nf : map.max_blocks);
+        if (base + nfreed > (int)map.max_blocks) nfreed = (int)map.max_blocks - base;
+        map.counters[LK_CTR_TOUCHED] = 0;
+        map.counters[LK_CTR_SCRATCH] = 0;
+        map.counters[LK_CTR_HEAVY] = 0;
+        map.counters[LK_CTR_GROUPS] = 0;
+        map.counters[LK_CTR_GIDX] = 0;
+        map.counters[LK_CTR_FALLBACK] = 0;
+    }
+    base = bcast0(base), nfreed = bcast0(nfreed);
+    for (int i = lane; i < nfreed; i += LK_WAVE) map.free_list[base + i] = map.freed_next[i];
+    wave_fence();
+    if (lane == 0) {
+        map.counters[LK_CTR_FREE] = (unsigned int)(base + nfreed);
+        map.counters[LK_CTR_FREED] = 0;
+    }
+    wave_fence();
+}
+// Stamp, BEFORE any of them is processed, every touched root whose planes may change in this bucket (the rule of dev_insert_root):
+// one lane per root.  After this pass LkMap::dirty is final for the bucket - what a speculative residual pass running beside the
+// insert needs to know to decide whether it has to wait for it (scan-resident stream kernel).
+__device__ __forceinline__ void dev_stamp_dirty_roots(const LkMap& map, const LkParams& pr, int n_touched) {
+    const int lane = threadIdx.x & 63;
+    for (int t = lane; t < n_touched; t += LK_WAVE) {
+        const int root = map.touched[t];
+        const lk_node_rec* nd = &map.nodes[root];
+        if (!root_is_light(pr, (int)nd->pad_[0], nd->state, map.planes[root].flags, nd->npts, nd->new_points)) map.dirty[root] = map.epoch;
+    }
+}
 
 // ------------------------------------------------------------------ pool initialisation
 __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned int n_hash) {

@@ -575,6 +575,42 @@ def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
     o.close()
 
 
+@pytest.mark.parametrize("use_kin", [False, True])
+def test_scan_resident_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_lib, use_kin):
+    """The scan-resident stream kernel (one launch per scan: the whole bucket loop with its messages and the map insert in one
+    resident workgroup, lk_scan_stream_kernel) against the per-bucket launches of the same library (lk_stream_resident(0)) on
+    config-1 scans with IMU (only_imu_use) or kinematic + IMU (leg fusion) messages, over a young map that is still growing (roots
+    created, planes initialised / refitted / cut while the scans run): state, covariance, re-projected cloud and map bit for bit on
+    every scan, and both equal to the oracle (counts exact, state 1e-7)."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=not use_kin)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    g_pb = hip_lib.LegKiloHip(scene.cfg())
+    g_pb.stream_resident(False)
+    t0 = 21.0
+    for obj in (o, g, g_pb):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0)
+    for k in range(4):
+        tb = t0 + 0.1 * k
+        ds = scenes.vlp_scan_input(scene, tb, k)
+        kw = dict(kins=synth.kin_stream(scene.traj, tb, tb + 0.1, scene.P, seed=3003 + k)) if use_kin else \
+            dict(imus=synth.imu_stream(scene.traj, tb, tb + 0.1, seed=3003 + k))
+        po, _ = o.process_scan(ds, tb, **kw)
+        pg, wg = g.process_scan(ds, tb, want_world=True, **kw)
+        pp, wp = g_pb.process_scan(ds, tb, want_world=True, **kw)
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (pg.n_buckets, pg.n_updates, int(pg.n_effect)) == \
+            (pp.n_buckets, pp.n_updates, int(pp.n_effect)), (k, po.n_effect, pg.n_effect, pp.n_effect)
+        assert po.n_buckets > 100
+        (xo, _), (xg, Pg), (xp, Pp) = o.get_state(), g.get_state(), g_pb.get_state()
+        assert np.abs(xo - xg).max() < 1e-7, (k, np.abs(xo - xg).max())
+        assert np.array_equal(xg, xp) and np.array_equal(Pg, Pp), (k, np.abs(xg - xp).max())
+        assert np.array_equal(wg, wp)
+    scenes.maps_identical(g.map_export(), g_pb.map_export())
+    scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+    for obj in (g, g_pb, o):
+        obj.close()
+
+
 def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
     """The pipelined stream path (insert of bucket k on its own stream beside predict + residual of bucket k+1, verify pass,
     legkilo_hip.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
