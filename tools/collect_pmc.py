@@ -10,8 +10,10 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*"))):
         continue
     c = sqlite3.connect(f).cursor()
     acc = {}
-    for name, gy, cn, val, dur in c.execute("select kernel_name, grid_size_y, counter_name, value, duration from counters_collection"):
-        if "lk_residual_kernel<false" in name and gy > 1:
+    rows = list(c.execute("select kernel_name, grid_size_y, counter_name, value, duration from counters_collection"))
+    gy_max = max([gy for name, gy, _, _, _ in rows if "lk_residual_kernel<false" in name] or [0])   # the full batch only (bench.py also times 128-slot shards)
+    for name, gy, cn, val, dur in rows:
+        if "lk_residual_kernel<false" in name and gy > 1 and gy == gy_max:
             a = acc.setdefault(cn, [0, 0.0, 0.0])
             a[0] += 1; a[1] += val; a[2] += dur
     for cn, (n, v, du) in acc.items():
