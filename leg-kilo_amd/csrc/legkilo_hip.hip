@@ -789,27 +789,42 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 #define LK_RESIDENT_MAX 512   // largest bucket (points) the resident kernel takes (= LK_SMALL_MAX): its tiles run one after the other in wave 0
 }  // extern "C" (a kernel template follows)
 // LDS flags between the waves of the resident workgroup (macros on the __shared__ variables themselves: through a pointer parameter
-// the accesses became system-scope FLAT loads).  FLAG_WAIT: wave-uniform spin until the other side has posted `need`.
-#define FLAG_WAIT(flag, need)                                                                                               \
-    do {                                                                                                                    \
-        while (__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (need)) __builtin_amdgcn_s_sleep(1); \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                              \
-    } while (0)
+// the accesses became system-scope FLAT loads).  FLAG_WAIT: wave-uniform spin until the other side has posted `need`; evaluates to
+// false when the wait was given up - another wave has raised f_abort, or this one does after LK_RESIDENT_TIMEOUT ticks of the 100 MHz
+// clock (a device fault in the other role must fail the call, never hang the GPU): the caller leaves its bucket loop.
+#define LK_RESIDENT_TIMEOUT 200000000ull   // 2 s
+#define LK_SPIN_UNTIL(cond)                                                                                                  \
+    ([&]() -> bool {                                                                                                          \
+        unsigned long long t0_ = 0;                                                                                           \
+        unsigned int spins_ = 0;                                                                                              \
+        while (!(cond)) {                                                                                                     \
+            if (__hip_atomic_load(&f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;               \
+            __builtin_amdgcn_s_sleep(1);                                                                                      \
+            if ((++spins_ & 1023u) == 0u) {                                                                                   \
+                const unsigned long long now_ = wall_clock64();                                                               \
+                if (t0_ == 0) t0_ = now_;                                                                                     \
+                else if (now_ - t0_ > LK_RESIDENT_TIMEOUT) {                                                                  \
+                    __hip_atomic_store(&f_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                          \
+                    if ((threadIdx.x & 63) == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SPEC_TIMEOUT);                      \
+                    return false;                                                                                             \
+                }                                                                                                             \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                                \
+        return true;                                                                                                          \
+    }())
+#define FLAG_WAIT(flag, need) LK_SPIN_UNTIL(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (need))
 #define FLAG_POST(flag, value)                                                                                              \
     do {                                                                                                                    \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* this wave's stores (global and LDS) are complete */        \
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&(flag), (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
     } while (0)
-// barrier among the LK_INS_WAVES insert waves only (a monotonic LDS counter; `phase` counts this wave's arrivals)
+// barrier among the LK_INS_WAVES insert waves only (a monotonic LDS counter; `phase` counts this wave's arrivals); false = given up
 #define LK_INS_WAVES 3
 #define TEAM_BARRIER(ctr, phase)                                                                                            \
-    do {                                                                                                                    \
-        ++(phase);                                                                                                          \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
-        while (__hip_atomic_load(&(ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < LK_INS_WAVES * (phase)) __builtin_amdgcn_s_sleep(1); \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                              \
-    } while (0)
+    (++(phase), __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"),                                                       \
+     (((threadIdx.x & 63) == 0) ? (void)__hip_atomic_fetch_add(&(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (void)0), \
+     LK_SPIN_UNTIL(__hip_atomic_load(&(ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LK_INS_WAVES * (phase)))
 template <int MSG, bool XID>
 __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
@@ -818,13 +833,14 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     __shared__ double rows[64 * LK_ROW2];
     __shared__ int f_post, f_decided, f_done;   // bucket index of: latest posterior snapshot / stamps final / insert complete
     __shared__ int team_ctr;                    // arrivals at the insert team's barrier
+    __shared__ int f_abort;                     // a wait was given up: every role leaves its loop
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LkFilter* f = &filters[0];
     const int nbk = rag_nb(rg, 0);
     if (nbk == 0) return;
     const double* T = rag_t(rg, 0);
     const unsigned long long* po = rag_pt_off(rg, 0);
-    if (tid == 0) f_post = -1, f_decided = -1, f_done = -1, team_ctr = 0;
+    if (tid == 0) f_post = -1, f_decided = -1, f_done = -1, team_ctr = 0, f_abort = 0;
     __syncthreads();
     if (wv >= 1) {
         // ================================================================= insert team (waves 1 .. LK_INS_WAVES)
@@ -836,25 +852,25 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             LkMap m = map;
             m.epoch = epoch0 + (unsigned int)b;
             const LkFilter* sn = snap2 + (b & 1);
-            FLAG_WAIT(f_post, b);
+            if (!FLAG_WAIT(f_post, b)) break;
             if (rank == 0) dev_bucket_begin_wave(m);
-            TEAM_BARRIER(team_ctr, phase);
+            if (!TEAM_BARRIER(team_ctr, phase)) break;
             for (int i = rank * LK_WAVE + lane; i < n; i += LK_INS_WAVES * LK_WAVE) dev_reproject_point(m, pr, sn, pts + base, world ? world + 4 * base : nullptr, 1, i);
-            TEAM_BARRIER(team_ctr, phase);
+            if (!TEAM_BARRIER(team_ctr, phase)) break;
             const int n_touched = (int)__hip_atomic_load(&m.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (rank == 0) {
                 if (n_touched > 0) dev_stamp_dirty_roots(m, pr, n_touched);
                 FLAG_POST(f_decided, b);
             }
             if (n_touched > 0) {
-                TEAM_BARRIER(team_ctr, phase);   // the stamping pass has read the roots' queues before the root pass resets them
+                if (!TEAM_BARRIER(team_ctr, phase)) break;   // the stamping pass has read the roots' queues before the root pass resets them
                 dev_insert_root<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
-                TEAM_BARRIER(team_ctr, phase);
+                if (!TEAM_BARRIER(team_ctr, phase)) break;
                 dev_insert_apply<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
-                TEAM_BARRIER(team_ctr, phase);
+                if (!TEAM_BARRIER(team_ctr, phase)) break;
                 dev_insert_fallback<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
             }
-            TEAM_BARRIER(team_ctr, phase);
+            if (!TEAM_BARRIER(team_ctr, phase)) break;
             if (rank == 0) FLAG_POST(f_done, b);
         }
         return;
@@ -910,7 +926,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             totv += (lane < 29) ? a : 0.0;
         }
         if (b > 0) {
-            FLAG_WAIT(f_decided, b - 1);   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
+            if (!FLAG_WAIT(f_decided, b - 1)) break;   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
             const unsigned int e_b = epoch0 + (unsigned int)b;
             const unsigned int from = b >= 2 ? e_b - 2u : epoch0;
             bool susp = false;
@@ -919,7 +935,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
                 susp = susp || spec_suspect(map, c.x, from) || spec_suspect(map, c.y, from);
             }
             if (__ballot(susp) != 0ull) {
-                FLAG_WAIT(f_done, b - 1);
+                if (!FLAG_WAIT(f_done, b - 1)) break;
                 if (lane == 0) atomicAdd(&map.counters[LK_CTR_SPEC_REDO], 1u);
                 totv = 0.0;
                 for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
@@ -938,7 +954,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         }
         core_sync<true>();
         // the posterior for the insert (dev_snapshot_posterior's fields): the buffer of bucket b - 2 is free once that insert is done
-        if (b >= 2) FLAG_WAIT(f_done, b - 2);
+        if (b >= 2 && !FLAG_WAIT(f_done, b - 2)) break;
         {
             LkFilter* sn = snap2 + (b & 1);
             for (int e = lane; e < 180; e += LK_WAVE) sn->P[e] = sm.P[e];
