@@ -919,12 +919,16 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         ro.world = world ? world + 4 * base : nullptr;
         ro.ids = ids + base;
         // speculative pass (the insert of bucket b - 1, possibly the tail of b - 2, may be running beside it)
-        double totv = 0.0;  // tot[j] in lanes 0..31
+        // A bucket's tile sums are combined in the order lk_small_bucket_kernel combines them (its four waves take the tiles round
+        // robin, then the wave sums are added in wave order): the two paths give the same bits for any bucket size.
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
             __builtin_amdgcn_wave_barrier();  // the previous tile's reads of the rows are complete
             const double a = residual_tile<false, 0, XID, true, true>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
-            totv += (lane < 29) ? a : 0.0;
+            const int w4 = (i0 >> 6) & 3;
+            if (w4 == 0) a0 += a; else if (w4 == 1) a1 += a; else if (w4 == 2) a2 += a; else a3 += a;
         }
+        double totv = (lane < 29) ? (((0.0 + a0) + a1) + a2) + a3 : 0.0;  // tot[j] in lanes 0..31
         if (b > 0) {
             if (!FLAG_WAIT(f_decided, b - 1)) break;   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
             const unsigned int e_b = epoch0 + (unsigned int)b;
@@ -937,12 +941,14 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (__ballot(susp) != 0ull) {
                 if (!FLAG_WAIT(f_done, b - 1)) break;
                 if (lane == 0) atomicAdd(&map.counters[LK_CTR_SPEC_REDO], 1u);
-                totv = 0.0;
+                a0 = a1 = a2 = a3 = 0.0;
                 for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
                     __builtin_amdgcn_wave_barrier();
                     const double a = residual_tile<false, 0, XID, true, false>(map, pr, bc, reinterpret_cast<const float4*>(pts + base), i0 + lane, n, rows, lane, ro, (size_t)0);
-                    totv += (lane < 29) ? a : 0.0;
+                    const int w4 = (i0 >> 6) & 3;
+                    if (w4 == 0) a0 += a; else if (w4 == 1) a1 += a; else if (w4 == 2) a2 += a; else a3 += a;
                 }
+                totv = (lane < 29) ? (((0.0 + a0) + a1) + a2) + a3 : 0.0;
             }
         }
         const int N = (int)(lane_bcast<28>(totv) + 0.5);

@@ -611,6 +611,47 @@ def test_scan_resident_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_
         obj.close()
 
 
+def test_scan_resident_kernel_edge_buckets(scene, oracle_lib, hip_lib):
+    """The scan-resident kernel on bucket shapes a real scan rarely has: 1, 2, 63, 64, 65, 257, 300 and 512 points (one to eight
+    tiles evaluated one after the other by the filter wave, re-evaluated together on a conflict), IMU messages before the first
+    bucket, between buckets and after the last one, on a map young enough that most buckets insert: bit-identical to the per-bucket
+    launches, counts identical to the oracle, state 1e-7."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    g_pb = hip_lib.LegKiloHip(scene.cfg())
+    g_pb.stream_resident(False)
+    t0 = 31.0
+    for obj in (o, g, g_pb):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0)
+    sizes = [1, 63, 2, 64, 65, 257, 1, 300, 512, 7]
+    for k in range(3):
+        tb = t0 + 0.1 * k
+        src = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=sum(sizes), n_buckets=1, seed_scan=7300 + k, seed_noise=7400 + k)
+        pts = src.copy()
+        curv = np.concatenate([np.full(n_, np.float32(0.002 * (i + 1))) for i, n_ in enumerate(sizes)])
+        pts["curvature"] = curv
+        imus = synth.imu_stream(scene.traj, tb - 0.004, tb + 0.1, seed=5003 + k)   # some stamped before the first bucket, some after the last
+        po, _ = o.process_scan(pts, tb, imus=imus)
+        pg, wg = g.process_scan(pts, tb, imus=imus, want_world=True)
+        pp, wp = g_pb.process_scan(pts, tb, imus=imus, want_world=True)
+        assert po.n_buckets == len(sizes)
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (pg.n_buckets, pg.n_updates, int(pg.n_effect)) == \
+            (pp.n_buckets, pp.n_updates, int(pp.n_effect)), (k, po.n_effect, pg.n_effect, pp.n_effect)
+        (xo, _), (xg, Pg), (xp, Pp) = o.get_state(), g.get_state(), g_pb.get_state()
+        assert np.abs(xo - xg).max() < 1e-7, (k, np.abs(xo - xg).max())
+        assert np.array_equal(xg, xp) and np.array_equal(Pg, Pp) and np.array_equal(wg, wp), k
+    scenes.maps_identical(g.map_export(), g_pb.map_export())
+    # a one-bucket, one-point scan
+    one = src[:1].copy()
+    one["curvature"] = 0.0
+    for obj in (g, g_pb):
+        obj.process_scan(one, t0 + 0.5)
+    assert np.array_equal(g.get_state()[0], g_pb.get_state()[0])
+    for obj in (g, g_pb, o):
+        obj.close()
+
+
 def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
     """The pipelined stream path (insert of bucket k on its own stream beside predict + residual of bucket k+1, verify pass,
     legkilo_hip.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
