@@ -2766,10 +2766,43 @@ int lk_stream_stats(lk_handle* h, uint64_t* out4) {
         const char* names[8] = {"desc+node", "points", "simulate", "stores", "eigen", "plane_var", "commit", "tail"};
         fprintf(stderr, "[ins] %llu groups, %llu fitted; per group (us):", hb[15], hb[14]);
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f;", names[k], (double)hb[k] / (double)(hb[15] ? hb[15] : 1) * 0.01);
+        fprintf(stderr, " block-load wait %.2f;", (double)hb[8] / (double)(hb[15] ? hb[15] : 1) * 0.01);
+        { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(lk_ins_dbg), z, sizeof(z)); }
         fprintf(stderr, "\n[ins] plane_var: %.0f shader cycles and %.2f us per fit -> %.2f GHz", (double)hb[12] / (double)(hb[14] ? hb[14] : 1),
                 (double)hb[13] / (double)(hb[14] ? hb[14] : 1) * 0.01, (double)hb[12] / ((double)hb[13] * 10.0 + 1e-9));
         fprintf(stderr, "\n[ins] last bucket: touched %u heavy %u groups %u gidx %u fallback %u\n", ctr[LK_CTR_TOUCHED], ctr[LK_CTR_HEAVY],
                 ctr[LK_CTR_GROUPS], ctr[LK_CTR_GIDX], ctr[LK_CTR_FALLBACK]);
+        unsigned int rh[6 * 32];
+        hipMemcpyFromSymbol(rh, HIP_SYMBOL(lk_root_hist), sizeof(rh));
+        const char* rows[6] = {"light", "one group", "several groups", "long", "wave before 2nd root", "load+sort+walk"};
+        for (int r = 0; r < 6; ++r) {
+            fprintf(stderr, "[root] %-22s 2-us bins:", rows[r]);
+            for (int b = 0; b < 32; ++b) fprintf(stderr, " %u", rh[r * 32 + b]);
+            fprintf(stderr, "\n");
+        }
+        memset(rh, 0, sizeof(rh));
+        hipMemcpyToSymbol(HIP_SYMBOL(lk_root_hist), rh, sizeof(rh));
+        {
+            unsigned long long sd[32];
+            hipMemcpyFromSymbol(sd, HIP_SYMBOL(lk_slow_dbg), sizeof(sd));
+            const char* pn[10] = {"desc+node", "points", "simulate", "stores", "eigen", "plane_var", "commit", "tail", "block-load", "-"};
+            for (int w = 0; w < 2; ++w) {
+                fprintf(stderr, "[apply] plane-fit groups %s 20 us: %llu; per group (us):", w == 0 ? ">=" : "<", sd[16 * w + 15]);
+                for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.2f;", pn[k], (double)sd[16 * w + k] / (double)(sd[16 * w + 15] ? sd[16 * w + 15] : 1) * 0.01);
+                fprintf(stderr, "\n");
+            }
+            memset(sd, 0, sizeof(sd));
+            hipMemcpyToSymbol(HIP_SYMBOL(lk_slow_dbg), sd, sizeof(sd));
+        }
+        unsigned int eh[16 * 32];
+        hipMemcpyFromSymbol(eh, HIP_SYMBOL(lk_ev_hist), sizeof(eh));
+        for (int r = 0; r < 16; ++r) {
+            fprintf(stderr, "[apply] flags %2d (1 new child, 2 new block, 4 frozen, 8 plane fit) 2-us bins:", r);
+            for (int b = 0; b < 32; ++b) fprintf(stderr, " %u", eh[r * 32 + b]);
+            fprintf(stderr, "\n");
+        }
+        memset(eh, 0, sizeof(eh));
+        hipMemcpyToSymbol(HIP_SYMBOL(lk_ev_hist), eh, sizeof(eh));
     }
 #endif
     unsigned int redo = 0;

@@ -655,9 +655,16 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
 #ifdef LK_DEBUG_INS
 // DEBUG BUILD ONLY (-DLK_DEBUG_INS): 100 MHz stamps per phase of apply_leaf, summed over all groups; [15] = groups
 __device__ unsigned long long lk_ins_dbg[16];
-#define INS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&lk_ins_dbg[k], t1_ - t0_); t0_ = t1_; } while (0)
+#define INS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); ph_[k] += t1_ - t0_; if ((threadIdx.x & 63) == 0) atomicAdd(&lk_ins_dbg[k], t1_ - t0_); t0_ = t1_; } while (0)
+__device__ unsigned long long lk_slow_dbg[2 * 16];   // per-phase sums of the groups slower / faster than 20 us; [15] = their number
+// per-root durations of the root kernel's waves: 6 rows x 32 bins of 2 us; rows: light / one group, applied inline / several groups,
+// emitted / long list / whole wave (all its roots) / the root's first phase (record + slot line loaded, indices sorted, walk done)
+__device__ unsigned int lk_root_hist[6 * 32];
+__device__ unsigned int lk_ev_hist[16 * 32];   // apply_leaf: [fit events of the group][duration, 2-us bins]
+#define ROOT_HIST(row, t_from) do { if ((threadIdx.x & 63) == 0) { unsigned long long d_ = (wall_clock64() - (t_from)) / 200ull; atomicAdd(&lk_root_hist[(row) * 32 + (int)(d_ > 31ull ? 31ull : d_)], 1u); } } while (0)
 #else
 #define INS_STAMP(k) do { } while (0)
+#define ROOT_HIST(row, t_from) do { } while (0)
 #endif
 #ifdef LK_DEBUG_LI
 __device__ unsigned long long lk_li_dbg[64];
@@ -728,6 +735,9 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
     const int lane = threadIdx.x & 63;
 #ifdef LK_DEBUG_INS
     unsigned long long t0_ = wall_clock64();
+    const unsigned long long ta_ = t0_;
+    unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int nev_ = 0;
     if (lane == 0) atomicAdd(&lk_ins_dbg[15], 1ull);
 #endif
     int leaf = Tn;
@@ -774,6 +784,10 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
         const int gs = min(g, LK_WAVE - n0);
         double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
         if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
+#ifdef LK_DEBUG_INS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        INS_STAMP(8);
+#endif
         {
             const int rr = lane - n0;
             const bool valid = rr >= 0 && rr < gs;
@@ -796,6 +810,7 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
         int fit_count = 0;
         while (consumed < gs && !stop) {
             const int rem = gs - consumed;
+
             if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
                 const int k = max(min(rem, thr + 1 - cur), 1);
                 cur += k, newp += k, consumed += k;
@@ -836,6 +851,12 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
         }
         INS_STAMP(2);
         // ---- commit points, counters, one full fit
+#ifdef LK_DEBUG_INS
+        if (Tn < 0) nev_ |= 1;
+        if (cur > n0 && r.block < 0) nev_ |= 2;
+        if (frozen) nev_ |= 4;
+        if (fitted && fit.is_plane) nev_ |= 8;
+#endif
         if (cur > n0 && r.block < 0) r.block = alloc_block(map);
         if (lane >= n0 && lane < cur) {
             lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
@@ -888,6 +909,17 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
     }
 #endif
     INS_STAMP(7);
+#ifdef LK_DEBUG_INS
+    if (lane == 0) {
+        unsigned long long d_ = (wall_clock64() - ta_) / 200ull;
+        atomicAdd(&lk_ev_hist[(nev_ > 15 ? 15 : nev_) * 32 + (int)(d_ > 31ull ? 31ull : d_)], 1u);
+        if (nev_ == 8) {
+            unsigned long long* o = &lk_slow_dbg[d_ >= 10ull ? 0 : 16];
+            for (int k = 0; k < 10; ++k) atomicAdd(&o[k], ph_[k]);
+            atomicAdd(&o[15], 1ull);
+        }
+    }
+#endif
     // ---------------- a cut and / or whatever is left of the group: the generic state machine, in its own kernel
     if (need_init || consumed < g) {
         if (off < 0) {
@@ -915,6 +947,9 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
     return false;
 }
 // One wave per touched root (see the comment block above).
+// (Round 3, measured and not kept - profiles/r03i_insert_chain_experiments.txt: waves taking roots from a queue counter instead of
+// striding cost 0.60 against 0.44 ms per 5 x 20k scan - thousands of same-address atomics at launch; larger grids leave the kernel
+// at 40 us: its duration is its slowest single root, 8-12 us typically with a tail to 30 us in the memory phases, see the histograms.)
 template <bool FROM_PV>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                                                 const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
@@ -923,7 +958,16 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
     LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
     BucketConst bc;
     if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
+#ifdef LK_DEBUG_INS
+    const unsigned long long tw_ = wall_clock64();
+    bool any_ = false;
+#endif
     for (int t = wave; t < n_touched; t += nwaves) {
+#ifdef LK_DEBUG_INS
+        const unsigned long long tr_ = wall_clock64();
+        if (any_) ROOT_HIST(4, tw_);   // a wave with a second root: its time so far
+        any_ = true;
+#endif
         const int root = bcast0(map.touched[t]);
         lk_node_rec* nd = &map.nodes[root];
         // one batch of loads: the root's record, its plane flags, its slot line
@@ -951,6 +995,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                 dst->var[3] = gm.var.yy, dst->var[4] = gm.var.yz, dst->var[5] = gm.var.zz;
             }
             if (lane == 0) nd->npts = rnpts + m, nd->new_points = rnewp + m, nd->block = block;
+            ROOT_HIST(0, tr_);
             continue;
         }
         if (lane == 0) map.dirty[root] = map.epoch;   // pipelined stream path: a plane of this root's subtree may change in this bucket (LkMap::dirty)
@@ -974,6 +1019,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         }
         if (m > LK_WAVE) {  // very long list: handed over whole
             insert_defer(map, root, 0, base, m, 1, root, 0);
+            ROOT_HIST(3, tr_);
             continue;
         }
         // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
@@ -1037,6 +1083,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
 #ifndef LK_X_NOINLINE
 #define LK_X_NOINLINE 0   // debug / A-B only: 1 = every root hands its groups to lk_insert_apply_kernel
 #endif
+        ROOT_HIST(5, tr_);
         if (ngroups == 1 && !LK_X_NOINLINE) {
             // ---- the whole root is one leaf group: applied here, from registers (lane j holds the j-th point)
             LeafInfo li;
@@ -1057,6 +1104,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                 if (lane < m) map.gidx[gbase + lane] = sidx;
             };
             apply_leaf(map, pr, Tn, Tp, To, m, root, li, -1, point_at, store_idx);
+            ROOT_HIST(1, tr_);
             continue;
         }
         // ---- several groups: one descriptor per group, the group's indices in lane (= input) order
@@ -1092,6 +1140,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                 ++gi;
             }
         }
+        ROOT_HIST(2, tr_);
     }
 }
 
