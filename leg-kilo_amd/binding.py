@@ -47,6 +47,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LegKiloError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # PyTorch ships its own copy of the HIP runtime.  When both copies live in one process, torch's has to come up FIRST: brought up
+        # after this library has created its streams, torch.cuda fails with "No HIP GPUs are available".  So a process that has torch
+        # imported (the multi-GPU replay, the device-pointer entries) gets torch's runtime initialised before the first handle exists.
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.init()
         L = C.CDLL(LIB_PATH)
         L.lk_last_error.restype = C.c_char_p
         L.lk_last_error.argtypes = [C.c_void_p]

@@ -28,7 +28,9 @@ def oracle_lib():
 @pytest.fixture(scope="session")
 def hip_lib():
     """The product library.  GPU tests must run the HIP path: no skip, no fallback."""
+    import torch  # noqa: F401  (some GPU tests hand torch device pointers to the library: binding.lib() then brings torch's HIP runtime up first)
     from legkilo_amd import binding
 
     assert os.path.exists(binding.LIB_PATH), "liblegkilo_hip.so missing: run __graft_entry__.build()"
+    binding.lib()
     return binding
