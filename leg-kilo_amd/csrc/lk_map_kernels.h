@@ -809,14 +809,18 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
         fit.is_plane = lplane;
         int fit_count = 0;
         while (consumed < gs && !stop) {
+            // one step = the points up to the next refit event of the leaf's current mode (or all that are left); ONE copy of the
+            // plane test in the instruction stream for the three modes (the root kernel's code is about as large as the instruction cache)
             const int rem = gs - consumed;
-
-            if (mode == 0) {  // voxel_map.cc:186-189 then init_octo_tree :119-137
-                const int k = max(min(rem, thr + 1 - cur), 1);
-                cur += k, newp += k, consumed += k;
-                if (cur > thr) {
-                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                    fit_count = cur, fitted = true, newp = 0;
+            const int m0 = mode;
+            // mode 0: voxel_map.cc:186-189 then init_octo_tree :119-137;  mode 1: :191-204;  mode 2: :224-237
+            const int lim = m0 == 0 ? thr + 1 - cur : min(6 - newp, (m0 == 1 ? pr.max_points_num : pr.max_points_num + 1) - cur);
+            const int k = max(min(rem, lim), 1);
+            cur += k, newp += k, consumed += k;
+            if (m0 == 0 ? cur > thr : newp > 5) {
+                fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+                fit_count = cur, fitted = true, newp = 0;
+                if (m0 == 0) {
                     if (fit.is_plane) {
                         mode = 1;
                         if (cur > pr.max_points_num) frozen = true, stop = true;
@@ -825,29 +829,17 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
                     } else {
                         general_init = true, stop = true;  // the generic code cuts the voxel
                     }
-                }
-            } else if (mode == 1) {  // voxel_map.cc:191-204
-                const int k = max(min(rem, min(6 - newp, pr.max_points_num - cur)), 1);
-                cur += k, newp += k, consumed += k;
-                if (newp > 5) {
-                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                    fit_count = cur, fitted = true, newp = 0;
+                } else if (m0 == 1) {
                     if (!fit.is_plane) {
                         if (L < pr.max_layer) flipped_to_tree = true, stop = true;
                         else mode = 2;
                     }
+                } else if (fit.is_plane) {
+                    mode = 1;
                 }
-                if (cur >= pr.max_points_num) frozen = true, stop = true;
-            } else {  // voxel_map.cc:224-237
-                const int k = max(min(rem, min(6 - newp, pr.max_points_num + 1 - cur)), 1);
-                cur += k, newp += k, consumed += k;
-                if (newp > 5) {
-                    fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
-                    fit_count = cur, fitted = true, newp = 0;
-                    if (fit.is_plane) mode = 1;
-                }
-                if (cur > pr.max_points_num) frozen = true, stop = true;
             }
+            if (m0 == 1 && cur >= pr.max_points_num) frozen = true, stop = true;
+            if (m0 == 2 && cur > pr.max_points_num) frozen = true, stop = true;
         }
         INS_STAMP(2);
         // ---- commit points, counters, one full fit
