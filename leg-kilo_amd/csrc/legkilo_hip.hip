@@ -1061,6 +1061,17 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
     return LK_OK;
 }
 
+// lk_reproject_kernel's body in one-wave workgroups for the stream path: the pass is a chain of dependent round trips per point (scan
+// point -> hash slot -> node walk -> the root's queue counter), so it wants every CU, not throughput per CU - 313 single-wave
+// workgroups instead of 79 of four waves: 12.9 -> 11.1 us per 20 000-point bucket, 6.5 -> 6.0 us at 1 960 points (kernel trace, same box)
+extern "C++" __global__ void __launch_bounds__(LK_WAVE)
+    lk_reproject_wave_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, int n,
+                             float* __restrict__ world, int do_insert) {
+    const int i = blockIdx.x * LK_WAVE + threadIdx.x;
+    if (i >= n) return;
+    dev_reproject_point(map, pr, filters, pts, world, do_insert, i);
+}
+
 // ------------------------------------------------------------------ one time bucket on the stream (no sync)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 // t_next: time of the NEXT bucket if the caller knows that it follows directly (no IMU / kinematic message in between) and is itself
@@ -1117,7 +1128,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         ins_filters = h->d_snap;
     }
     if ((d_world || do_insert) && !fuse)
-        LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->stream, m, h->pr,
+        LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_wave_kernel, dim3((n + LK_WAVE - 1) / LK_WAVE), dim3(LK_WAVE), 0, h->stream, m, h->pr,
                                                   ins_filters, d_pts, n, d_world, do_insert ? 1 : 0));
     if (do_insert) {
         // one wave per touched root (append / group / apply of single-group roots), then one wave per emitted leaf group (2 resident
