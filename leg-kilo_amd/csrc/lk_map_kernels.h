@@ -642,9 +642,10 @@ __device__ __forceinline__ void dev_update_octo(const LkMap& m, const LkParams& 
 //                            that stays below layer_init_num, a plane root that reaches neither its 6th new point - refit,
 //                            voxel_map.cc:195 - nor max_points_num - freeze, :199) is finished at once, one lane per point.
 //                            Otherwise the wave sorts the root's queued indices in registers, walks every point (read-only) to
-//                            its target and forms the groups with ballots.  ONE group (98 % of the roots): the wave applies it
-//                            right away - the points, the leaf's counters and its block id are already in registers, so nothing
-//                            is handed over through memory.  Several groups: one descriptor per group + its indices are emitted.
+//                            its target and forms the groups with ballots.  ONE group (98 % of the roots) or up to
+//                            LK_INLINE_GROUPS: the wave applies them right away, one after the other - the points, the leaf's
+//                            counters and its block id are already in registers, so nothing is handed over through memory.
+//                            More groups: one descriptor per group + its indices are emitted.
 //   lk_insert_apply_kernel   one wave per EMITTED group: the same register simulation of voxel_map.cc:186-237 (apply_leaf).  A root
 //                            with six leaf groups is six work items side by side; replayed one after the other by the root's wave
 //                            they set the kernel's duration (80-150 k cycles against a mean of 36 k).
@@ -1076,27 +1077,46 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
 #define LK_X_NOINLINE 0   // debug / A-B only: 1 = every root hands its groups to lk_insert_apply_kernel
 #endif
         ROOT_HIST(5, tr_);
-        if (ngroups == 1 && !LK_X_NOINLINE) {
-            // ---- the whole root is one leaf group: applied here, from registers (lane j holds the j-th point)
-            LeafInfo li;
-            li.npts = __builtin_amdgcn_readlane(t_npts, 0), li.new_points = __builtin_amdgcn_readlane(t_newp, 0);
-            li.block = __builtin_amdgcn_readlane(t_block, 0), li.layer = __builtin_amdgcn_readlane(t_layer, 0);
-            li.state = (unsigned int)__builtin_amdgcn_readlane((int)t_state, 0), li.is_plane = __builtin_amdgcn_readlane(t_plane, 0);
-            const int Tn = __builtin_amdgcn_readlane(tnode, 0), Tp = __builtin_amdgcn_readlane(tparent, 0), To = __builtin_amdgcn_readlane(toct, 0);
-            auto point_at = [&](int rr, bool valid, PtU& pt) {
-                if (FROM_PV) {
-                    const int idx = __shfl(sidx, rr, LK_WAVE);
-                    if (valid) load_pt(pv, nullptr, idx, pt.pw, pt.var);
-                } else {
-                    const float qx = __shfl(p4.x, rr, LK_WAVE), qy = __shfl(p4.y, rr, LK_WAVE), qz = __shfl(p4.z, rr, LK_WAVE);
-                    if (valid) geom_to_pt(point_geom(qx, qy, qz, bc, pr), pt);
-                }
-            };
-            auto store_idx = [&](int gbase) {
-                if (lane < m) map.gidx[gbase + lane] = sidx;
-            };
-            apply_leaf(map, pr, Tn, Tp, To, m, root, li, -1, point_at, store_idx);
-            ROOT_HIST(1, tr_);
+#ifndef LK_INLINE_GROUPS
+#define LK_INLINE_GROUPS 3   // roots with at most this many leaf groups are finished by their own wave, group after group (>= 1)
+#endif
+        if (ngroups <= LK_INLINE_GROUPS && !LK_X_NOINLINE) {
+            // ---- one leaf group (98 % of the roots) or a few: applied here, from registers, one after the other.  A group's points are
+            // compacted to lanes 0 .. g-1 in lane (= input) order - the identity when the root is one group.  The launch for the emitted
+            // groups then finds nothing to do in the steady state (a handful of groups cost it ~10 us per bucket otherwise).
+            unsigned long long todo = __ballot(mine);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int Tn = __builtin_amdgcn_readlane(tnode, leader), Tp = __builtin_amdgcn_readlane(tparent, leader),
+                          To = __builtin_amdgcn_readlane(toct, leader);
+                const unsigned long long grp = __ballot(mine && tnode == Tn && tparent == Tp && toct == To) & todo;
+                todo &= ~grp;
+                const int g = __popcll(grp);
+                const bool in = ((grp >> lane) & 1ull) != 0;
+                const int dst = (in ? __popcll(grp & ((1ull << lane) - 1ull)) : 63) << 2;   // g == 64: every lane is a member
+                const float cx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(p4.x)));
+                const float cy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(p4.y)));
+                const float cz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(p4.z)));
+                const int cidx = __builtin_amdgcn_ds_permute(dst, sidx);
+                LeafInfo li;
+                li.npts = __builtin_amdgcn_readlane(t_npts, leader), li.new_points = __builtin_amdgcn_readlane(t_newp, leader);
+                li.block = __builtin_amdgcn_readlane(t_block, leader), li.layer = __builtin_amdgcn_readlane(t_layer, leader);
+                li.state = (unsigned int)__builtin_amdgcn_readlane((int)t_state, leader), li.is_plane = __builtin_amdgcn_readlane(t_plane, leader);
+                auto point_at = [&](int rr, bool valid, PtU& pt) {
+                    if (FROM_PV) {
+                        const int idx = __shfl(cidx, rr, LK_WAVE);
+                        if (valid) load_pt(pv, nullptr, idx, pt.pw, pt.var);
+                    } else {
+                        const float qx = __shfl(cx, rr, LK_WAVE), qy = __shfl(cy, rr, LK_WAVE), qz = __shfl(cz, rr, LK_WAVE);
+                        if (valid) geom_to_pt(point_geom(qx, qy, qz, bc, pr), pt);
+                    }
+                };
+                auto store_idx = [&](int gb) {
+                    if (lane < g) map.gidx[gb + lane] = cidx;
+                };
+                apply_leaf(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx);
+            }
+            ROOT_HIST(ngroups == 1 ? 1 : 2, tr_);
             continue;
         }
         // ---- several groups: one descriptor per group, the group's indices in lane (= input) order
