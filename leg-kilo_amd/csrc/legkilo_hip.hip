@@ -1061,6 +1061,22 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
     return LK_OK;
 }
 
+// The root pass of a large bucket with the NEXT bucket's predict beside it: workgroup 0 is the 256-thread predict (it reads and writes
+// the live filter only; the insert passes read the posterior's snapshot), the others are lk_insert_root_kernel.  The predict's ~5 us
+// disappear behind the 30-40 us root pass instead of lengthening the update launch every later kernel of the bucket waits for.
+static_assert(LK_MB == LK_FB, "the predict workgroup runs in the root kernel's launch shape");
+extern "C++" __global__ void __launch_bounds__(LK_MB)
+    lk_insert_root_predict_kernel(LkMap map, LkParams pr, const LkFilter* snap, const lk_point* __restrict__ pts, int n, LkFilter* live,
+                                  const double* __restrict__ Q, double t_next) {
+    if (blockIdx.x == 0) {
+        __shared__ FilterSmem sm;
+        dev_predict(&live[0], Q, t_next, sm);
+        return;
+    }
+    dev_insert_root<false>(map, pr, snap, pts, (const lk_pt_rec*)nullptr, n, (int)(((blockIdx.x - 1) * LK_MB + threadIdx.x) >> 6),
+                           (int)(((gridDim.x - 1) * LK_MB) >> 6));
+}
+
 // lk_reproject_kernel's body in one-wave workgroups for the stream path: the pass is a chain of dependent round trips per point (scan
 // point -> hash slot -> node walk -> the root's queue counter), so it wants every CU, not throughput per CU - 313 single-wave
 // workgroups instead of 79 of four waves: 12.9 -> 11.1 us per 20 000-point bucket, 6.5 -> 6.0 us at 1 960 points (kernel trace, same box)
@@ -1085,6 +1101,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
     const LkFilter* ins_filters = h->d_filters;   // what the insert reads the posterior from (large buckets: its snapshot)
+    bool predict_in_root = false;                 // large buckets: the next bucket's predict rides in the root pass's launch
     if (do_insert && h->spec_enable && !h->profiling && n > LK_SMALL_MAX && !was_pre) {
         static const bool xid_en = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
         return enqueue_bucket_spec(h, d_pts, n, t, d_world, h->pr.ext_identity && xid_en);
@@ -1119,11 +1136,13 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         memset(&ro, 0, sizeof(ro));
         ro.world = d_world;
         const bool fuse_next = pre_predicted != nullptr && t_next == t_next;
+        static const bool predict_in_root_on = getenv("LEGKILO_PREDICT_IN_ROOT") == nullptr || atoi(getenv("LEGKILO_PREDICT_IN_ROOT")) != 0;
+        predict_in_root = fuse_next && do_insert && predict_in_root_on;   // n > LK_SMALL_MAX here: the insert below is the three-launch form
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
         LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
                                                  h->d_partials, h->part_stride, ro, (size_t)0));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
-                                               nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, fuse_next ? t_next : 0.0, fuse_next ? 1 : 0, h->d_snap));
+                                               nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, fuse_next ? t_next : 0.0, fuse_next && !predict_in_root ? 1 : 0, h->d_snap));
         if (fuse_next) *pre_predicted = true;
         ins_filters = h->d_snap;
     }
@@ -1141,8 +1160,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
                                                         ins_filters, d_pts, n));
             return LK_OK;
         }
-        LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
-                                                    ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
+        if (predict_in_root)
+            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_predict_kernel, dim3(grid + 1), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                        ins_filters, d_pts, n, h->d_filters, h->d_Q, t_next));
+        else
+            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+                                                        ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
                                                ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
