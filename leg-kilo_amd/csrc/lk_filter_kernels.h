@@ -316,6 +316,10 @@ __device__ void dev_point_update(LkFilter* f, FilterSmem& sm, const double* A21,
     dev_kalman_apply(f, sm, 6);
 }
 
+#ifndef LK_BLOCK_UPDATE_WAVE
+#define LK_BLOCK_UPDATE_WAVE 1   // the 256-thread kernels solve and apply the point update in their wave 0 (0 = dev_point_update, barrier-separated)
+#endif
+__device__ void dev_point_update_wave0(LkFilter* f, FilterSmem& sm, const double* tot, int N);   // defined behind wave_update_core
 // The bucket's totals [A(21) b(6) sumR count] are in tot[] (LDS, visible to the whole workgroup): bookkeeping of
 // KILO.cc:193,211-212 and the information-form update.  Called by all LK_FB threads.
 __device__ void dev_update_from_totals(LkFilter* f, FilterSmem& sm, double* tot, double t) {
@@ -331,7 +335,9 @@ __device__ void dev_update_from_totals(LkFilter* f, FilterSmem& sm, double* tot,
             f->last_update_t = t;  // KILO.cc:212
         }
     }
-    if (N > 0) {
+    if (N > 0 && LK_BLOCK_UPDATE_WAVE) {
+        dev_point_update_wave0(f, sm, tot, N);
+    } else if (N > 0) {
         if (N == 1) {  // eskf.cc:98-104: s = 1/(0.0001 + hPh^T + r)  <=>  r' = r + 1e-4
             double r = tot[27];
             double sc = r / (r + 0.0001);
@@ -530,6 +536,25 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
     }
     if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+}
+
+// The point update of the 256-thread kernels (lk_update_kernel, lk_update_snap_kernel, lk_small_bucket_kernel) through the one-wave core:
+// the workgroup stages P and x in LDS, its wave 0 runs wave_update_core - the 6 x 37 system one column per lane, Gauss-Jordan in
+// registers: six dependent steps instead of six times four workgroup barriers with single-thread pivot searches between them - and the
+// workgroup writes the posterior back.  The same sums in the same order as dev_point_update (the two have always had to agree bit for
+// bit: test_batch_replay_frozen_map), N == 1 handled inside the core.  The staging area is FilterSmem::A/B, idle during an update.
+__device__ void dev_point_update_wave0(LkFilter* f, FilterSmem& sm, const double* tot, int N) {
+    static_assert(sizeof(WaveSmem) <= sizeof(double) * 1800, "WaveSmem must fit FilterSmem::A + B");
+    WaveSmem& w = *reinterpret_cast<WaveSmem*>(&sm.A[0]);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 900; i += LK_FB) w.P[i] = f->P[i];
+    if (tid < 36) w.x[tid] = f->x[tid];
+    __syncthreads();
+    if (tid < LK_WAVE) wave_update_core<true>(w, tid < 32 ? tot[tid] : 0.0, N, tid);
+    __syncthreads();
+    for (int i = tid; i < 900; i += LK_FB) f->P[i] = w.P[i];
+    if (tid < 36) f->x[tid] = w.x[tid];
+    __syncthreads();
 }
 
 // updateByImu (eskf.cc:125-135) with the rows of KILO.cc:246-253 on LDS-resident, already propagated state: H selects
