@@ -1139,15 +1139,20 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         static const bool predict_in_root_on = getenv("LEGKILO_PREDICT_IN_ROOT") == nullptr || atoi(getenv("LEGKILO_PREDICT_IN_ROOT")) != 0;
         predict_in_root = fuse_next && do_insert && predict_in_root_on;   // n > LK_SMALL_MAX here: the insert below is the three-launch form
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
-        LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
+        static const int lds_res = getenv("LEGKILO_LDS_RES") ? atoi(getenv("LEGKILO_LDS_RES")) : 0;
+        LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), lds_res, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
                                                  h->d_partials, h->part_stride, ro, (size_t)0));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
                                                nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, fuse_next ? t_next : 0.0, fuse_next && !predict_in_root ? 1 : 0, h->d_snap));
         if (fuse_next) *pre_predicted = true;
         ins_filters = h->d_snap;
     }
+    static const int lds_rp = getenv("LEGKILO_LDS_REPROJ") ? atoi(getenv("LEGKILO_LDS_REPROJ")) : 0;
+    static const int lds_root = getenv("LEGKILO_LDS_ROOT") ? atoi(getenv("LEGKILO_LDS_ROOT")) : 0;
+    static const int lds_apply = getenv("LEGKILO_LDS_APPLY") ? atoi(getenv("LEGKILO_LDS_APPLY")) : 0;
+    static const int lds_rootp = getenv("LEGKILO_LDS_ROOTP") ? atoi(getenv("LEGKILO_LDS_ROOTP")) : 0;
     if ((d_world || do_insert) && !fuse)
-        LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_wave_kernel, dim3((n + LK_WAVE - 1) / LK_WAVE), dim3(LK_WAVE), 0, h->stream, m, h->pr,
+        LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_wave_kernel, dim3((n + LK_WAVE - 1) / LK_WAVE), dim3(LK_WAVE), lds_rp, h->stream, m, h->pr,
                                                   ins_filters, d_pts, n, d_world, do_insert ? 1 : 0));
     if (do_insert) {
         // one wave per touched root (append / group / apply of single-group roots), then one wave per emitted leaf group (2 resident
@@ -1161,12 +1166,12 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
             return LK_OK;
         }
         if (predict_in_root)
-            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_predict_kernel, dim3(grid + 1), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_predict_kernel, dim3(grid + 1), dim3(LK_MB), lds_rootp, h->stream, h->map, h->pr,
                                                         ins_filters, d_pts, n, h->d_filters, h->d_Q, t_next));
         else
-            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+            LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), lds_root, h->stream, h->map, h->pr,
                                                         ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
-        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->stream, h->map, h->pr,
+        LAUNCH(h, "insert", hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), lds_apply, h->stream, h->map, h->pr,
                                                ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
         LAUNCH(h, "insert_fallback", hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->stream,
                                                         h->map, h->pr, ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));

@@ -89,20 +89,22 @@ LK_HD void lk_eig3_vec1(double a00, double a01, double a02, double a11, double a
     v[0] = c0 * ux + c1 * tx, v[1] = c0 * uy + c1 * ty, v[2] = c0 * uz + c1 * tz;
 }
 
-// A = [a0 a1 a2; a1 a3 a4; a2 a4 a5] (upper triangle, row-major).  ev[3] ascending; V row-major, COLUMN k = eigenvector of ev[k].
-LK_HD void lk_eig_sym3(const double* Ain, double* ev, double* V) {
+// A = [a0 a1 a2; a1 a3 a4; a2 a4 a5] (upper triangle, row-major).  ev[3] ascending; v0, v1, v2 = unit eigenvectors of ev[0], ev[1], ev[2].
+// (Three separate vectors, not a 3 x 3 array: on the device a caller that picks a column by a run-time index made the compiler keep
+// the array in memory - promoted to LDS, 72 B per thread - and the map kernels ran 30-40 % longer for it.)
+LK_HD void lk_eig_sym3_cols(const double* Ain, double* ev, double* v0, double* v1, double* v2) {
     double a00 = Ain[0], a01 = Ain[1], a02 = Ain[2], a11 = Ain[3], a12 = Ain[4], a22 = Ain[5];
     double mx = fmax(fmax(fabs(a00), fabs(a01)), fmax(fabs(a02), fabs(a11)));
     mx = fmax(mx, fmax(fabs(a12), fabs(a22)));
     if (!(mx > 0.0)) {   // zero matrix (or NaN input): identity basis
         ev[0] = ev[1] = ev[2] = (mx == 0.0) ? 0.0 : mx;
-        V[0] = 1, V[1] = 0, V[2] = 0, V[3] = 0, V[4] = 1, V[5] = 0, V[6] = 0, V[7] = 0, V[8] = 1;
+        v0[0] = 1, v0[1] = 0, v0[2] = 0, v1[0] = 0, v1[1] = 1, v1[2] = 0, v2[0] = 0, v2[1] = 0, v2[2] = 1;
         return;
     }
     const double inv = 1.0 / mx;
     a00 *= inv, a01 *= inv, a02 *= inv, a11 *= inv, a12 *= inv, a22 *= inv;
     const double nrm = a01 * a01 + a02 * a02 + a12 * a12;
-    double e0, e1, e2, v0[3], v1[3], v2[3];
+    double e0, e1, e2;
     if (nrm > 0.0) {
         const double q = (a00 + a11 + a22) / 3.0;
         const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
@@ -114,36 +116,41 @@ LK_HD void lk_eig_sym3(const double* Ain, double* ev, double* V) {
         const double twoThirdsPi = 2.09439510239319549;
         const double beta2 = 2.0 * cos(ang), beta0 = 2.0 * cos(ang + twoThirdsPi), beta1 = -(beta0 + beta2);
         e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;   // ascending
-        if (hd >= 0.0) {   // e2 is the isolated one
-            lk_eig3_vec0(a00, a01, a02, a11, a12, a22, e2, v2);
-            lk_eig3_vec1(a00, a01, a02, a11, a12, a22, v2, e1, v1);
-            v0[0] = v1[1] * v2[2] - v1[2] * v2[1], v0[1] = v1[2] * v2[0] - v1[0] * v2[2], v0[2] = v1[0] * v2[1] - v1[1] * v2[0];
-        } else {           // e0 is the isolated one
-            lk_eig3_vec0(a00, a01, a02, a11, a12, a22, e0, v0);
-            lk_eig3_vec1(a00, a01, a02, a11, a12, a22, v0, e1, v1);
-            v2[0] = v0[1] * v1[2] - v0[2] * v1[1], v2[1] = v0[2] * v1[0] - v0[0] * v1[2], v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
-        }
+        // the isolated eigenvalue's vector first (e2 when hd >= 0, else e0), the middle one from its complement, the third as a cross
+        // product: v0 = v1 x v2, or v2 = v0 x v1.  One copy of the arithmetic with the operands SELECTED (a branch per case writes
+        // through a pointer that depends on the branch, which keeps the three vectors in memory on the device)
+        const bool top = hd >= 0.0;
+        double iso[3], oth[3];
+        lk_eig3_vec0(a00, a01, a02, a11, a12, a22, top ? e2 : e0, iso);
+        lk_eig3_vec1(a00, a01, a02, a11, a12, a22, iso, e1, v1);
+        const double px = top ? v1[0] : iso[0], py = top ? v1[1] : iso[1], pz = top ? v1[2] : iso[2];   // p x q with (p, q) = (v1, v2) or (v0, v1)
+        const double qx = top ? iso[0] : v1[0], qy = top ? iso[1] : v1[1], qz = top ? iso[2] : v1[2];
+        oth[0] = py * qz - pz * qy, oth[1] = pz * qx - px * qz, oth[2] = px * qy - py * qx;
+        for (int k = 0; k < 3; ++k) v2[k] = top ? iso[k] : oth[k], v0[k] = top ? oth[k] : iso[k];
     } else {   // diagonal already: sort the diagonal, unit vectors
         double d[3] = {a00, a11, a22};
         int i0 = 0, i1 = 1, i2 = 2;
-        if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
-        if (d[i1] > d[i2]) { int t = i1; i1 = i2; i2 = t; }
-        if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
-        e0 = d[i0], e1 = d[i1], e2 = d[i2];
+        double d0 = d[0], d1 = d[1], d2 = d[2];   // sorted as scalars beside their indices (no run-time index into d[])
+        if (d0 > d1) { int t = i0; i0 = i1; i1 = t; double u = d0; d0 = d1; d1 = u; }
+        if (d1 > d2) { int t = i1; i1 = i2; i2 = t; double u = d1; d1 = d2; d2 = u; }
+        if (d0 > d1) { int t = i0; i0 = i1; i1 = t; double u = d0; d0 = d1; d1 = u; }
+        e0 = d0, e1 = d1, e2 = d2;
         for (int k = 0; k < 3; ++k) v0[k] = (k == i0) ? 1.0 : 0.0, v1[k] = (k == i1) ? 1.0 : 0.0, v2[k] = (k == i2) ? 1.0 : 0.0;
     }
     if (nrm > 0.0) {
         // Rayleigh quotients of the (orthonormal) eigenvectors: the trigonometric eigenvalues lose digits when two of them nearly
         // coincide (acos near +-1); v^T A v is second-order accurate in the eigenvector error
-        const double* vs[3] = {v0, v1, v2};
-        double er[3];
-        for (int k = 0; k < 3; ++k) {
-            const double* v = vs[k];
+        auto rq = [&](const double* v) {
             const double ax = a00 * v[0] + a01 * v[1] + a02 * v[2], ay = a01 * v[0] + a11 * v[1] + a12 * v[2], az = a02 * v[0] + a12 * v[1] + a22 * v[2];
-            er[k] = v[0] * ax + v[1] * ay + v[2] * az;
-        }
-        e0 = er[0], e1 = er[1], e2 = er[2];
+            return v[0] * ax + v[1] * ay + v[2] * az;
+        };
+        e0 = rq(v0), e1 = rq(v1), e2 = rq(v2);
     }
     ev[0] = e0 * mx, ev[1] = e1 * mx, ev[2] = e2 * mx;
+}
+// V row-major, COLUMN k = eigenvector of ev[k]
+LK_HD void lk_eig_sym3(const double* Ain, double* ev, double* V) {
+    double v0[3], v1[3], v2[3];
+    lk_eig_sym3_cols(Ain, ev, v0, v1, v2);
     for (int k = 0; k < 3; ++k) V[3 * k + 0] = v0[k], V[3 * k + 1] = v1[k], V[3 * k + 2] = v2[k];
 }

@@ -101,6 +101,18 @@ __device__ __forceinline__ void load_pt(const lk_pt_rec* base, const int* idx, i
 #ifndef LK_EIG_JACOBI
 #define LK_EIG_JACOBI 0
 #endif
+// eigenvectors as three separate vectors (see lk_eig_sym3_cols: a 3 x 3 array picked by a run-time column index ends up in LDS / scratch)
+__device__ __forceinline__ void eig_sym3_dev(const double* Ain, double* ev, double* V);
+__device__ __forceinline__ void eig_sym3_cols_dev(const double* Ain, double* ev, double* v0, double* v1, double* v2) {
+#if !LK_EIG_JACOBI
+    lk_eig_sym3_cols(Ain, ev, v0, v1, v2);
+#else
+    double V[9];
+    eig_sym3_dev(Ain, ev, V);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v0[k] = V[3 * k + 0], v1[k] = V[3 * k + 1], v2[k] = V[3 * k + 2];
+#endif
+}
 __device__ __forceinline__ void eig_sym3_dev(const double* Ain, double* ev, double* V) {
 #if !LK_EIG_JACOBI
     lk_eig_sym3(Ain, ev, V);
@@ -168,12 +180,15 @@ __device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, lk_match_rec* mr, 
     double c[3] = {s[0] / n, s[1] / n, s[2] / n};
     double cov[6] = {s[3] / n - c[0] * c[0], s[4] / n - c[0] * c[1], s[5] / n - c[0] * c[2],
                      s[6] / n - c[1] * c[1], s[7] / n - c[1] * c[2], s[8] / n - c[2] * c[2]};
-    double ev[3], V[9];
-    eig_sym3_dev(cov, ev, V);
-    int imin = 0, imax = 0;
-    for (int k = 1; k < 3; ++k) {
-        if (ev[k] < ev[imin]) imin = k;
-        if (ev[k] > ev[imax]) imax = k;
+    double ev[3], V0[3], V1[3], V2[3];   // eigenvectors of ev[0], ev[1], ev[2]
+    eig_sym3_cols_dev(cov, ev, V0, V1, V2);
+    int imin = 0, imax = 0;   // first minimum / first maximum, tracked as scalars (ev[imin] with a run-time index keeps ev[] in memory)
+    {
+        double lo = ev[0], hi = ev[0];
+        if (ev[1] < lo) imin = 1, lo = ev[1];
+        if (ev[1] > hi) imax = 1, hi = ev[1];
+        if (ev[2] < lo) imin = 2, lo = ev[2];
+        if (ev[2] > hi) imax = 2, hi = ev[2];
     }
     int imid = 3 - imin - imax;
     if (imid > 2) imid = imin;
@@ -183,9 +198,9 @@ __device__ __noinline__ bool dev_init_plane(lk_plane_rec* pl, lk_match_rec* mr, 
     for (int q = 0; q < 21; ++q) acc[q] = 0.0;
     // select eigen-columns without dynamic register indexing
     auto col = [&](int k, double* o) {
-        o[0] = (k == 0) ? V[0] : (k == 1) ? V[1] : V[2];
-        o[1] = (k == 0) ? V[3] : (k == 1) ? V[4] : V[5];
-        o[2] = (k == 0) ? V[6] : (k == 1) ? V[7] : V[8];
+        o[0] = (k == 0) ? V0[0] : (k == 1) ? V1[0] : V2[0];
+        o[1] = (k == 0) ? V0[1] : (k == 1) ? V1[1] : V2[1];
+        o[2] = (k == 0) ? V0[2] : (k == 1) ? V1[2] : V2[2];
     };
     auto evk = [&](int k) { return (k == 0) ? ev[0] : (k == 1) ? ev[1] : ev[2]; };
     double vmin[3], vmid[3], vmax[3];
@@ -275,13 +290,15 @@ struct PlaneFit {
 // cov - t I is positive semi-definite, and it is positive definite iff its three leading principal minors are > 0
 // (Sylvester).  Used for the refit events in the middle of a bucket, whose eigenvectors nobody ever reads; differs
 // from the Jacobi decision only when lambda_min equals the threshold to rounding.
-template <bool decide_only = false>
+// REUSE: the sums come from `prev` (a compile-time choice: with a run-time pointer that may be null the nine doubles became a private
+// ARRAY - promoted to LDS, 72 B x 256 threads, or spilled to scratch - and the insert kernels ran 30-40 % longer for it)
+template <bool decide_only = false, bool REUSE = false>
 __device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool active, int count, float planer_threshold,
-                                                    const double* reuse_s9 = nullptr) {
+                                                    const PlaneFit* prev = nullptr) {
     double s[9];
-    if (reuse_s9) {   // same points, same count as the event these sums come from: the nine wave reductions are not repeated
+    if (REUSE) {   // same points, same count as the event these sums come from: the nine wave reductions are not repeated
 #pragma unroll
-        for (int q = 0; q < 9; ++q) s[q] = reuse_s9[q];
+        for (int q = 0; q < 9; ++q) s[q] = prev->s9[q];
     } else {
 #pragma unroll
         for (int q = 0; q < 9; ++q) s[q] = 0.0;
@@ -310,19 +327,22 @@ __device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool activ
         for (int k = 0; k < 3; ++k) f.vmin[k] = f.vmid[k] = f.vmax[k] = 0.0;
         return f;
     }
-    double ev[3], V[9];
-    eig_sym3_dev(cov, ev, V);
-    int imin = 0, imax = 0;
-    for (int k = 1; k < 3; ++k) {
-        if (ev[k] < ev[imin]) imin = k;
-        if (ev[k] > ev[imax]) imax = k;
+    double ev[3], V0[3], V1[3], V2[3];   // eigenvectors of ev[0], ev[1], ev[2]
+    eig_sym3_cols_dev(cov, ev, V0, V1, V2);
+    int imin = 0, imax = 0;   // first minimum / first maximum, tracked as scalars (ev[imin] with a run-time index keeps ev[] in memory)
+    {
+        double lo = ev[0], hi = ev[0];
+        if (ev[1] < lo) imin = 1, lo = ev[1];
+        if (ev[1] > hi) imax = 1, hi = ev[1];
+        if (ev[2] < lo) imin = 2, lo = ev[2];
+        if (ev[2] > hi) imax = 2, hi = ev[2];
     }
     int imid = 3 - imin - imax;
     if (imid > 2) imid = imin;
     auto col = [&](int k, double* o) {
-        o[0] = (k == 0) ? V[0] : (k == 1) ? V[1] : V[2];
-        o[1] = (k == 0) ? V[3] : (k == 1) ? V[4] : V[5];
-        o[2] = (k == 0) ? V[6] : (k == 1) ? V[7] : V[8];
+        o[0] = (k == 0) ? V0[0] : (k == 1) ? V1[0] : V2[0];
+        o[1] = (k == 0) ? V0[1] : (k == 1) ? V1[1] : V2[1];
+        o[2] = (k == 0) ? V0[2] : (k == 1) ? V1[2] : V2[2];
     };
     auto evk = [&](int k) { return (k == 0) ? ev[0] : (k == 1) ? ev[1] : ev[2]; };
     col(imin, f.vmin), col(imid, f.vmid), col(imax, f.vmax);
@@ -868,11 +888,9 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
             if (fitted) {
                 // the one full fit of this leaf in this bucket: the state of its LAST refit event
                 const bool decided = fit.is_plane;
-                double s9[9];   // the last event tested exactly these fit_count points
-#pragma unroll
-                for (int q = 0; q < 9; ++q) s9[q] = fit.s9[q];
+                const PlaneFit last = fit;   // the last event tested exactly these fit_count points: its sums are reused
                 INS_STAMP(3);
-                fit = plane_test_regs<false>(ppw, lane < fit_count, fit_count, pr.planer_threshold, s9);
+                fit = plane_test_regs<false, true>(ppw, lane < fit_count, fit_count, pr.planer_threshold, &last);
                 INS_STAMP(4);
                 fit.is_plane = decided;  // control flow above already followed the event's decision
                 double acc21[21];
