@@ -1067,10 +1067,23 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
 static_assert(LK_MB == LK_FB, "the predict workgroup runs in the root kernel's launch shape");
 extern "C++" __global__ void __launch_bounds__(LK_MB)
     lk_insert_root_predict_kernel(LkMap map, LkParams pr, const LkFilter* snap, const lk_point* __restrict__ pts, int n, LkFilter* live,
-                                  const double* __restrict__ Q, double t_next) {
+                                  const double* __restrict__ Q, double t_next, int q_diag) {
     if (blockIdx.x == 0) {
-        __shared__ FilterSmem sm;
-        dev_predict(&live[0], Q, t_next, sm);
+        // the predict as ONE wave on the one-wave core (7.7 KB of LDS instead of the 256-thread predict's 38 KB in every workgroup
+        // of this launch; the same bits: the scan-resident kernel runs this core against the 256-thread kernels in the tests)
+        __shared__ WaveSmem sm;
+        if (threadIdx.x >= LK_WAVE) return;
+        LkFilter* f = &live[0];
+        const int lane = threadIdx.x;
+        for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+        if (lane < 36) sm.x[lane] = f->x[lane];
+        const double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+        core_sync<true>();
+        wave_predict_core<true>(sm, Q, t_next - t_upd, t_next - t_pred, lane, q_diag != 0);   // KILO.cc:111-115
+        core_sync<true>();
+        for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+        if (lane < 36) f->x[lane] = sm.x[lane];
+        if (lane == 0) f->last_predict_t = t_next;
         return;
     }
     dev_insert_root<false>(map, pr, snap, pts, (const lk_pt_rec*)nullptr, n, (int)(((blockIdx.x - 1) * LK_MB + threadIdx.x) >> 6),
@@ -1167,7 +1180,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         }
         if (predict_in_root)
             LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_predict_kernel, dim3(grid + 1), dim3(LK_MB), lds_rootp, h->stream, h->map, h->pr,
-                                                        ins_filters, d_pts, n, h->d_filters, h->d_Q, t_next));
+                                                        ins_filters, d_pts, n, h->d_filters, h->d_Q, t_next, h->q_diag ? 1 : 0));
         else
             LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), lds_root, h->stream, h->map, h->pr,
                                                         ins_filters, d_pts, (const lk_pt_rec*)nullptr, n));
