@@ -1061,8 +1061,8 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
     return LK_OK;
 }
 
-// The root pass of a large bucket with the NEXT bucket's predict beside it: workgroup 0 is the 256-thread predict (it reads and writes
-// the live filter only; the insert passes read the posterior's snapshot), the others are lk_insert_root_kernel.  The predict's ~5 us
+// The root pass of a large bucket with the NEXT bucket's predict beside it: workgroup 0 is the predict (it reads and writes the live
+// filter only; the insert passes read the posterior's snapshot), the others are lk_insert_root_kernel.  The predict's ~5 us
 // disappear behind the 30-40 us root pass instead of lengthening the update launch every later kernel of the bucket waits for.
 static_assert(LK_MB == LK_FB, "the predict workgroup runs in the root kernel's launch shape");
 extern "C++" __global__ void __launch_bounds__(LK_MB)
