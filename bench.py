@@ -2,7 +2,8 @@
 """bench.py — LiDAR scans/s through the per-time-bucket ESKF update on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W; without a launcher
+     `python bench.py --gpus N` starts its N ranks itself, the same way)
 
 Workload (BASELINE.json metric "LiDAR scans/sec (per-point ESKF update), 100k-pt scan, 1->8 MI355X"), config 5 with
 config 3's per-scan semantics:
@@ -53,7 +54,7 @@ SIMDS, CLK_GHZ = 1024, 2.4
 N_PTS = 100_000
 N_BUCKETS = 5
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
-FP64_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: fp64 vector peak (the matrix rate is the same)
+FP64_PEAK_TFLOPS = 78.6    # AMD MI355X datasheet: peak fp64 vector = fp64 matrix = 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 row; 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6)
 COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
 
@@ -173,6 +174,8 @@ def main():
     ap.add_argument("--config1-scans", type=int, default=2048, help="scans of the ragged config-1 batch measured as an extra (0 = skip)")
     ap.add_argument("--sustained-s", type=float, default=1.2, help="length of the sustained run reported in extra (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
+    ap.add_argument("--overlay-scans", type=int, default=1024, help="scans of the batch replayed WITH the map insert (per-scan overlay, extra.overlay_*; 0 = skip)")
+    ap.add_argument("--overlay-check", type=int, default=24, help="of those, scans the oracle replays (insert on, private copy of the map) for extra.overlay_parity")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (slot ranges / streams they rotate over: 2 or 3; 3 gains 2 % in steady state - 1.753 vs 1.789 ms at 60 steps - and loses it to the longer drain of a 20-step region)")
     ap.add_argument("--step-sweep", action="store_true", help="also time regions of 1..64 steps (extra.step_sweep_ms)")
@@ -180,10 +183,23 @@ def main():
     ap.add_argument("--cache-dir", default="", help="keep generated inputs here between runs of one session (profiling passes)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) - the same
+        # command line under torch.distributed.run; rank 0 of that run prints the JSON line, its exit code is ours
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_size}"
+    if world_size != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size} (launch with --nproc-per-node {args.gpus}, or without a launcher: bench.py starts its own ranks)")
     strong = args.total_scans > 0
     if strong:
         g0, g1 = replay.shard_range(args.total_scans, rank, world_size)
@@ -476,6 +492,45 @@ def main():
         "other_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items() if k != "residual"},
     }
 
+    # ---- extra: the same batch WITH the map insert - every scan on its own copy-on-write overlay of the shared map (SURVEY 8d config 5,
+    # "scan-local insert overlay"; KILO.cc:216-233 after every bucket): what KILO::process computes per scan, for the whole batch
+    ov = None
+    S_ov = min(args.overlay_scans, S) if rank == 0 else 0
+    if S_ov > 0:
+        try:
+            g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
+            g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)   # warm (allocates the overlay pools)
+            tov = []
+            for _ in range(3):
+                g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
+                g.synchronize()
+                tc = time.perf_counter()
+                ov_poses = g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt)
+                tov.append(time.perf_counter() - tc)
+            t_ov = float(np.median(tov))
+            ov_p = np.frombuffer(ov_poses, dtype=_abi.pose_dtype()).copy()
+            extra["overlay_scans"] = S_ov
+            extra["overlay_ms_per_batch"] = round(t_ov * 1e3, 3)
+            extra["overlay_scans_per_s"] = round(S_ov / t_ov, 1)
+            extra["overlay_alg_GBs"] = round(ALG_BYTES_FULL * N_PTS * S_ov / t_ov / 1e9, 1)
+            extra["overlay_alg_frac_of_hbm_peak"] = round(ALG_BYTES_FULL * N_PTS * S_ov / t_ov / 1e9 / HBM_PEAK_GBS, 4)
+            extra["overlay_mean_n_effect"] = round(float(ov_p["n_effect"].astype(np.float64).mean()), 1)
+            r_, n_, b_ = g.overlay_stats()
+            extra["overlay_private_per_scan_max"] = {"roots": r_, "nodes": n_, "point_blocks": b_}
+            # where the time goes: the same replay once more with an event pair around every launch
+            g.profile_reset()
+            g.profile_enable(1)
+            g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
+            g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)
+            g.profile_enable(0)
+            extra["overlay_kernel_ms_per_batch"] = {k: round(g.profile_get(k)[1], 3) for k in
+                                                    ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_cow", "ov_insert_root",
+                                                     "ov_insert_apply", "ov_insert_fallback")}
+            ov = ov_p
+        except Exception as e:  # noqa: BLE001
+            extra["overlay_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+            warnings.append("overlay replay failed: " + extra["overlay_error"])
+
     extra.update({"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
                   "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok, "rccl_map_broadcast_ms": bcast_ms,
                   "rccl_map_scatter_allgather_ms": bcast2_ms})
@@ -670,6 +725,25 @@ def main():
             tc = time.perf_counter()
             o.process_scan(sscans[k], t_after + 0.1 * k, with_sort=True)
             tfull.append(time.perf_counter() - tc)
+        if ov is not None and args.overlay_check > 0:
+            # the overlay replay against the oracle: each scan on a PRIVATE copy of the device's map (blob re-imported), insert on
+            n_oc = min(args.overlay_check, len(ov))
+            oc_eq, oc_dpos, oc_t = 0, 0.0, []
+            for s in range(n_oc):
+                o.map_import(map_blob_for_oracle)
+                o.set_map_insert(True)
+                o.set_state(xs[s], Ps[s])
+                o.set_times(0.0, 0.0)
+                tc = time.perf_counter()
+                pose, _ = o.process_scan(scans[tile[s]], 0.0, with_sort=True)
+                oc_t.append(time.perf_counter() - tc)
+                oc_eq += int((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect)) == (int(ov[s]["n_buckets"]), int(ov[s]["n_updates"]), int(ov[s]["n_effect"])))
+                oc_dpos = max(oc_dpos, float(np.abs(np.array(pose.pos) - ov[s]["pos"]).max()))
+            parity["overlay"] = {"n": n_oc, "counts_equal": oc_eq, "max_pos_delta_m": oc_dpos, "tolerance_m": 1e-7,
+                                 "checker": "oracle.process_scan with insert ON on a private copy of the device's map blob"}
+            parity["ok"] = bool(parity["ok"] and oc_dpos <= 1e-7 and oc_eq >= n_oc - max(1, n_oc // 50))
+            extra["overlay_cpu_port_scans_per_s"] = round(1.0 / float(np.median(oc_t)), 2)
+            extra["overlay_speedup_vs_cpu_port"] = round(extra["overlay_scans_per_s"] / extra["overlay_cpu_port_scans_per_s"], 1)
         o.close()
         cpu_baseline = {
             "value": round(1.0 / float(np.median(tcs)), 3), "unit": "scans/s", "cores": 1, "kind": "port",

@@ -47,7 +47,9 @@ typedef enum lk_status {
     LK_ERR_HIP = -2,       /* HIP runtime error (text in lk_last_error) */
     LK_ERR_CAPACITY = -3,  /* a device pool (hash / nodes / point blocks / scan) overflowed */
     LK_ERR_NO_DEVICE = -4, /* no gfx950 device visible; there is NO CPU fallback */
-    LK_ERR_STATE = -5      /* call order violated (e.g. update before set_state) */
+    LK_ERR_STATE = -5,     /* call order violated (e.g. update before set_state) */
+    LK_ERR_TIMEOUT = -6    /* a bounded device-side wait of the stream path was given up (fault / pre-empted GPU): the filter keeps its
+                              pre-scan state, the map may hold a partial insert - restore it and replay the scan.  Not sticky. */
 } lk_status;
 
 /* ESKF::Config (eskf.h:49-65) + VoxelMapConfig (voxel_map.h:41-57) + extrinsics
@@ -320,6 +322,25 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
                               const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, const double* d_x36,
                               const double* d_P900, lk_pose* host_out);
 
+/* ---- batch replay WITH the map insert (SURVEY.md 8d, config 5 "scan-local insert overlay") ----
+ * What KILO::process does per scan - predict, residual, update AND re-projection + UpdateVoxelMap after every bucket (KILO.cc:108-233,
+ * :375-395; voxel_map.cc:336-361), so that buckets 2..n of a scan are matched against the planes their own scan has refitted, cut or
+ * created - for n_scans independent scans at once.  Every scan (filter slot s) starts from the handle's map and inserts into its own
+ * copy-on-write overlay; the handle's map is not changed, and the overlays are discarded by the next replay.  Same argument meaning
+ * as lk_batch_replay_dev (priors from lk_batch_set_priors(_dev); synchronous; out may be NULL).  Per slot the result equals
+ * lk_process_scan_dev on a handle that holds a private copy of the map.  LK_ERR_CAPACITY when a scan's overlay outgrows its pools
+ * (the message names the slot and the sizes in use). */
+int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
+                                const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
+/* Per-scan overlay capacities: root voxels a scan's inserts may touch or create, octree nodes and live point blocks of those voxels
+ * (0 = derived from the scan size: n_pts / 6 roots, 1.5 nodes and 1 block per root).  Releases pools of another shape. */
+int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per_scan, uint32_t blocks_per_scan);
+/* The voxels scan `slot` of the LAST overlay replay holds privately - every root voxel its inserts touched or created, whole octrees -
+ * as a map blob (lk_map_export's format; blob == NULL: size query).  Voxels not in it are the handle's, unchanged. */
+int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes);
+/* Largest private root / node / point-block count any scan of the last overlay replay reached (any pointer may be NULL). */
+int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks);
+
 /* Ragged batch: the scans of a recorded run differ in size, in their time buckets (KILO.cc:375-378) and in their start
  * time.  Scan s = d_pts[scan_off[s] .. scan_off[s+1]) (scan_off: n_scans + 1 entries) on filter slot s; n_buckets[s] buckets
  * whose bounds (n_buckets[s] + 1 offsets relative to the scan's first point, first 0, last = points in the scan) and time
@@ -367,7 +388,8 @@ int lk_synchronize(lk_handle* h);
  * default is the sequential order on one stream, which measures faster) the map insert of bucket k (KILO.cc:216-233) runs on a second HIP stream beside
  * the predict + residual pass of bucket k+1, and a verify pass re-evaluates the tiles whose points looked at a root voxel the
  * insert stamped.  Results are those of the sequential order.  lk_stream_stats: out4 = { buckets that went through the
- * pipeline, their residual tiles, tiles the verify pass evaluated again, 0 } since lk_create. */
+ * HIP-stream pipeline, their residual tiles, tiles its verify pass evaluated again, buckets the scan-resident kernel (below, its own
+ * mechanism: LDS flags inside one workgroup) evaluated again after a conflicting insert } since lk_create. */
 int lk_stream_pipeline(lk_handle* h, int on);
 /* Scan-resident stream kernel: a scan whose time buckets all hold <= 512 points (the reference's own scan shape: 2 ms bins of a dozen
  * points) runs its whole bucket loop - messages, predict, residual, update AND map insert (KILO.cc:375-395, :216-233) - as ONE launch

@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_stats",
 ]
 
@@ -346,6 +346,32 @@ class LegKiloHip:
                                                    C.c_size_t(n_pts), C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)),
                                                    C.c_void_p(d_x36) if d_x36 else None, C.c_void_p(d_P900) if d_P900 else None,
                                                    C.c_void_p(host_out_ptr) if host_out_ptr else None))
+
+    def batch_replay_overlay_dev(self, d_pts, n_scans, n_pts, t_begin, bucket_off, bucket_dt, want_poses=True):
+        """Batch replay WITH the map insert: every scan on its own copy-on-write overlay of the handle's map (lk_batch_replay_overlay_dev)."""
+        off = np.ascontiguousarray(bucket_off, dtype=np.uint32)
+        dt = _f64(bucket_dt)
+        poses = (abi.lk_pose * n_scans)() if want_poses else None
+        self._chk(self.L.lk_batch_replay_overlay_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts),
+                                                     C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
+        return poses
+
+    def overlay_reserve(self, roots_per_scan=0, nodes_per_scan=0, blocks_per_scan=0):
+        self._chk(self.L.lk_overlay_reserve(self.h, C.c_uint32(roots_per_scan), C.c_uint32(nodes_per_scan), C.c_uint32(blocks_per_scan)))
+
+    def overlay_export(self, slot):
+        """Map blob of the voxels scan `slot` of the last overlay replay holds privately."""
+        nbytes = C.c_size_t(0)
+        self._chk(self.L.lk_overlay_export(self.h, C.c_uint32(slot), None, C.byref(nbytes)))
+        buf = np.zeros(nbytes.value, dtype=np.uint8)
+        self._chk(self.L.lk_overlay_export(self.h, C.c_uint32(slot), _p(buf), C.byref(nbytes)))
+        return buf
+
+    def overlay_stats(self):
+        """(max roots, max nodes, max point blocks) any scan's overlay reached in the last overlay replay."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.lk_overlay_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     @staticmethod
     def ragged_tables(scan_off, bucket_offs, bucket_dts, t_begins, imus=None, kins=None):

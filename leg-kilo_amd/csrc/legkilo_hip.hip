@@ -20,6 +20,7 @@
 #include "lk_point_kernels.h"
 #include "lk_map_kernels.h"
 #include "lk_pre_kernels.h"
+#include "lk_overlay_kernels.h"
 
 static_assert(sizeof(lk_plane_rec) == 256, "plane record must be 256 B");
 static_assert(sizeof(lk_node_rec) == 128, "node record must be 128 B");
@@ -71,8 +72,8 @@ struct lk_handle {
     bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
     int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
-    uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0;
-    unsigned int spec_redo_seen = 0;
+    uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0, res_redo_total = 0;
+    unsigned int spec_redo_seen = 0, res_redo_seen = 0;
     double acc_norm = 1.0;
     bool q_diag = true;        // d_Q holds a diagonal matrix (zero-initialised; lk_set_Q re-checks)
     // frozen-map grid of batch replay (LkMap::grid): valid until the map changes
@@ -87,6 +88,12 @@ struct lk_handle {
     unsigned int *pre_k0 = nullptr, *pre_k1 = nullptr, *pre_flags = nullptr, *pre_pos = nullptr, *pre_misc = nullptr;
     int *pre_v0 = nullptr, *pre_v1 = nullptr, *pre_starts = nullptr;
     void* pre_tmp = nullptr;
+    // batch replay with a per-scan insert overlay (lk_overlay_kernels.h): the pools of all slots, grow-only
+    LkOverlay ov = {};
+    uint32_t ov_slots = 0;                                // slots the pools were allocated for
+    uint32_t ov_want_roots = 0, ov_want_nodes = 0, ov_want_blocks = 0;   // lk_overlay_reserve (0: derived from the scan size)
+    uint32_t ov_last_slots = 0;                           // slots of the last overlay replay (lk_overlay_export / lk_overlay_stats)
+    unsigned int* d_ov_status = nullptr;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfEntry> prof;
@@ -158,16 +165,25 @@ static int check_map_errors(lk_handle* h) {
     unsigned int ctr[LK_CTR_COUNT];
     HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ctr[LK_CTR_ERR] & LK_E_SPEC_TIMEOUT) {
+        // not sticky: the word is cleared, so the handle stays usable once its map has been restored
+        const unsigned int rest = ctr[LK_CTR_ERR] & ~LK_E_SPEC_TIMEOUT;
+        HIPCHK(h, hipMemcpyAsync(h->map.counters + LK_CTR_ERR, &rest, sizeof(rest), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return fail(h, LK_ERR_TIMEOUT, "a wait between the filter and the insert side of the stream path timed out (device fault, or a pre-empted / debugged GPU; "
+                                       "LEGKILO_RESIDENT_TIMEOUT_MS raises the bound): the filter keeps its state from before the scan, the map may hold a partial "
+                                       "insert - restore it (lk_map_import) and replay the scan");
+    }
     if (ctr[LK_CTR_ERR]) {
         char buf[160];
-        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch, 32 insert-stream wait timed out)",
-                 ctr[LK_CTR_ERR]);
+        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch, 16 bad blob)", ctr[LK_CTR_ERR]);
         return fail(h, LK_ERR_CAPACITY, buf);
     }
     return LK_OK;
 }
 
 static int create_pools(lk_handle* h, const lk_config* cfg);
+static void ov_free(lk_handle* h);
 
 extern "C" {
 
@@ -330,6 +346,8 @@ void lk_destroy(lk_handle* h) {
     for (void* p : pre)
         if (p) hipFree(p);
     if (h->h_rag) hipHostFree(h->h_rag);
+    ov_free(h);
+    if (h->d_ov_status) hipFree(h->d_ov_status);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -792,7 +810,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 // the accesses became system-scope FLAT loads).  FLAG_WAIT: wave-uniform spin until the other side has posted `need`; evaluates to
 // false when the wait was given up - another wave has raised f_abort, or this one does after LK_RESIDENT_TIMEOUT ticks of the 100 MHz
 // clock (a device fault in the other role must fail the call, never hang the GPU): the caller leaves its bucket loop.
-#define LK_RESIDENT_TIMEOUT 200000000ull   // 2 s
+#define LK_RESIDENT_TIMEOUT_MS 2000u   // default bound of every wait inside the resident kernel (LEGKILO_RESIDENT_TIMEOUT_MS overrides)
 #define LK_SPIN_UNTIL(cond)                                                                                                  \
     ([&]() -> bool {                                                                                                          \
         unsigned long long t0_ = 0;                                                                                           \
@@ -803,7 +821,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
             if ((++spins_ & 1023u) == 0u) {                                                                                   \
                 const unsigned long long now_ = wall_clock64();                                                               \
                 if (t0_ == 0) t0_ = now_;                                                                                     \
-                else if (now_ - t0_ > LK_RESIDENT_TIMEOUT) {                                                                  \
+                else if (now_ - t0_ > resident_timeout_) {                                                                  \
                     __hip_atomic_store(&f_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                          \
                     if ((threadIdx.x & 63) == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SPEC_TIMEOUT);                      \
                     return false;                                                                                             \
@@ -828,7 +846,8 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 template <int MSG, bool XID>
 __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
-                          LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0) {
+                          LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0, unsigned int timeout_ms) {
+    const unsigned long long resident_timeout_ = (unsigned long long)timeout_ms * 100000ull;   // ticks of the 100 MHz wall clock
     __shared__ WaveSmem sm;
     __shared__ double rows[64 * LK_ROW2];
     __shared__ int f_post, f_decided, f_done;   // bucket index of: latest posterior snapshot / stamps final / insert complete
@@ -940,7 +959,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             }
             if (__ballot(susp) != 0ull) {
                 if (!FLAG_WAIT(f_done, b - 1)) break;
-                if (lane == 0) atomicAdd(&map.counters[LK_CTR_SPEC_REDO], 1u);
+                if (lane == 0) atomicAdd(&map.counters[LK_CTR_RES_REDO], 1u);
                 a0 = a1 = a2 = a3 = 0.0;
                 for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
                     __builtin_amdgcn_wave_barrier();
@@ -970,6 +989,9 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         FLAG_POST(f_post, b);
         ++b;
     }
+    // a wait was given up (a fault or a pre-empted GPU): the filter keeps its PRE-SCAN state - the call fails with LK_ERR_TIMEOUT, the
+    // map holds a partial insert (restore it from a checkpoint / blob and replay the scan)
+    if (__hip_atomic_load(&f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
     for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
     if (lane < 36) f->x[lane] = sm.x[lane];
     if (lane == 0) {
@@ -1000,6 +1022,12 @@ static int spec_join(lk_handle* h) {
     h->spec_base = h->epoch + 1;
     return LK_OK;
 }
+// every launch of the pipelined path is checked where it is issued (a bad launch configuration must name its kernel, not the last one)
+#define SPEC_LAUNCH(...)                                \
+    do {                                                \
+        __VA_ARGS__;                                    \
+        HIPCHK(h, hipGetLastError());                   \
+    } while (0)
 static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool xid) {
     const int nblk = (n + LK_PB - 1) / LK_PB;
     const int nblk_r = (n + LK_RB - 1) / LK_RB;
@@ -1023,36 +1051,36 @@ static int enqueue_bucket_spec(lk_handle* h, const lk_point* d_pts, int n, doubl
         HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_I, 0));
     }
     // insert stream, ahead of the posterior: the bucket's pool bookkeeping
-    hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->ins, m);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_bucket_begin_kernel, dim3(1), dim3(256), 0, h->ins, m));
     // main stream
-    hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_predict_kernel, dim3(1), dim3(LK_FB), 0, h->stream, h->d_filters, h->d_Q, t));
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
     ro.world = d_world;
     ro.ids = h->d_ids;
     if (first) {
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
-        hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
-                           h->part_stride, ro, (size_t)0);
+        SPEC_LAUNCH(hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
+                           h->part_stride, ro, (size_t)0));
     } else {
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true, true> : lk_residual_kernel<false, 0, false, true>;
-        hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
-                           h->part_stride, ro, (size_t)0);
+        SPEC_LAUNCH(hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n, h->d_partials,
+                           h->part_stride, ro, (size_t)0));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_D[(e - 1) & 1u], 0));
         const unsigned int from = std::max(e - 2, h->spec_base);
         const auto ver_kernel = xid ? lk_verify_kernel<true> : lk_verify_kernel<false>;
-        hipLaunchKernelGGL(ver_kernel, dim3(nblk_r), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, n, h->d_partials, ro, from, e - 1);
+        SPEC_LAUNCH(hipLaunchKernelGGL(ver_kernel, dim3(nblk_r), dim3(LK_RB), 0, h->stream, m, h->pr, h->d_filters, d_pts, n, h->d_partials, ro, from, e - 1));
     }
-    hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials, nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, 0.0, -1, snap);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials, nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, 0.0, -1, snap));
     HIPCHK(h, hipEventRecord(h->ev_U[e & 1u], h->stream));
     // insert stream: the bucket's insert, from the snapshot of its posterior
     HIPCHK(h, hipStreamWaitEvent(h->ins, h->ev_U[e & 1u], 0));
-    hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->ins, m, h->pr, snap, d_pts, n, d_world, 1);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_reproject_kernel, dim3(nblk), dim3(LK_PB), 0, h->ins, m, h->pr, snap, d_pts, n, d_world, 1));
     const int grid = std::min(std::max((n + 3) / 4, 1), 512);
-    hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_insert_root_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n));
     HIPCHK(h, hipEventRecord(h->ev_D[e & 1u], h->ins));   // the stamps are final: new roots (re-projection), roots whose planes may change (root pass)
-    hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
-    hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n);
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_insert_apply_kernel<false>, dim3(grid), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n));
+    SPEC_LAUNCH(hipLaunchKernelGGL(lk_insert_fallback_kernel<false>, dim3(std::min(grid, 8)), dim3(LK_MB), 0, h->ins, m, h->pr, snap, d_pts, (const lk_pt_rec*)nullptr, n));
     HIPCHK(h, hipEventRecord(h->ev_I, h->ins));
     HIPCHK(h, hipGetLastError());
     h->spec_open = true;
@@ -1105,6 +1133,11 @@ extern "C++" __global__ void __launch_bounds__(LK_WAVE)
 // predict -> residual (+A,b partials) -> 6x6 update -> re-project + hash -> per-root insert
 // t_next: time of the NEXT bucket if the caller knows that it follows directly (no IMU / kinematic message in between) and is itself
 // a large bucket - its predict then runs in this bucket's launch (`*pre_predicted` tells the next call) -, NaN otherwise.
+// dynamic-LDS padding knobs of the stream launches (placement experiments): clamped to what a workgroup may ask for on top of its static LDS
+static int lds_knob(const char* name) {
+    const char* e = getenv(name);
+    return e ? std::min(std::max(atoi(e), 0), 48 * 1024) : 0;
+}
 static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, float* d_world, bool do_insert, double t_next = NAN,
                           bool* pre_predicted = nullptr) {
     const LkMap& m = h->map;
@@ -1152,7 +1185,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         static const bool predict_in_root_on = getenv("LEGKILO_PREDICT_IN_ROOT") == nullptr || atoi(getenv("LEGKILO_PREDICT_IN_ROOT")) != 0;
         predict_in_root = fuse_next && do_insert && predict_in_root_on;   // n > LK_SMALL_MAX here: the insert below is the three-launch form
         const auto res_kernel = xid ? lk_residual_kernel<false, 0, true> : lk_residual_kernel<false, 0, false>;
-        static const int lds_res = getenv("LEGKILO_LDS_RES") ? atoi(getenv("LEGKILO_LDS_RES")) : 0;
+        static const int lds_res = lds_knob("LEGKILO_LDS_RES");
         LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), lds_res, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
                                                  h->d_partials, h->part_stride, ro, (size_t)0));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
@@ -1160,10 +1193,10 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         if (fuse_next) *pre_predicted = true;
         ins_filters = h->d_snap;
     }
-    static const int lds_rp = getenv("LEGKILO_LDS_REPROJ") ? atoi(getenv("LEGKILO_LDS_REPROJ")) : 0;
-    static const int lds_root = getenv("LEGKILO_LDS_ROOT") ? atoi(getenv("LEGKILO_LDS_ROOT")) : 0;
-    static const int lds_apply = getenv("LEGKILO_LDS_APPLY") ? atoi(getenv("LEGKILO_LDS_APPLY")) : 0;
-    static const int lds_rootp = getenv("LEGKILO_LDS_ROOTP") ? atoi(getenv("LEGKILO_LDS_ROOTP")) : 0;
+    static const int lds_rp = lds_knob("LEGKILO_LDS_REPROJ");
+    static const int lds_root = lds_knob("LEGKILO_LDS_ROOT");
+    static const int lds_apply = lds_knob("LEGKILO_LDS_APPLY");
+    static const int lds_rootp = lds_knob("LEGKILO_LDS_ROOTP");
     if ((d_world || do_insert) && !fuse)
         LAUNCH(h, "reproject", hipLaunchKernelGGL(lk_reproject_wave_kernel, dim3((n + LK_WAVE - 1) / LK_WAVE), dim3(LK_WAVE), lds_rp, h->stream, m, h->pr,
                                                   ins_filters, d_pts, n, d_world, do_insert ? 1 : 0));
@@ -1538,14 +1571,16 @@ static void fill_header(lk_handle* h, lk_blob_header& hd, const unsigned int* ct
     hd.max_points_num = h->cfg.max_points_num;
 }
 
-int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
-    CHECK_H(h);
+// host blob of one LkMap (the handle's map, or one slot's overlay): header | roots (sorted by key) | nodes | planes | blocks
+static int export_map_blob(lk_handle* h, const LkMap& m, unsigned int hash_cap, void* blob, size_t* bytes) {
     if (!bytes) return fail(h, LK_ERR_INVALID, "bytes is null");
     unsigned int ctr[LK_CTR_COUNT];
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(ctr, m.counters, sizeof(ctr), hipMemcpyDeviceToHost));
     lk_blob_header hd;
     fill_header(h, hd, ctr, LK_ABI_VERSION);
+    hd.n_nodes = std::min(ctr[LK_CTR_NODES], m.max_nodes);
+    hd.n_blocks = std::min(ctr[LK_CTR_BLOCKS], m.max_blocks);
     size_t total = sizeof(hd) + (size_t)hd.n_roots * sizeof(lk_root_rec) + (size_t)hd.n_nodes * (sizeof(lk_node_rec) + sizeof(lk_plane_rec)) +
                    (size_t)hd.n_blocks * sizeof(lk_block_rec);
     hd.bytes = total;
@@ -1554,8 +1589,8 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
         return LK_OK;
     }
     if (*bytes < total) return fail(h, LK_ERR_INVALID, "blob buffer too small");
-    std::vector<int4> table(h->hash_cap);
-    HIPCHK(h, hipMemcpy(table.data(), h->map.hash, sizeof(int4) * h->hash_cap, hipMemcpyDeviceToHost));
+    std::vector<int4> table(hash_cap);
+    HIPCHK(h, hipMemcpy(table.data(), m.hash, sizeof(int4) * hash_cap, hipMemcpyDeviceToHost));
     std::vector<lk_root_rec> roots;
     roots.reserve(hd.n_roots);
     for (const int4& e : table)
@@ -1569,13 +1604,23 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
     p += sizeof(hd);
     memcpy(p, roots.data(), roots.size() * sizeof(lk_root_rec));
     p += roots.size() * sizeof(lk_root_rec);
-    HIPCHK(h, hipMemcpy(p, h->map.nodes, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(p, m.nodes, (size_t)hd.n_nodes * sizeof(lk_node_rec), hipMemcpyDeviceToHost));
     p += (size_t)hd.n_nodes * sizeof(lk_node_rec);
-    HIPCHK(h, hipMemcpy(p, h->map.planes, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(p, m.planes, (size_t)hd.n_nodes * sizeof(lk_plane_rec), hipMemcpyDeviceToHost));
     p += (size_t)hd.n_nodes * sizeof(lk_plane_rec);
-    HIPCHK(h, hipMemcpy(p, h->map.blocks, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(p, m.blocks, (size_t)hd.n_blocks * sizeof(lk_block_rec), hipMemcpyDeviceToHost));
     *bytes = total;
     return LK_OK;
+}
+int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
+    CHECK_H(h);
+    return export_map_blob(h, h->map, h->hash_cap, blob, bytes);
+}
+// the voxels scan `slot` of the last overlay replay holds privately (the roots its inserts touched or created), as a map blob
+int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
+    CHECK_H(h);
+    if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
+    return export_map_blob(h, ov_slot_map(h->ov, slot), h->ov.hash_cap, blob, bytes);
 }
 
 // A blob is only usable by a handle configured like the one that wrote it: the voxel size defines the keys, max_layer
@@ -1888,12 +1933,13 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
     const unsigned int epoch0 = h->epoch + 1u;
     h->epoch += (unsigned int)nb;
     h->spec_base = h->epoch + 1u;
-    void (*k)(LkMap, LkParams, LkFilter*, const lk_point*, LkRagged, const double*, LkFilter*, float*, int2*, unsigned int) =
+    static const unsigned int timeout_ms = getenv("LEGKILO_RESIDENT_TIMEOUT_MS") ? (unsigned int)std::max(1, atoi(getenv("LEGKILO_RESIDENT_TIMEOUT_MS"))) : LK_RESIDENT_TIMEOUT_MS;
+    void (*k)(LkMap, LkParams, LkFilter*, const lk_point*, LkRagged, const double*, LkFilter*, float*, int2*, unsigned int, unsigned int) =
         msg_kind == 2 ? (xid ? lk_scan_stream_kernel<2, true> : lk_scan_stream_kernel<2, false>)
       : msg_kind == 1 ? (xid ? lk_scan_stream_kernel<1, true> : lk_scan_stream_kernel<1, false>)
                       : (xid ? lk_scan_stream_kernel<0, true> : lk_scan_stream_kernel<0, false>);
     LAUNCH(h, "scan_stream", hipLaunchKernelGGL(k, dim3(1), dim3((1 + LK_INS_WAVES) * LK_WAVE), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                                h->d_ids, epoch0));
+                                                h->d_ids, epoch0, timeout_ms));
     return LK_OK;
 }
 // a scan is taken by the resident kernel when all its buckets are small (LEGKILO_RESIDENT=0: always per-bucket launches)
@@ -1987,6 +2033,14 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     CHECK_H(h);
     if (n == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scan");
     if (n > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "scan exceeds max_scan_points");
+    if (!d_pts || !bucket_off || !bucket_dt) return fail(h, LK_ERR_INVALID, "null argument");
+    // the same table rules as the ragged batch entry, checked before any path is chosen: offsets non-decreasing and inside the scan,
+    // times finite and non-decreasing (KILO.cc:367-370 sorts the scan by time)
+    if (bucket_off[n_buckets] > n) return fail(h, LK_ERR_INVALID, "bucket offsets run past the scan");
+    for (size_t b = 0; b < n_buckets; ++b) {
+        if (bucket_off[b + 1] < bucket_off[b]) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing");
+        if (!std::isfinite(bucket_dt[b]) || (b > 0 && bucket_dt[b] < bucket_dt[b - 1])) return fail(h, LK_ERR_INVALID, "bucket times must be finite and non-decreasing");
+    }
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
     if (resident_enabled(h)) {
@@ -2724,6 +2778,185 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     return LK_OK;
 }
 
+// ------------------------------------------------------------------ batch replay with a per-scan insert overlay
+// (lk_overlay_kernels.h) KILO::process for every scan of the batch - predict, residual, update AND map insert per bucket (KILO.cc:108-233,
+// :375-395) - each scan on its own copy-on-write overlay of the handle's map, which itself stays untouched.
+static void ov_free(lk_handle* h) {
+    LkOverlay& o = h->ov;
+    void* ptrs[] = {o.hash, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    memset(&o, 0, sizeof(o));
+    h->ov_slots = 0;
+}
+static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap) {
+    // per-scan capacities: a 100 000-point scan touches ~13 000 root voxels of a young map (tools/overlay_sizing.py), one live point
+    // block each; lk_overlay_reserve overrides
+    const uint32_t roots = h->ov_want_roots ? h->ov_want_roots : (uint32_t)std::max<size_t>(1024, n_pts_scan / 6);
+    const uint32_t nodes = h->ov_want_nodes ? h->ov_want_nodes : roots + roots / 2;
+    const uint32_t blocks = h->ov_want_blocks ? h->ov_want_blocks : roots;
+    const uint32_t hash_cap = next_pow2(2u * roots);
+    const uint32_t scan_cap = (uint32_t)((biggest_bucket + 63) & ~(size_t)63);
+    const size_t cells = (size_t)fmap.gdim[0] * (size_t)fmap.gdim[1] * (size_t)fmap.gdim[2];
+    const uint32_t bit_words = (uint32_t)((cells + 31) / 32);
+    LkOverlay& o = h->ov;
+    if (S <= h->ov_slots && hash_cap <= o.hash_cap && nodes <= o.nodes_cap && blocks <= o.blocks_cap && scan_cap <= o.scan_cap && bit_words <= o.bit_words)
+        return LK_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t S2 = std::max(S, h->ov_slots);
+    LkOverlay n = {};
+    n.hash_cap = std::max(hash_cap, o.hash_cap), n.nodes_cap = std::max(nodes, o.nodes_cap), n.blocks_cap = std::max(blocks, o.blocks_cap);
+    n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
+    ov_free(h);
+    h->ov = n;
+    const size_t s = S2;
+    auto get = [&](auto** q, size_t bytes) -> hipError_t { return hipMalloc((void**)q, bytes); };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = get(&o.hash, s * n.hash_cap * sizeof(int4));
+    if (e == hipSuccess) e = get(&o.planes, s * n.nodes_cap * sizeof(lk_plane_rec));
+    if (e == hipSuccess) e = get(&o.match, s * n.nodes_cap * sizeof(lk_match_rec));
+    if (e == hipSuccess) e = get(&o.nodes, s * n.nodes_cap * sizeof(lk_node_rec));
+    if (e == hipSuccess) e = get(&o.blocks, s * n.blocks_cap * sizeof(lk_block_rec));
+    if (e == hipSuccess) e = get(&o.counters, s * LK_CTR_COUNT * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.touched, s * n.scan_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.next, s * n.scan_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.scratch, s * n.scan_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.gidx, s * n.scan_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.groups, s * n.scan_cap * 2 * sizeof(LkGroup));
+    if (e == hipSuccess) e = get(&o.slots, s * n.nodes_cap * LK_SLOTS * sizeof(int));
+    if (e == hipSuccess) e = get(&o.free_list, s * n.blocks_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.freed_next, s * n.blocks_cap * sizeof(int));
+    if (e == hipSuccess) e = get(&o.dirty, s * n.nodes_cap * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
+    if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ov_free(h);
+        char buf[256];
+        snprintf(buf, sizeof(buf), "overlay pools for %u scans (%u roots / %u nodes / %u point blocks each) do not fit: %s (lk_overlay_reserve sets smaller per-scan capacities)",
+                 S2, roots, n.nodes_cap, n.blocks_cap, hipGetErrorString(e));
+        return fail(h, LK_ERR_CAPACITY, buf);
+    }
+    h->ov_slots = S2;
+    return LK_OK;
+}
+
+int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per_scan, uint32_t blocks_per_scan) {
+    CHECK_H(h);
+    if ((roots_per_scan && roots_per_scan < 16) || (nodes_per_scan && nodes_per_scan < roots_per_scan) || (blocks_per_scan && blocks_per_scan < 16))
+        return fail(h, LK_ERR_INVALID, "overlay capacities too small (0 = derive from the scan size)");
+    h->ov_want_roots = roots_per_scan, h->ov_want_nodes = nodes_per_scan, h->ov_want_blocks = blocks_per_scan;
+    if (h->ov_slots) {   // pools of another shape are released; the next replay allocates what it needs
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        ov_free(h);
+    }
+    return LK_OK;
+}
+
+int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin, const uint32_t* bucket_off,
+                                const double* bucket_dt, size_t n_buckets, lk_pose* out) {
+    CHECK_H(h);
+    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
+    if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
+    if (!d_pts || !bucket_off || !bucket_dt) return fail(h, LK_ERR_INVALID, "null argument");
+    const int S = (int)n_scans;
+    std::vector<size_t> live;
+    size_t biggest = 0;
+    for (size_t b = 0; b < n_buckets; ++b) {
+        if (bucket_off[b + 1] < bucket_off[b] || bucket_off[b + 1] > n_pts) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing and end inside the scan");
+        if (!std::isfinite(bucket_dt[b]) || (b > 0 && bucket_dt[b] < bucket_dt[b - 1])) return fail(h, LK_ERR_INVALID, "bucket times must be finite and non-decreasing");
+        if (bucket_off[b + 1] == bucket_off[b]) continue;
+        if ((size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
+        biggest = std::max(biggest, (size_t)(bucket_off[b + 1] - bucket_off[b]));
+        live.push_back(b);
+    }
+    if (live.empty()) return fail(h, LK_ERR_INVALID, "empty scans");
+    int rc = join_side_streams(h);   // an asynchronous frozen-map batch may still be using the filter slots
+    if (rc) return rc;
+    LkMap fmap;
+    rc = frozen_map(h, &fmap);
+    if (rc) return rc;
+    if (!fmap.grid_on) return fail(h, LK_ERR_STATE, "overlay replay needs the frozen-map grid (root keys' bounding box too large, LEGKILO_GRID=0, or out of device memory)");
+    rc = ov_reserve(h, (uint32_t)S, n_pts, biggest, fmap);
+    if (rc) return rc;
+    const LkOverlay ov = h->ov;
+    hipStream_t st = h->stream;
+    rc = zero_scan_counters(h, 0, (uint32_t)S);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, h->d_filters, S, t_begin);
+    {
+        const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);
+        LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
+    }
+    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
+    LkFilter* fl = h->d_filters;
+    double* parts = h->d_partials;
+    for (size_t k = 0; k < live.size(); ++k) {
+        const size_t b = live[k];
+        const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
+        const double t = t_begin + bucket_dt[b];
+        const int nblk = (nb + LK_RB - 1) / LK_RB;
+        const lk_point* pts = d_pts + bucket_off[b];
+        if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
+        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb, parts, h->part_stride));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
+        // the bucket's insert into every slot's overlay, from the posterior (KILO.cc:216-233)
+        LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
+        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
+        const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
+        LAUNCH(h, "ov_cow", hipLaunchKernelGGL(lk_ov_cow_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov));
+        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(lk_ov_insert_root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        if (k + 1 < live.size())
+            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
+                                                    t_begin + bucket_dt[live[k + 1]], 2));
+    }
+    h->ov_last_slots = (uint32_t)S;
+    const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
+    unsigned int stt[8];
+    HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, st));
+    if (out) {
+        std::vector<lk_pose> tmp(n_scans);
+        rc = fetch_poses(h, tmp.data(), S);   // synchronises
+        if (rc) return rc;
+        memcpy(out, tmp.data(), sizeof(lk_pose) * n_scans);
+    } else {
+        HIPCHK(h, hipStreamSynchronize(st));
+    }
+    if (stt[0]) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots of %u / %u / %u per scan (lk_overlay_reserve)",
+                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.nodes_cap, ov.blocks_cap, ov.hash_cap / 2);
+        return fail(h, LK_ERR_CAPACITY, buf);
+    }
+    return LK_OK;
+}
+
+int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks) {
+    CHECK_H(h);
+    if (!h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay has run on this handle");
+    const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
+    unsigned int stt[8];
+    HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((h->ov_last_slots + 255u) / 256u, 64u)), dim3(256), 0, h->stream, h->ov, h->ov_last_slots, h->d_ov_status);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (max_nodes) *max_nodes = stt[1];
+    if (max_blocks) *max_blocks = stt[2];
+    if (max_roots) *max_roots = stt[3];
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------ measurement hooks
 int lk_profile_enable(lk_handle* h, int on) {
     CHECK_H(h);
@@ -2857,13 +3090,16 @@ int lk_stream_stats(lk_handle* h, uint64_t* out4) {
         hipMemcpyToSymbol(HIP_SYMBOL(lk_ev_hist), eh, sizeof(eh));
     }
 #endif
-    unsigned int redo = 0;
-    HIPCHK(h, hipMemcpyAsync(&redo, h->map.counters + LK_CTR_SPEC_REDO, sizeof(redo), hipMemcpyDeviceToHost, h->stream));
+    unsigned int redo[3] = {0, 0, 0};   // LK_CTR_SPEC_REDO, [13], LK_CTR_RES_REDO
+    HIPCHK(h, hipMemcpyAsync(redo, h->map.counters + LK_CTR_SPEC_REDO, sizeof(redo), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (redo < h->spec_redo_seen) h->spec_redo_seen = 0;          // the device word is reset with the pools (map import)
-    h->spec_redo_total += (uint64_t)(redo - h->spec_redo_seen);
-    h->spec_redo_seen = redo;
-    out4[0] = h->spec_buckets, out4[1] = h->spec_tiles, out4[2] = h->spec_redo_total, out4[3] = 0;
+    if (redo[0] < h->spec_redo_seen) h->spec_redo_seen = 0;          // the device words are reset with the pools (map import)
+    h->spec_redo_total += (uint64_t)(redo[0] - h->spec_redo_seen);
+    h->spec_redo_seen = redo[0];
+    if (redo[2] < h->res_redo_seen) h->res_redo_seen = 0;
+    h->res_redo_total += (uint64_t)(redo[2] - h->res_redo_seen);
+    h->res_redo_seen = redo[2];
+    out4[0] = h->spec_buckets, out4[1] = h->spec_tiles, out4[2] = h->spec_redo_total, out4[3] = h->res_redo_total;
     return LK_OK;
 }
 void* lk_stream(lk_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -41,6 +41,8 @@ enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK
        LK_CTR_HEAVY = 6, LK_CTR_FREE = 7 /* signed: blocks poppable this bucket */, LK_CTR_FREED = 8 /* blocks retired
        during this bucket */, LK_CTR_GROUPS = 9 /* leaf groups of this bucket */, LK_CTR_GIDX = 10 /* their indices */, LK_CTR_FALLBACK = 11 /* groups handed to the generic code */,
        LK_CTR_SPEC_REDO = 12 /* cumulative: tiles the verify pass of the pipelined stream path evaluated again */,
+       /* 13: LK_CTR_NODES0 of a private overlay map (lk_overlay_kernels.h) */
+       LK_CTR_RES_REDO = 14 /* cumulative: buckets the scan-resident stream kernel evaluated again after a conflicting insert */,
        LK_CTR_COUNT = 16 };
 
 struct LkFilter {

@@ -42,6 +42,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // the second), so the count halves with every step: ceil(N/2) + ceil(N/4) + ... exchanges instead of 6 N (N = 21: 24 instead of
 // 126; N = 9: 13 instead of 54), after which lane L holds the complete sum of ONE component, and N more shuffles gather them.
 // The summation order differs from wave_sum's butterfly (a different, equally valid rounding of the same sum).
+#ifndef LK_WSN_READLANE
+#define LK_WSN_READLANE 0
+#endif
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double* v) {
     const int lane = threadIdx.x & 63;
@@ -76,7 +79,11 @@ __device__ __forceinline__ void wave_sum_n(double* v) {
         // gathered with ds_bpermute, not v_readlane: 2 N scalar results at once (N = 21: 42 SGPRs on top of a kernel that already
         // spills scalars) gave wrong values in lk_insert_root_kernel - varying with unrelated code changes - while the vector form
         // is stable (round 3, tools A/B: -DLK_READLANE=0 fixed every failing test)
+#if LK_WSN_READLANE
+        r[c] = lane_bcast_u(v[0], src);    // A/B build only (tools/probes/readlane_gather): the v_readlane form of the gather
+#else
         r[c] = __shfl(v[0], src, LK_WAVE);
+#endif
     }
 #pragma unroll
     for (int c = 0; c < N; ++c) v[c] = r[c];

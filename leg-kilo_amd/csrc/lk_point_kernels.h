@@ -220,6 +220,7 @@ __device__ __forceinline__ bool match_flat(const LkMap& m, int cell, const Point
 
 // Root voxel of a key for the matcher: index into m.match[] (a node id from the hash table, or a grid cell), -1 = none.
 // GRID: 0 = hash table (compile-time), 1 = frozen-map grid (compile-time), 2 = decided by m.grid_on at run time
+// (3 = frozen-map grid + one slot's insert overlay: find_root_ov below)
 template <int GRID>
 __device__ __forceinline__ int find_root(const LkMap& m, int kx, int ky, int kz) {
     if (GRID == 1 || (GRID == 2 && m.grid_on)) {
@@ -228,6 +229,33 @@ __device__ __forceinline__ int find_root(const LkMap& m, int kx, int ky, int kz)
         return (int)(m.grid_base + (uz * (unsigned int)m.gdim[1] + uy) * (unsigned int)m.gdim[0] + ux);
     }
     return hash_find(m, kx, ky, kz);  // KILO.cc:149
+}
+
+// Batch replay with a per-scan insert overlay (lk_overlay_kernels.h): what the residual pass needs of ONE slot's private map.
+struct LkOvView {
+    const int4* hash;              // the slot's private root table
+    unsigned int hash_mask;
+    const lk_match_rec* match;     // the slot's private match / node pools (ids are slot-local)
+    const lk_node_rec* nodes;
+    const unsigned int* bits;      // one bit per base grid cell: the slot has a private root at that key
+};
+// Root of a key for the overlay matcher: >= 0 a cell of the base map's frozen grid (match_flat), <= -2 the private root
+// -2 - code of the slot (match_root on the private pools), -1 none.  The bit of the key's cell is requested together with
+// nothing else depending on it; only a set bit (the scan has inserted into that voxel) costs the trip to the private table.
+__device__ __forceinline__ int find_root_ov(const LkMap& base, const LkOvView& ov, int kx, int ky, int kz) {
+    const unsigned int ux = (unsigned int)(kx - base.gmin[0]), uy = (unsigned int)(ky - base.gmin[1]), uz = (unsigned int)(kz - base.gmin[2]);
+    const bool in = ux < (unsigned int)base.gdim[0] && uy < (unsigned int)base.gdim[1] && uz < (unsigned int)base.gdim[2];
+    unsigned int cell = 0;
+    if (in) {
+        cell = (uz * (unsigned int)base.gdim[1] + uy) * (unsigned int)base.gdim[0] + ux;
+        if (!((ov.bits[cell >> 5] >> (cell & 31u)) & 1u)) return (int)(base.grid_base + cell);
+    }
+    LkMap pm = {};
+    pm.hash = const_cast<int4*>(ov.hash);
+    pm.hash_mask = ov.hash_mask;
+    const int r = hash_find(pm, kx, ky, kz);
+    if (r >= 0) return -2 - r;
+    return in ? (int)(base.grid_base + cell) : -1;
 }
 
 // KILO.cc:156-172: key of the ONE neighbour voxel that is tried when the home voxel gave no match.  loc is in
@@ -289,7 +317,7 @@ __device__ __forceinline__ bool spec_suspect(const LkMap& m, int code, unsigned 
 template <bool EMIT_ROWS, int GRID = 2, bool XID = false, bool SHORT = false, bool SPEC = false>
 __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams& pr, const BucketConst& bc,
                                                 const float4* __restrict__ spts, int i, int n, double* rows, int lane,
-                                                const ResidualOut& out, size_t out_base) {
+                                                const ResidualOut& out, size_t out_base, const LkOvView* ovv = nullptr) {
     bool ok = false;
     double h[6] = {0, 0, 0, 0, 0, 0}, z = 0, R = 0;
     {
@@ -305,7 +333,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             float loc[3];
             int key[3];
             key_trunc(g.p_w, pr, loc, key);
-            root = find_root<GRID>(map, key[0], key[1], key[2]);  // KILO.cc:149
+            root = GRID == 3 ? find_root_ov(map, *ovv, key[0], key[1], key[2]) : find_root<GRID>(map, key[0], key[1], key[2]);  // KILO.cc:149
             // stored at once (not carried through the match): registers set this kernel's occupancy
             if (SPEC) out.ids[out_base + i] = make_int2(spec_code(root, key), LK_SPEC_NONE);
         }
@@ -314,9 +342,12 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         double prob = 0;
         Match best;
         best.row = rows + lane * LK_ROW2;
-        const bool grid_cell = GRID == 1 || (GRID == 2 && map.grid_on != 0);
+        const bool grid_cell = GRID == 1 || GRID == 3 || (GRID == 2 && map.grid_on != 0);
         bool home = false;
+        LkMap pmv = {};   // GRID == 3: the slot's private pools (match_root reads match[] and nodes[].child only)
+        if (GRID == 3) pmv.match = const_cast<lk_match_rec*>(ovv->match), pmv.nodes = const_cast<lk_node_rec*>(ovv->nodes);
         if (root >= 0) home = grid_cell ? match_flat<XID>(map, root, g, bc, pr, success, prob, best) : match_root<XID>(map, root, false, g, bc, pr, success, prob, best);
+        else if (GRID == 3 && root <= -2) home = match_root<XID>(pmv, -2 - root, false, g, bc, pr, success, prob, best);
         // the one-neighbour retry (KILO.cc:156-178): only when the home voxel EXISTS (the lookup at KILO.cc:149 found a tree)
         if (home && !success && !LK_X_NORETRY) {
             float loc[3];     // re-derived here rather than kept alive across the home voxel's walk
@@ -325,12 +356,14 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             neighbour_key(pr, loc, key, near);
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) {
-                nroot = find_root<GRID>(map, near[0], near[1], near[2]);
+                nroot = GRID == 3 ? find_root_ov(map, *ovv, near[0], near[1], near[2]) : find_root<GRID>(map, near[0], near[1], near[2]);
                 if (SPEC) out.ids[out_base + i].y = spec_code(nroot, near);
             }
             if (nroot >= 0) {
                 if (grid_cell) match_flat<XID>(map, nroot, g, bc, pr, success, prob, best);
                 else match_root<XID>(map, nroot, false, g, bc, pr, success, prob, best);
+            } else if (GRID == 3 && nroot <= -2) {
+                match_root<XID>(pmv, -2 - nroot, false, g, bc, pr, success, prob, best);
             }
         }
         ok = success;

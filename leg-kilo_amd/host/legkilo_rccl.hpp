@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 
@@ -32,6 +33,24 @@ inline void lkCheck(lk_handle* h, int rc, const char* what) {
     if (rc != LK_OK) throw std::runtime_error(std::string(what) + ": " + lk_last_error(h));
 }
 
+// Device memory of the HANDLE's device (lk_device_malloc selects it: a rank that has made no lk_* call yet may have another device
+// current), released on every path out of a scope - an exception between two collectives must not leak the staging buffers.
+class DeviceBuf {
+  public:
+    DeviceBuf(lk_handle* h, size_t bytes) : h_(h) { lkCheck(h, lk_device_malloc(h, &p_, bytes ? bytes : 16), "lk_device_malloc"); }
+    ~DeviceBuf() {
+        if (p_) lk_device_free(h_, p_);
+    }
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+    template <typename T>
+    T* as() const { return static_cast<T*>(p_); }
+
+  private:
+    lk_handle* h_;
+    void* p_ = nullptr;
+};
+
 inline void shardRange(size_t n_total, int rank, int world, size_t* start, size_t* stop) {
     const size_t base = n_total / (size_t)world, rem = n_total % (size_t)world;
     *start = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
@@ -40,7 +59,9 @@ inline void shardRange(size_t n_total, int rank, int world, size_t* start, size_
 
 enum class MapTransport { ring, scatter_allgather };
 
-// Returns the blob size in bytes.  Collective: every rank of `comm` calls it with its own handle.
+// Returns the blob size in bytes.  Collective: every rank of `comm` calls it with its own handle.  An exception thrown here (a HIP, RCCL
+// or lk_* failure on THIS rank) releases this rank's buffers, but the peers may be left inside a collective: treat it as fatal for the
+// communicator (ncclCommAbort) - there is no partial map on any rank, lk_map_import_dev replaces a map only after validating the blob.
 inline size_t broadcastMap(lk_handle* h, ncclComm_t comm, int rank, int world, int src, MapTransport how = MapTransport::scatter_allgather) {
     hipStream_t st = static_cast<hipStream_t>(lk_stream(h));
     unsigned long long nbytes = 0;
@@ -49,37 +70,34 @@ inline size_t broadcastMap(lk_handle* h, ncclComm_t comm, int rank, int world, i
         lkCheck(h, lk_map_export_dev(h, nullptr, &b), "lk_map_export_dev (size)");
         nbytes = b;
     }
-    unsigned long long* d_n = nullptr;
-    hipCheckRt(hipMalloc(&d_n, sizeof(*d_n)), "hipMalloc");
-    hipCheckRt(hipMemcpyAsync(d_n, &nbytes, sizeof(nbytes), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
-    rcclCheck(ncclBroadcast(d_n, d_n, 1, ncclUint64, src, comm, st), "ncclBroadcast (size)");
-    hipCheckRt(hipMemcpyAsync(&nbytes, d_n, sizeof(nbytes), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-    hipCheckRt(hipStreamSynchronize(st), "hipStreamSynchronize");
-    hipCheckRt(hipFree(d_n), "hipFree");
+    {
+        DeviceBuf d_n(h, sizeof(nbytes));
+        hipCheckRt(hipMemcpyAsync(d_n.as<void>(), &nbytes, sizeof(nbytes), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        rcclCheck(ncclBroadcast(d_n.as<void>(), d_n.as<void>(), 1, ncclUint64, src, comm, st), "ncclBroadcast (size)");
+        hipCheckRt(hipMemcpyAsync(&nbytes, d_n.as<void>(), sizeof(nbytes), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+        hipCheckRt(hipStreamSynchronize(st), "hipStreamSynchronize");
+    }
+    if (nbytes == 0) return 0;   // (cannot happen with lk_map_export_dev - an empty map still has a header and its hash table - but a size of 0 must not reach the import)
     const size_t per = (nbytes + (size_t)world - 1) / (size_t)world;   // slice of the scatter + all-gather form
-    unsigned char* blob = nullptr;
-    hipCheckRt(hipMalloc(&blob, per * (size_t)world + 16), "hipMalloc (blob)");
+    DeviceBuf blob(h, per * (size_t)world + 16);
     if (rank == src) {
         size_t b = nbytes;
-        lkCheck(h, lk_map_export_dev(h, blob, &b), "lk_map_export_dev");
+        lkCheck(h, lk_map_export_dev(h, blob.as<void>(), &b), "lk_map_export_dev");
     }
     if (how == MapTransport::ring || world == 1) {
-        rcclCheck(ncclBroadcast(blob, blob, nbytes, ncclUint8, src, comm, st), "ncclBroadcast (blob)");
+        rcclCheck(ncclBroadcast(blob.as<void>(), blob.as<void>(), nbytes, ncclUint8, src, comm, st), "ncclBroadcast (blob)");
     } else {
-        unsigned char* mine = nullptr;
-        hipCheckRt(hipMalloc(&mine, per), "hipMalloc (slice)");
+        DeviceBuf mine(h, per);
         rcclCheck(ncclGroupStart(), "ncclGroupStart");
         if (rank == src)
-            for (int r = 0; r < world; ++r) rcclCheck(ncclSend(blob + (size_t)r * per, per, ncclUint8, r, comm, st), "ncclSend");
-        rcclCheck(ncclRecv(mine, per, ncclUint8, src, comm, st), "ncclRecv");
+            for (int r = 0; r < world; ++r) rcclCheck(ncclSend(blob.as<unsigned char>() + (size_t)r * per, per, ncclUint8, r, comm, st), "ncclSend");
+        rcclCheck(ncclRecv(mine.as<void>(), per, ncclUint8, src, comm, st), "ncclRecv");
         rcclCheck(ncclGroupEnd(), "ncclGroupEnd");
-        rcclCheck(ncclAllGather(mine, blob, per, ncclUint8, comm, st), "ncclAllGather (blob)");
-        hipCheckRt(hipStreamSynchronize(st), "hipStreamSynchronize");
-        hipCheckRt(hipFree(mine), "hipFree");
+        rcclCheck(ncclAllGather(mine.as<void>(), blob.as<void>(), per, ncclUint8, comm, st), "ncclAllGather (blob)");
+        hipCheckRt(hipStreamSynchronize(st), "hipStreamSynchronize");   // `mine` is released at the end of this scope
     }
-    if (rank != src) lkCheck(h, lk_map_import_dev(h, blob, nbytes), "lk_map_import_dev");
+    if (rank != src) lkCheck(h, lk_map_import_dev(h, blob.as<void>(), nbytes), "lk_map_import_dev");
     hipCheckRt(hipStreamSynchronize(st), "hipStreamSynchronize");
-    hipCheckRt(hipFree(blob), "hipFree");
     return (size_t)nbytes;
 }
 

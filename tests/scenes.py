@@ -221,6 +221,34 @@ def maps_identical(blob_a, blob_b):
     return len(A)
 
 
+def subtree_sig(node):
+    """Hashable digest of a canon_map node and everything below it: counters, state bits, stored points, tree shape."""
+    return (node["layer"], node["npts"], node["new_points"], node["state"], node["is_plane"],
+            None if node["pts"] is None else node["pts"].tobytes(),
+            bytes(node["plane"]["plane_var"].tobytes()) if node["is_plane"] else None,
+            tuple((k, subtree_sig(v)) for k, v in sorted(node["children"].items())))
+
+
+def compare_overlay(overlay_blob, base_canon, after_canon, where, rtol=1e-6, ptol=1e-9):
+    """One scan's insert overlay (lk_overlay_export) against the map a checker holds AFTER replaying that scan alone on a private
+    copy of the base map: every private voxel equals the checker's voxel of that key (tree shape, counters, state bits exactly;
+    planes and points to the tolerances of compare_nodes), and every voxel the checker changed or created is private."""
+    ov = canon_map(overlay_blob)
+    stats = {}
+    for key, node in ov.items():
+        assert key in after_canon, (where, "private voxel the checker does not have", key)
+        compare_nodes(node, after_canon[key], (where, key), rtol, stats, ptol)
+    changed = 0
+    for key, node in after_canon.items():
+        if key in base_canon and subtree_sig(node) == subtree_sig(base_canon[key]):
+            continue
+        changed += 1
+        assert key in ov, (where, "voxel changed by the checker's insert but not private on the device", key)
+    stats["private_roots"] = len(ov)
+    stats["changed_roots"] = changed
+    return stats
+
+
 def rows_close(h6a, za, Ra, h6b, zb, Rb, valid, rtol=1e-9):
     """Compare observation rows up to the per-row sign of the plane normal."""
     v = valid.astype(bool)

@@ -818,6 +818,147 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     o.close()
 
 
+def test_config5_full_size_batch(big, oracle_lib, hip_lib):
+    """Config 5 at its stated per-scan size through the graded entry: 64 filter slots x 100 000 points x 5 buckets of 20 000 on the
+    asynchronous batch entry bench.py times (two batches in flight on two slot ranges), against the oracle replaying every slot on
+    the DEVICE's map blob: counts exact, positions and rotations to 1e-9.  (16 distinct scans, each replayed from four different
+    priors - generating a 100 000-point ray-cast scan costs 0.4 s of host time.)"""
+    scene, o_big, _, t0 = big
+    S, U, n_pts = 64, 16, 100000
+    blob = o_big.map_export()
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=2 * S))
+    g.map_import(blob)
+    g.init_process_cov_q()
+    dev_blob = g.map_export()        # what the device holds (ids may differ from the oracle's export; the voxels are the same)
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    o.init_process_cov_q()
+    o.map_import(dev_blob)
+    o.set_map_insert(False)
+    rng = np.random.default_rng(646464)
+    tbs = [t0 + 0.9 + 0.13 * u for u in range(U)]
+    scans = [synth.dense_scan(scene.world, scene.traj, tbs[u], scene.P, n=n_pts, n_buckets=5, seed_scan=6405 + u, seed_noise=6506 + u) for u in range(U)]
+    off, dt = synth.buckets_of(scans[0])
+    tile = np.arange(S) % U
+    xs = np.stack([synth.initial_state(scene.traj, tbs[tile[s]], scene.P, rng, 0.02, 0.5) for s in range(S)])
+    Ps = np.tile((1e-4 * np.eye(30)).reshape(1, 900), (S, 1))
+    allpts = np.concatenate([scans[u] for u in tile])
+    d_pts, d_x, d_P = g.device_malloc(allpts.nbytes), g.device_malloc(xs.nbytes), g.device_malloc(Ps.nbytes)
+    g.h2d(d_pts, allpts)
+    g.h2d(d_x, np.ascontiguousarray(xs))
+    g.h2d(d_P, np.ascontiguousarray(Ps))
+    outs = [np.zeros(S, dtype=abi.pose_dtype()) for _ in range(2)]
+    for k in range(2):
+        g.batch_replay_async_dev(d_pts, k * S, S, n_pts, 0.0, off, dt, d_x36=d_x, d_P900=d_P, host_out_ptr=outs[k].ctypes.data)
+    g.synchronize()
+    for f in ("rot", "pos", "vel", "n_effect", "n_buckets", "n_updates"):
+        assert np.array_equal(outs[0][f], outs[1][f]), f
+    worst = 0.0
+    for s in range(S):
+        o.set_state(xs[s], Ps[s].reshape(30, 30))
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(scans[tile[s]], 0.0)
+        r = outs[0][s]
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (int(r["n_buckets"]), int(r["n_updates"]), int(r["n_effect"])), (s, po.n_effect, r["n_effect"])
+        d = max(float(np.abs(np.array(po.pos) - r["pos"]).max()), float(np.abs(np.array(po.rot) - r["rot"]).max()))
+        worst = max(worst, d)
+        assert d < 1e-9, (s, d)
+    print("config 5 at full size: 64 slots, counts exact, worst pose delta", worst)
+    for d in (d_pts, d_x, d_P):
+        g.device_free(d)
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("case", ["scattered", "sectors", "tiny"])
+def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
+    """Batch replay WITH the map insert (lk_batch_replay_overlay_dev, SURVEY 8d config 5 "scan-local insert overlay"): every scan
+    of the batch runs KILO::process's whole bucket loop - predict, residual, update, re-projection + UpdateVoxelMap per bucket
+    (KILO.cc:108-233, :375-395) - on its own copy-on-write overlay of the shared map.  Per slot the checker is the oracle on a
+    private copy of that map (lko_map_import of the same blob, insert ON): identical counts, every state entry to 1e-6, and the
+    slot's private voxels (lk_overlay_export) equal the oracle's voxels of those keys - tree shape, counters and state bits
+    exactly - while every voxel the oracle changed or created is private on the device.  The handle's own map stays untouched.
+      scattered: the buckets are a random partition of the scan (every bucket's insert refits / creates planes the next bucket
+                 matches) on a young map - the overlay lookup path of the residual pass is what decides the counts;
+      sectors:   config 5's shape at full size (100 000 points, 5 azimuth sectors of 20 000);
+      tiny:      12 buckets of 40..90 points, one scan of a single bucket's worth of new voxels."""
+    if case == "sectors":
+        S, n_pts, nb, young = 3, 100000, 5, False
+    elif case == "scattered":
+        S, n_pts, nb, young = 4, 30000, 5, True
+    else:
+        S, n_pts, nb, young = 5, 800, 12, True
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    t0 = 21.0
+    x0 = scenes.init_filter(o, scene, t0)
+    scenes.first_frame(o, scene, t0, x0, dense=20000 if young else 100000)
+    if not young:
+        for k in range(3):   # a few full scans with insert: frozen leaves, refitted planes, cut voxels
+            tb = t0 + 0.1 * (k + 1)
+            o.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30))
+            o.set_times(tb, tb)
+            o.process_scan(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=3100 + k, seed_noise=3200 + k), tb)
+    blob = o.map_export()
+    g.map_import(blob)
+    g.init_process_cov_q()
+    base = scenes.canon_map(blob)
+    rng = np.random.default_rng(515151)
+    xs, Ps, scans = [], [], []
+    for s in range(S):
+        tb = t0 + 0.5 + 0.21 * s
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=7005 + s, seed_noise=7106 + s)
+        if case != "sectors":
+            curv = pts["curvature"].copy()
+            pts = pts[rng.permutation(len(pts))]
+            pts["curvature"] = curv
+        scans.append(pts)
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+    off, dt = synth.buckets_of(scans[0])
+    for sc in scans:
+        o2, d2 = synth.buckets_of(sc)
+        assert np.array_equal(o2, off) and np.array_equal(d2, dt)
+    allpts = np.concatenate(scans)
+    d_pts = g.device_malloc(allpts.nbytes)
+    g.h2d(d_pts, allpts)
+    g.batch_set_priors(np.array(xs), np.array(Ps))
+    frozen = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
+    n_eff_frozen = [int(p.n_effect) for p in frozen]
+    g.batch_set_priors(np.array(xs), np.array(Ps))
+    poses = g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
+    Xall, Pall = g.batch_get_states(0, S)
+    # the shared map is untouched, and a second replay gives the same bits (the overlays start empty every time)
+    assert np.array_equal(g.map_export(), np.frombuffer(blob, dtype=np.uint8)) or scenes.maps_identical(g.map_export(), blob)
+    g.batch_set_priors(np.array(xs), np.array(Ps))
+    poses2 = g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
+    X2, P2 = g.batch_get_states(0, S)
+    assert np.array_equal(Xall, X2) and np.array_equal(Pall, P2)
+    assert [int(p.n_effect) for p in poses] == [int(p.n_effect) for p in poses2]
+    g.device_free(d_pts)
+    differs = 0
+    for s in range(S):
+        o.map_import(blob)
+        o.set_map_insert(True)
+        o.set_state(xs[s], Ps[s])
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(scans[s], 0.0)
+        xo, Po = o.get_state()
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (poses[s].n_buckets, poses[s].n_updates, int(poses[s].n_effect)), \
+            (case, s, po.n_buckets, po.n_updates, po.n_effect, poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect, n_eff_frozen[s])
+        assert np.abs(xo - Xall[s]).max() < 1e-6, (case, s, np.abs(xo - Xall[s]).max())
+        assert np.abs(Pall[s] - Po).max() <= 1e-6 * np.abs(Po).max(), (case, s)
+        st = scenes.compare_overlay(g.overlay_export(s), base, scenes.canon_map(o.map_export()), (case, s), rtol=1e-5, ptol=1e-7)
+        assert st["private_roots"] > 0 and st["changed_roots"] > 0, (case, s, st)
+        differs += int(int(po.n_effect) != n_eff_frozen[s])
+        print(f"overlay {case} slot {s}: n_effect {int(po.n_effect)} (frozen map: {n_eff_frozen[s]}), private roots {st['private_roots']}, "
+              f"changed by the oracle {st['changed_roots']}, nodes compared {st.get('nodes', 0)}, max |dx| {np.abs(xo - Xall[s]).max():.2e}")
+    if case == "scattered":   # the insert really changed what later buckets matched
+        assert differs == S, (differs, S)
+    print("overlay high-water marks (roots, nodes, blocks):", g.overlay_stats())
+    g.close()
+    o.close()
+
+
 def test_frozen_grid_equals_hash_and_follows_the_map(scene, oracle_lib, hip_lib, monkeypatch):
     """Batch replay looks root voxels up through the frozen-map grid (dense array of root records + flattened subtree lists,
     rebuilt when the map changes) and runs the kernel specialised for ext_R == I; LEGKILO_GRID=0 / LEGKILO_XID=0 keep the hash
