@@ -1616,11 +1616,30 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
     CHECK_H(h);
     return export_map_blob(h, h->map, h->hash_cap, blob, bytes);
 }
-// the voxels scan `slot` of the last overlay replay holds privately (the roots its inserts touched or created), as a map blob
+// the voxels scan `slot` of the last overlay replay holds privately (the roots its inserts touched or created), as a map blob: the
+// slot's key table is turned into the int4 form the exporter reads (entry index = root node id)
 int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
     CHECK_H(h);
     if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
-    return export_map_blob(h, ov_slot_map(h->ov, slot), h->ov.hash_cap, blob, bytes);
+    const LkOverlay& ov = h->ov;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> keys(ov.hash_cap);
+    HIPCHK(h, hipMemcpy(keys.data(), ov.keys + (size_t)slot * ov.hash_cap, sizeof(unsigned long long) * ov.hash_cap, hipMemcpyDeviceToHost));
+    std::vector<int4> table(ov.hash_cap);
+    for (unsigned int i = 0; i < ov.hash_cap; ++i) {
+        if (keys[i] == LK_OV_EMPTY) {
+            table[i] = make_int4(INT_MIN, INT_MIN, INT_MIN, LK_EMPTY);
+        } else {
+            int k3[3];
+            ov_unpack_key(keys[i], k3);
+            table[i] = make_int4(k3[0], k3[1], k3[2], (int)i);
+        }
+    }
+    LkMap m = ov_slot_map(ov, slot);
+    DevTemps tmp;
+    HIPCHK(h, tmp.alloc(&m.hash, sizeof(int4) * ov.hash_cap));
+    HIPCHK(h, hipMemcpy(m.hash, table.data(), sizeof(int4) * ov.hash_cap, hipMemcpyHostToDevice));
+    return export_map_blob(h, m, ov.hash_cap, blob, bytes);
 }
 
 // A blob is only usable by a handle configured like the one that wrote it: the voxel size defines the keys, max_layer
@@ -2783,7 +2802,7 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
 // :375-395) - each scan on its own copy-on-write overlay of the handle's map, which itself stays untouched.
 static void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
-    void* ptrs[] = {o.hash, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
+    void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
                     o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -2791,29 +2810,30 @@ static void ov_free(lk_handle* h) {
     h->ov_slots = 0;
 }
 static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap) {
-    // per-scan capacities: a 100 000-point scan touches ~13 000 root voxels of a young map (tools/overlay_sizing.py), one live point
-    // block each; lk_overlay_reserve overrides
-    const uint32_t roots = h->ov_want_roots ? h->ov_want_roots : (uint32_t)std::max<size_t>(1024, n_pts_scan / 6);
-    const uint32_t nodes = h->ov_want_nodes ? h->ov_want_nodes : roots + roots / 2;
+    // per-scan capacities: a 100 000-point scan touches ~13 000 root voxels of a young map, ~4 700 of the bench's mature one, one live
+    // point block each (measured: extra.overlay_private_per_scan_max); lk_overlay_reserve overrides
+    const uint32_t roots = h->ov_want_roots ? h->ov_want_roots : (uint32_t)std::min<size_t>(std::max<size_t>(8192, n_pts_scan / 6), std::max<size_t>(1024, n_pts_scan));
+    const uint32_t nodes = h->ov_want_nodes ? std::max(h->ov_want_nodes, roots + 64u) : roots + roots / 2;
     const uint32_t blocks = h->ov_want_blocks ? h->ov_want_blocks : roots;
-    const uint32_t hash_cap = next_pow2(2u * roots);
+    const uint32_t hash_cap = next_pow2(2u * roots);          // the roots' records ARE the table entries: node ids [0, hash_cap)
+    const uint32_t nodes_cap = hash_cap + (nodes - roots);    // children from hash_cap upwards
     const uint32_t scan_cap = (uint32_t)((biggest_bucket + 63) & ~(size_t)63);
     const size_t cells = (size_t)fmap.gdim[0] * (size_t)fmap.gdim[1] * (size_t)fmap.gdim[2];
     const uint32_t bit_words = (uint32_t)((cells + 31) / 32);
     LkOverlay& o = h->ov;
-    if (S <= h->ov_slots && hash_cap <= o.hash_cap && nodes <= o.nodes_cap && blocks <= o.blocks_cap && scan_cap <= o.scan_cap && bit_words <= o.bit_words)
+    if (S <= h->ov_slots && hash_cap == o.hash_cap && nodes_cap <= o.nodes_cap && blocks <= o.blocks_cap && scan_cap <= o.scan_cap && bit_words <= o.bit_words)
         return LK_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const uint32_t S2 = std::max(S, h->ov_slots);
     LkOverlay n = {};
-    n.hash_cap = std::max(hash_cap, o.hash_cap), n.nodes_cap = std::max(nodes, o.nodes_cap), n.blocks_cap = std::max(blocks, o.blocks_cap);
-    n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
+    n.hash_cap = hash_cap, n.nodes_cap = std::max(nodes_cap, hash_cap + (o.nodes_cap > o.hash_cap ? o.nodes_cap - o.hash_cap : 0u));
+    n.blocks_cap = std::max(blocks, o.blocks_cap), n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
     ov_free(h);
     h->ov = n;
     const size_t s = S2;
     auto get = [&](auto** q, size_t bytes) -> hipError_t { return hipMalloc((void**)q, bytes); };
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = get(&o.hash, s * n.hash_cap * sizeof(int4));
+    if (e == hipSuccess) e = get(&o.keys, s * n.hash_cap * sizeof(unsigned long long));
     if (e == hipSuccess) e = get(&o.planes, s * n.nodes_cap * sizeof(lk_plane_rec));
     if (e == hipSuccess) e = get(&o.match, s * n.nodes_cap * sizeof(lk_match_rec));
     if (e == hipSuccess) e = get(&o.nodes, s * n.nodes_cap * sizeof(lk_node_rec));
@@ -2824,10 +2844,10 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.scratch, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.gidx, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.groups, s * n.scan_cap * 2 * sizeof(LkGroup));
-    if (e == hipSuccess) e = get(&o.slots, s * n.nodes_cap * LK_SLOTS * sizeof(int));
+    if (e == hipSuccess) e = get(&o.slots, s * n.hash_cap * LK_SLOTS * sizeof(int));
     if (e == hipSuccess) e = get(&o.free_list, s * n.blocks_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.freed_next, s * n.blocks_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.dirty, s * n.nodes_cap * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.dirty, s * n.hash_cap * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
@@ -2837,10 +2857,12 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
         ov_free(h);
         char buf[256];
         snprintf(buf, sizeof(buf), "overlay pools for %u scans (%u roots / %u nodes / %u point blocks each) do not fit: %s (lk_overlay_reserve sets smaller per-scan capacities)",
-                 S2, roots, n.nodes_cap, n.blocks_cap, hipGetErrorString(e));
+                 S2, roots, nodes, n.blocks_cap, hipGetErrorString(e));
         return fail(h, LK_ERR_CAPACITY, buf);
     }
     h->ov_slots = S2;
+    hipLaunchKernelGGL(lk_ov_init_kernel, dim3((n.hash_cap + 255) / 256, S2), dim3(256), 0, h->stream, h->ov);
+    HIPCHK(h, hipGetLastError());
     return LK_OK;
 }
 
@@ -2888,13 +2910,16 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (rc) return rc;
     hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, h->d_filters, S, t_begin);
     {
-        const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);
+        const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
         LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
     }
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
     LkFilter* fl = h->d_filters;
     double* parts = h->d_partials;
+    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 2;
+    const auto root_kernel = root_waves >= 4 ? lk_ov_insert_root_kernel<4> : root_waves == 3 ? lk_ov_insert_root_kernel<3> : lk_ov_insert_root_kernel<2>;
+    static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
     for (size_t k = 0; k < live.size(); ++k) {
         const size_t b = live[k];
         const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
@@ -2908,9 +2933,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
         LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
-        const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
-        LAUNCH(h, "ov_cow", hipLaunchKernelGGL(lk_ov_cow_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov));
-        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(lk_ov_insert_root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
+        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         if (k + 1 < live.size())
@@ -2935,7 +2960,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (stt[0]) {
         char buf[256];
         snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots of %u / %u / %u per scan (lk_overlay_reserve)",
-                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.nodes_cap, ov.blocks_cap, ov.hash_cap / 2);
+                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.nodes_cap - ov.hash_cap / 2, ov.blocks_cap, ov.hash_cap / 2);
         return fail(h, LK_ERR_CAPACITY, buf);
     }
     return LK_OK;

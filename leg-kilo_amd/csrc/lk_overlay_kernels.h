@@ -6,12 +6,12 @@
 // owns a complete private LkMap - hash table, node / plane / match / point-block pools, per-bucket work lists - that starts EMPTY and
 // only ever holds the root voxels this scan's inserts touch:
 //   * the re-projection pass looks a point's root up in the slot's private table first, then in the base map; a point that the base
-//     (or private) tree would ignore - it lands in a frozen leaf - is dropped right there, as on the stream path.  Otherwise the root
-//     is made private: a NEW private root is claimed (lock-free, as root_find_or_create) and, when the base map has a voxel at that
-//     key, remembers it (lk_node_rec::pad_[LK_PAD_COWSRC]); the point is queued on the private root;
-//   * lk_ov_cow_kernel, one wave per touched root, copies the base voxel's whole octree - node, plane, match records and the live
-//     leaves' points - into the slot's pools (child / block ids renumbered).  Whole subtrees are copied on first touch, so a private
-//     tree never points into the base pools;
+//     (or private) tree would ignore - it lands in a frozen leaf - is dropped right there, as on the stream path.  Otherwise the
+//     point's key is claimed in the slot's table (one relaxed 64-bit CAS; the table index is the root's node id) and the point is
+//     queued on that root record;
+//   * lk_ov_materialise_kernel, one wave per touched root that does not exist yet, copies the base voxel's whole octree - node,
+//     plane, match records and the live leaves' points - into the slot's pools (child / block ids renumbered), or creates an empty
+//     root where the base map has none.  Whole subtrees are copied on first touch, so a private tree never points into the base pools;
 //   * the root / apply / fallback passes of the stream path (dev_insert_root, dev_insert_apply, dev_insert_fallback) then run
 //     UNCHANGED on the private LkMap, with the slot as a second grid dimension: thousands of roots per launch instead of ~1000.
 //   * the residual pass of the next bucket finds a key's root through one bit per base grid cell ("this slot has a private root
@@ -25,15 +25,21 @@
 #include "lk_point_kernels.h"
 
 #define LK_PAD_QCOUNT 0   // lk_node_rec::pad_[0]: points queued on a root in the current bucket (queue_point_on_root)
-#define LK_PAD_COWSRC 3   // lk_node_rec::pad_[3] of a PRIVATE root: 1 + id of the base root still to be copied into it (0: nothing pending)
-#define LK_CTR_NODES0 13  // LkMap::counters[13] of a private map: its node count when the current bucket's insert began
+#define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 1 once the root exists in the slot's map (0: its key may have been claimed in this bucket)
+#define LK_PAD_BASE 4     // lk_node_rec::pad_[4] of a private root record that does not exist yet: 1 + id of the base map's voxel of that key (0: none)
+#define LK_OV_EMPTY 0x8000000000000000ull   // empty entry of a slot's key table (a packed key never has bit 63 set)
 
 // The overlay pools of all slots, passed by value.  Slot s owns element range [s * cap, (s + 1) * cap) of every array.
+// Private root table of a slot: open addressing over PACKED 64-bit keys (3 x 21 bits), and the root's node id IS its table index -
+// node records [0, hash_cap) of the slot are its roots, children are allocated from hash_cap upwards.  A key is claimed with ONE
+// relaxed 64-bit compare-and-swap and nothing has to be published to the other lanes: no lock word, no fences (an agent-scope
+// acquire / release is an L2 invalidate / write-back on a part whose eight XCDs each have their own L2 - the first version of this
+// pass spun on one per point and took 14 ms per launch where this one takes a fraction of a millisecond).
 struct LkOverlay {
-    int4* hash;
+    unsigned long long* keys;    // [S][hash_cap]
     lk_plane_rec* planes;
     lk_match_rec* match;
-    lk_node_rec* nodes;
+    lk_node_rec* nodes;          // [S][nodes_cap], nodes_cap = hash_cap + children
     lk_block_rec* blocks;
     unsigned int* counters;      // [S][LK_CTR_COUNT]
     int* touched;                // [S][scan_cap]
@@ -41,10 +47,10 @@ struct LkOverlay {
     int* scratch;                // [S][scan_cap]
     int* gidx;                   // [S][scan_cap]
     int* groups;                 // [S][2 * scan_cap * 16]  (LkGroup = 16 ints)
-    int* slots;                  // [S][nodes_cap][LK_SLOTS]
+    int* slots;                  // [S][hash_cap][LK_SLOTS]: only roots queue points
     int* free_list;              // [S][blocks_cap]
     int* freed_next;             // [S][blocks_cap]
-    unsigned int* dirty;         // [S][nodes_cap]
+    unsigned int* dirty;         // [S][hash_cap] (roots only; epoch 0)
     unsigned int* newroot;       // one shared dummy table (epoch 0: only ever written with 0)
     unsigned int* spec;          // one shared dummy
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
@@ -54,7 +60,7 @@ struct LkOverlay {
 __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int slot) {
     LkMap m = {};
     const size_t s = slot;
-    m.hash = ov.hash + s * ov.hash_cap;
+    m.hash = nullptr;            // the private table is ov.keys (ov_key_find / ov_key_claim)
     m.planes = ov.planes + s * ov.nodes_cap;
     m.match = ov.match + s * ov.nodes_cap;
     m.nodes = ov.nodes + s * ov.nodes_cap;
@@ -63,7 +69,7 @@ __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int s
     m.touched = ov.touched + s * ov.scan_cap;
     m.heavy = nullptr;
     m.next = ov.next + s * ov.scan_cap;
-    m.slots = ov.slots + s * ov.nodes_cap * LK_SLOTS;
+    m.slots = ov.slots + s * ov.hash_cap * LK_SLOTS;
     m.scratch = ov.scratch + s * ov.scan_cap;
     m.groups = ov.groups + s * ov.scan_cap * 32;
     m.gidx = ov.gidx + s * ov.scan_cap;
@@ -73,7 +79,7 @@ __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int s
     m.max_nodes = ov.nodes_cap;
     m.max_blocks = ov.blocks_cap;
     m.max_scan = ov.scan_cap;
-    m.dirty = ov.dirty + s * ov.nodes_cap;
+    m.dirty = ov.dirty + s * ov.hash_cap;
     m.newroot = ov.newroot;
     m.spec = ov.spec;
     m.epoch = 0;
@@ -81,20 +87,105 @@ __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int s
     return m;
 }
 
+// 3 x 21-bit two's complement fields; false when a component does not fit (|key| >= 2^20 voxels)
+__host__ __device__ inline bool ov_pack_key(int kx, int ky, int kz, unsigned long long* out) {
+    const int lim = 1 << 20;
+    if (kx < -lim || kx >= lim || ky < -lim || ky >= lim || kz < -lim || kz >= lim) return false;
+    *out = ((unsigned long long)((unsigned int)kx & 0x1fffffu)) | ((unsigned long long)((unsigned int)ky & 0x1fffffu) << 21) |
+           ((unsigned long long)((unsigned int)kz & 0x1fffffu) << 42);
+    return true;
+}
+__host__ __device__ inline void ov_unpack_key(unsigned long long k, int* key) {
+    for (int c = 0; c < 3; ++c) {
+        const int f = (int)((k >> (21 * c)) & 0x1fffffu);
+        key[c] = (f & 0x100000) ? f - 0x200000 : f;
+    }
+}
+__device__ __forceinline__ unsigned int ov_slot_hash(int kx, int ky, int kz) { return lk_hash3(kx, ky, kz); }
+// plain loads, two consecutive entries per round trip; the entry index (= the root's node id) or -1.  Entries only ever go from
+// empty to a key, so a stale view can only miss a key that was claimed in the running launch.
+__device__ __forceinline__ int ov_key_find(const unsigned long long* __restrict__ keys, unsigned int mask, unsigned long long pk, unsigned int h) {
+    unsigned int s = h & mask;
+    for (unsigned int probe = 0; probe <= mask; probe += 2) {
+        const unsigned long long e0 = keys[s], e1 = keys[(s + 1) & mask];
+        if (e0 == pk) return (int)s;
+        if (e0 == LK_OV_EMPTY) return -1;
+        if (e1 == pk) return (int)((s + 1) & mask);
+        if (e1 == LK_OV_EMPTY) return -1;
+        s = (s + 2) & mask;
+    }
+    return -1;
+}
+// find-or-claim: one relaxed 64-bit CAS per probed entry that looks empty; -1 = table full.  *claimed: THIS lane's CAS put the key in
+// (exactly one lane per new key ever sees that)
+__device__ __forceinline__ int ov_key_claim(unsigned long long* keys, unsigned int mask, unsigned long long pk, unsigned int h, bool* claimed) {
+    unsigned int s = h & mask;
+    *claimed = false;
+    for (unsigned int probe = 0; probe <= mask; ++probe) {
+        unsigned long long e = keys[s];
+        if (e == LK_OV_EMPTY) {
+            e = atomicCAS(&keys[s], LK_OV_EMPTY, pk);   // returns the old value: empty -> we claimed it
+            if (e == LK_OV_EMPTY) {
+                *claimed = true;
+                return (int)s;
+            }
+        }
+        if (e == pk) return (int)s;
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
 // ---------------------------------------------------------------- start of a replay: every slot's private map is empty
+__device__ __forceinline__ void ov_root_record_reset(lk_node_rec* nd) {   // a root record's bucket-local queue and "exists" flag
+    nd->list_head = -1;
+    nd->pad_[LK_PAD_QCOUNT] = 0;
+    nd->pad_[LK_PAD_LIVE] = 0;
+    nd->pad_[LK_PAD_BASE] = 0;
+}
+// once per allocation: every table entry empty, every root record's queue fields clean
+__global__ void __launch_bounds__(256) lk_ov_init_kernel(LkOverlay ov) {
+    const unsigned int slot = blockIdx.y;
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ov.hash_cap) {
+        ov.keys[(size_t)slot * ov.hash_cap + i] = LK_OV_EMPTY;
+        ov_root_record_reset(&ov.nodes[(size_t)slot * ov.nodes_cap + i]);
+    }
+}
+// per replay: only the entries the PREVIOUS replay claimed are touched (a 100 000-point scan claims ~5 000 of 32 768: resetting every
+// root record cost 3 ms per 1024-scan batch, this pass reads the key tables - 8 B per entry - and rewrites the claimed records)
 __global__ void __launch_bounds__(256) lk_ov_reset_kernel(LkOverlay ov) {
     const unsigned int slot = blockIdx.y;
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < ov.hash_cap) ov.hash[(size_t)slot * ov.hash_cap + i] = make_int4((int)0x80000000, (int)0x80000000, (int)0x80000000, LK_EMPTY);
+    if (i < ov.hash_cap) {
+        unsigned long long* k = &ov.keys[(size_t)slot * ov.hash_cap + i];
+        if (*k != LK_OV_EMPTY) {
+            *k = LK_OV_EMPTY;
+            ov_root_record_reset(&ov.nodes[(size_t)slot * ov.nodes_cap + i]);
+        }
+    }
     if (i < ov.bit_words) ov.bits[(size_t)slot * ov.bit_words + i] = 0u;
-    if (i < LK_CTR_COUNT) ov.counters[(size_t)slot * LK_CTR_COUNT + i] = 0u;
+    if (i < LK_CTR_COUNT) ov.counters[(size_t)slot * LK_CTR_COUNT + i] = (i == LK_CTR_NODES) ? ov.hash_cap : 0u;
+    if (i == 0) {
+        // the record an exhausted node pool clamps its ids to (create_child, ov_copy_node) must be a sane empty node: the call fails
+        // with LK_ERR_CAPACITY, but nothing may follow a garbage child or block id on the way there
+        const size_t last = (size_t)slot * ov.nodes_cap + ov.nodes_cap - 1;
+        lk_node_rec* nd = &ov.nodes[last];
+        for (int c = 0; c < 8; ++c) nd->child[c] = -1;
+        nd->voxel_center[0] = nd->voxel_center[1] = nd->voxel_center[2] = 0.0;
+        nd->quater_length = 0.f;
+        nd->layer = LK_MAX_LAYER, nd->npts = 0, nd->new_points = 0, nd->state = 0, nd->block = -1;
+        nd->list_head = -1;
+        for (int c = 0; c < 8; ++c) nd->pad_[c] = 0;
+        ov.planes[last].flags = 0;
+        ov.match[last].flags = 0;
+    }
 }
 
-// start of a bucket's insert in every slot: dev_bucket_begin_wave + the node count the bucket starts from
+// start of a bucket's insert in every slot
 __global__ void __launch_bounds__(LK_WAVE) lk_ov_begin_kernel(LkOverlay ov) {
     const LkMap pm = ov_slot_map(ov, blockIdx.x);
     dev_bucket_begin_wave(pm);
-    if (threadIdx.x == 0) pm.counters[LK_CTR_NODES0] = min(pm.counters[LK_CTR_NODES], pm.max_nodes);
 }
 
 // ---------------------------------------------------------------- re-projection + hashing half of the insert
@@ -126,72 +217,11 @@ __device__ __forceinline__ bool ov_cell_of(const LkMap& base, const int* key, un
     return true;
 }
 
-// root_find_or_create (lk_point_kernels.h) on the slot's private table, without its plain-load fast path (the caller has tried
-// it).  A root created here is a complete empty root voxel (voxel_map.cc:345-357) that remembers the base voxel it stands for.
-__device__ __forceinline__ int ov_root_find_or_create(const LkMap& pm, const LkMap& base, unsigned int* __restrict__ bits, const LkParams& pr,
-                                                      const int* key, int base_root) {
-    unsigned int s = lk_hash3(key[0], key[1], key[2]) & pm.hash_mask;
-    int* slotw = reinterpret_cast<int*>(pm.hash);
-    for (unsigned int trips = 0; trips < 64u * (pm.hash_mask + 1u); ++trips) {
-        const int w = __hip_atomic_load(&slotw[4 * s + 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == LK_EMPTY) {
-            int expected = LK_EMPTY;
-            if (__hip_atomic_compare_exchange_strong(&slotw[4 * s + 3], &expected, LK_LOCKED, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
-                const unsigned int id = atomicAdd(&pm.counters[LK_CTR_NODES], 1u);
-                if (id >= pm.max_nodes) {
-                    atomicOr(&pm.counters[LK_CTR_ERR], LK_E_NODES_FULL);
-                    __hip_atomic_store(&slotw[4 * s + 3], LK_EMPTY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    return -1;
-                }
-                atomicAdd(&pm.counters[LK_CTR_ROOTS], 1u);
-                lk_node_rec* nd = &pm.nodes[id];
-                const double vs = (double)pr.voxel_size_f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) nd->child[c] = -1;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    nd->voxel_center[c] = (0.5 + key[c]) * vs;  // voxel_map.cc:355-357
-                    nd->key[c] = key[c];
-                }
-                nd->quater_length = pr.voxel_size_f / 4;          // voxel_map.cc:354
-                nd->layer = 0;
-                nd->npts = 0;
-                nd->new_points = 0;
-                nd->state = LK_NODE_UPDATE_ENABLE;
-                nd->block = -1;
-                nd->list_head = -1;
-                nd->pad_[LK_PAD_QCOUNT] = 0;
-                nd->pad_[LK_PAD_COWSRC] = (unsigned int)(base_root + 1);
-                pm.planes[id].flags = 0;
-                pm.match[id].flags = 0;
-                unsigned int cell;
-                if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
-                slotw[4 * s + 0] = key[0];
-                slotw[4 * s + 1] = key[1];
-                slotw[4 * s + 2] = key[2];
-                __hip_atomic_store(&slotw[4 * s + 3], (int)id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                return (int)id;
-            }
-            continue;  // lost the race: re-read this slot
-        }
-        if (w == LK_LOCKED) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const int kx = __hip_atomic_load(&slotw[4 * s + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int ky = __hip_atomic_load(&slotw[4 * s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int kz = __hip_atomic_load(&slotw[4 * s + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (kx == key[0] && ky == key[1] && kz == key[2]) return w;
-        s = (s + 1) & pm.hash_mask;
-    }
-    atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
-    return -1;
-}
-
 // KILO.cc:216-230 + the hashing half of UpdateVoxelMap (voxel_map.cc:343-358) for bucket point i of slot blockIdx.y, on the
-// slot's overlay.  A private root created in an EARLIER bucket (id below the node count this bucket began with) is complete and
-// is walked itself; one created in THIS launch is still an empty placeholder - the base voxel it stands for is walked instead
-// (the insert's first phase is read-only on every tree, so the base voxel is still the truth).
+// slot's overlay.  A private root that exists (created by an earlier bucket: LK_PAD_LIVE) is walked itself; otherwise the base
+// voxel of the key, if any, is still the truth - the insert's first phase is read-only on every tree.  A point that is not ignored
+// claims its key in the slot's table (if nobody has) and is queued on that entry = root record; lk_ov_materialise_kernel then
+// creates the roots that do not exist yet.
 __global__ void __launch_bounds__(LK_WAVE)
     lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                            size_t pts_slot_stride, int n) {
@@ -199,104 +229,197 @@ __global__ void __launch_bounds__(LK_WAVE)
     if (i >= n) return;
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
+    unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
     const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
     const V3 pw = point_world(p.x, p.y, p.z, bc, pr);
     int key[3];
     key_floor(pw, pr.voxel_size_f, key);
-    const int nodes0 = (int)pm.counters[LK_CTR_NODES0];
-    const int proot = hash_find(pm, key[0], key[1], key[2]);
-    int broot = -1;
-    if (proot >= 0 && proot < nodes0) {
-        if (ov_walk_ignored(pm, proot, pw, pr.max_layer)) return;
-    } else {
-        broot = hash_find(base, key[0], key[1], key[2]);
-        if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return;
+    unsigned long long pk;
+    if (!ov_pack_key(key[0], key[1], key[2], &pk)) {
+        atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
+        return;
     }
-    const int root = proot >= 0 ? proot : ov_root_find_or_create(pm, base, ov.bits + (size_t)slot * ov.bit_words, pr, key, broot);
-    if (root < 0) return;
+    const unsigned int hk = ov_slot_hash(key[0], key[1], key[2]);
+    int root = ov_key_find(keys, pm.hash_mask, pk, hk);
+    if (root >= 0 && pm.nodes[root].pad_[LK_PAD_LIVE] != 0) {
+        if (ov_walk_ignored(pm, root, pw, pr.max_layer)) return;
+    } else {
+        const int broot = hash_find(base, key[0], key[1], key[2]);
+        if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return;
+        if (root < 0) {
+            bool claimed;
+            root = ov_key_claim(keys, pm.hash_mask, pk, hk, &claimed);
+            if (root < 0) {
+                atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
+                return;
+            }
+            // what the materialise pass copies into this root (no lookup there): stored by the ONE lane that claimed the key - a store
+            // per point cost 2.8 ms per 1024-scan batch
+            if (claimed) pm.nodes[root].pad_[LK_PAD_BASE] = (unsigned int)(broot + 1);
+        }
+    }
     queue_point_on_root(pm, root, i);
 }
 
 // ---------------------------------------------------------------- copy-on-write of a base voxel's octree
-// One wave copies node `src` of the base map (and, recursively, its children) into node `dst` of the private map: plane and match
-// records as 16-B chunks, a live leaf's points into a private block, child and block ids renumbered.  The root keeps the queue
-// fields the re-projection pass has filled in (pad_[LK_PAD_QCOUNT], list_head).
+// One wave copies node `src` of the base map (and, recursively, its children) into node `dst` of the private map, in TWO memory round
+// trips per node: (1) the source's node record (one 16-B chunk per lane 0..7), plane record (lanes 8..23) and match record (lanes
+// 24..32) are requested together; (2) the live leaf's points (<= 8 doubles per lane), the private block id and the children's node
+// ids (ONE bump of the node counter for all of them) are requested together; then everything is stored.  Child and block ids are
+// renumbered.  The root (L == 0) keeps the queue fields the re-projection pass has filled in (list_head, pad_[]).
 template <int L>
 __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base, const int src, const int dst) {
     const int lane = threadIdx.x & 63;
-    const lk_node_rec* sn = &base.nodes[src];
-    lk_node_rec* dn = &pm.nodes[dst];
-    const int s_block = bcast0(sn->block), s_npts = bcast0(sn->npts);
-    if (lane < 16) reinterpret_cast<uint4*>(&pm.planes[dst])[lane] = reinterpret_cast<const uint4*>(&base.planes[src])[lane];
-    else if (lane < 25) reinterpret_cast<uint4*>(&pm.match[dst])[lane - 16] = reinterpret_cast<const uint4*>(&base.match[src])[lane - 16];
-    int nblock = -1;
-    if (s_block >= 0) {
-        nblock = alloc_block(pm);
-        const int nd8 = min(max(s_npts, 0), LK_BLOCK_PTS) * 9;   // lk_pt_rec = 9 doubles; only the first npts records hold points
-        const double* sp = reinterpret_cast<const double*>(&base.blocks[s_block]);
-        double* dp = reinterpret_cast<double*>(&pm.blocks[nblock]);
-        for (int k = lane; k < nd8; k += LK_WAVE) dp[k] = sp[k];
-    }
-    if (lane == 0) {
+    // ---- trip 1
+    int4 rec = make_int4(0, 0, 0, 0);
+    uint4 pv = make_uint4(0, 0, 0, 0);
+    if (lane < 8) rec = reinterpret_cast<const int4*>(&base.nodes[src])[lane];
+    else if (lane < 24) pv = reinterpret_cast<const uint4*>(&base.planes[src])[lane - 8];
+    else if (lane < 33) pv = reinterpret_cast<const uint4*>(&base.match[src])[lane - 24];
+    int child[8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dn->voxel_center[c] = sn->voxel_center[c], dn->key[c] = sn->key[c];
-        dn->quater_length = sn->quater_length;
-        dn->layer = sn->layer;
-        dn->npts = s_npts;
-        dn->new_points = sn->new_points;
-        dn->state = sn->state;
-        dn->block = nblock;
-        if (L > 0) dn->list_head = -1, dn->pad_[LK_PAD_QCOUNT] = 0;
-        dn->pad_[LK_PAD_COWSRC] = 0;
-    }
-    // children one at a time (nothing is kept across the recursion but the loop index)
     for (int c = 0; c < 8; ++c) {
-        const int ch = bcast0(sn->child[c]);
-        int id = -1;
-        if (ch >= 0) {
-            if (lane == 0) {
-                unsigned int nn = atomicAdd(&pm.counters[LK_CTR_NODES], 1u);
-                if (nn >= pm.max_nodes) {
-                    atomicOr(&pm.counters[LK_CTR_ERR], LK_E_NODES_FULL);
-                    nn = pm.max_nodes - 1;   // memory-safe; the error flag fails the call
-                }
-                id = (int)nn;
+        const int comp = (c & 3) == 0 ? rec.x : (c & 3) == 1 ? rec.y : (c & 3) == 2 ? rec.z : rec.w;
+        child[c] = __builtin_amdgcn_readlane(comp, c >> 2);
+    }
+    const int s_npts = __builtin_amdgcn_readlane(rec.x, 4), s_block = __builtin_amdgcn_readlane(rec.w, 4);   // bytes 64..79: npts, new_points, state, block
+    int n_child = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) n_child += child[c] >= 0 ? 1 : 0;
+    // ---- trip 2
+    const int nd8 = s_block >= 0 ? min(max(s_npts, 0), LK_BLOCK_PTS) * 9 : 0;   // lk_pt_rec = 9 doubles; only the first npts records hold points
+    double pt[8];
+    {
+        const double* sp = reinterpret_cast<const double*>(&base.blocks[s_block >= 0 ? s_block : 0]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pt[k] = (lane + 64 * k < nd8) ? sp[lane + 64 * k] : 0.0;
+    }
+    int nblock = -1, cbase = -1;
+    if (lane == 0) {
+        if (s_block >= 0) nblock = pop_or_bump_block(pm);
+        if (n_child > 0) {
+            unsigned int nn = atomicAdd(&pm.counters[LK_CTR_NODES], (unsigned int)n_child);
+            if (nn + (unsigned int)n_child > pm.max_nodes) {
+                atomicOr(&pm.counters[LK_CTR_ERR], LK_E_NODES_FULL);
+                nn = pm.max_nodes - (unsigned int)n_child;   // memory-safe; the error flag fails the call (lk_ov_reset_kernel keeps the last record sane)
             }
-            id = bcast0(id);
-            if constexpr (L < LK_MAX_LAYER) ov_copy_node<L + 1>(pm, base, ch, id);
+            cbase = (int)nn;
         }
-        if (lane == 0) dn->child[c] = id;
+    }
+    nblock = bcast0(nblock), cbase = bcast0(cbase);
+    // ---- stores
+    if (lane >= 8 && lane < 24) reinterpret_cast<uint4*>(&pm.planes[dst])[lane - 8] = pv;
+    else if (lane >= 24 && lane < 33) reinterpret_cast<uint4*>(&pm.match[dst])[lane - 24] = pv;
+    if (nd8 > 0) {
+        double* dp = reinterpret_cast<double*>(&pm.blocks[nblock]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (lane + 64 * k < nd8) dp[lane + 64 * k] = pt[k];
+    }
+    int nchild[8];
+    {
+        int run = cbase;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) nchild[c] = child[c] >= 0 ? run++ : -1;
+    }
+    int4* drec = reinterpret_cast<int4*>(&pm.nodes[dst]);
+    if (lane == 0) drec[0] = make_int4(nchild[0], nchild[1], nchild[2], nchild[3]);
+    else if (lane == 1) drec[1] = make_int4(nchild[4], nchild[5], nchild[6], nchild[7]);
+    else if (lane == 2 || lane == 3) drec[lane] = rec;                        // voxel_center, quater_length, layer
+    else if (lane == 4) drec[4] = make_int4(rec.x, rec.y, rec.z, nblock);     // npts, new_points, state, block
+    else if (lane == 5) {
+        if (L > 0) drec[5] = make_int4(rec.x, rec.y, rec.z, -1);              // key, list_head
+        else pm.nodes[dst].key[0] = rec.x, pm.nodes[dst].key[1] = rec.y, pm.nodes[dst].key[2] = rec.z;
+    } else if ((lane == 6 || lane == 7) && L > 0) drec[lane] = make_int4(0, 0, 0, 0);   // pad_: a child queues nothing
+    if constexpr (L < LK_MAX_LAYER) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (child[c] >= 0) ov_copy_node<L + 1>(pm, base, child[c], nchild[c]);
     }
 }
-__global__ void __launch_bounds__(LK_MB) lk_ov_cow_kernel(LkMap base, LkOverlay ov) {
-    const LkMap pm = ov_slot_map(ov, blockIdx.y);
+// One wave per touched root that does not exist in the slot's map yet: the base voxel of its key is copied (copy-on-write), or - the
+// base map has none - an empty root voxel is created (voxel_map.cc:345-357).  Then the key's bit is set for the residual pass.
+__global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    const unsigned int slot = blockIdx.y;
+    const LkMap pm = ov_slot_map(ov, slot);
+    if (pm.counters[LK_CTR_ERR]) return;
+    const unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
+    unsigned int* bits = ov.bits + (size_t)slot * ov.bit_words;
+    const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * LK_MB) >> 6);
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
-    for (int t = wave; t < n_touched; t += nwaves) {
-        const int root = bcast0(pm.touched[t]);
-        const int src1 = bcast0((int)pm.nodes[root].pad_[LK_PAD_COWSRC]);
-        if (src1 > 0) ov_copy_node<0>(pm, base, src1 - 1, root);
+    for (int t0 = wave * LK_WAVE; t0 < n_touched; t0 += nwaves * LK_WAVE) {
+        // a wave takes 64 consecutive touched roots: their ids, flags and keys are fetched by one lane each (three round trips for all
+        // 64 instead of three per root), then the roots that need it are materialised one after the other
+        const int tt = t0 + lane;
+        int my_root = -1, my_base = 0;
+        bool need = false;
+        unsigned long long my_key = 0ull;
+        if (tt < n_touched) {
+            my_root = pm.touched[tt];
+            const lk_node_rec* nd = &pm.nodes[my_root];
+            need = nd->pad_[LK_PAD_LIVE] == 0;
+            my_base = (int)nd->pad_[LK_PAD_BASE];
+            my_key = keys[my_root];
+        }
+        unsigned long long todo = __ballot(need);
+        while (todo) {
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int root = __builtin_amdgcn_readlane(my_root, src_lane);
+            const int broot = __builtin_amdgcn_readlane(my_base, src_lane) - 1;
+            int key[3];
+            ov_unpack_key(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(my_key >> 32), src_lane) << 32) |
+                              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(my_key & 0xffffffffull), src_lane), key);
+            lk_node_rec* nd = &pm.nodes[root];
+            if (broot >= 0) {
+                ov_copy_node<0>(pm, base, broot, root);
+            } else if (lane == 0) {
+                const double vs = (double)pr.voxel_size_f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) nd->child[c] = -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) nd->voxel_center[c] = (0.5 + key[c]) * vs, nd->key[c] = key[c];  // voxel_map.cc:355-357
+                nd->quater_length = pr.voxel_size_f / 4;                                                        // voxel_map.cc:354
+                nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = LK_NODE_UPDATE_ENABLE, nd->block = -1;
+                pm.planes[root].flags = 0;
+                pm.match[root].flags = 0;
+            }
+            if (lane == 0) {
+                nd->pad_[LK_PAD_LIVE] = 1;
+                unsigned int cell;
+                if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
+            }
+        }
+        const int n_new = __popcll(__ballot(need));
+        if (lane == 0 && n_new) atomicAdd(&pm.counters[LK_CTR_ROOTS], (unsigned int)n_new);
     }
 }
 
 // ---------------------------------------------------------------- the ordered insert, slot = blockIdx.y
-__global__ void __launch_bounds__(LK_MB)
+// W = waves per SIMD the register allocation aims at (2: the stream path's 216 VGPRs; 3: <= 168): this launch is a throughput pass over
+// ~10^6 roots, each a chain of dependent round trips - concurrency, not the single wave's speed, sets its duration
+template <int W>
+__global__ void __launch_bounds__(LK_MB, W)
     lk_ov_insert_root_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
+    if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
     dev_insert_root<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
                            (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
+    if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
     dev_insert_apply<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
                             (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
+    if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
     dev_insert_fallback<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
                                (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
@@ -313,7 +436,7 @@ __global__ void LK_RES_BOUNDS
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
     LkOvView ovv;
-    ovv.hash = ov.hash + (size_t)slot * ov.hash_cap;
+    ovv.keys = ov.keys + (size_t)slot * ov.hash_cap;
     ovv.hash_mask = ov.hash_cap - 1;
     ovv.match = ov.match + (size_t)slot * ov.nodes_cap;
     ovv.nodes = ov.nodes + (size_t)slot * ov.nodes_cap;
@@ -334,7 +457,7 @@ __global__ void __launch_bounds__(256) lk_ov_status_kernel(LkOverlay ov, unsigne
             atomicOr(&out[0], c[LK_CTR_ERR]);
             atomicMin(&out[4], s);
         }
-        atomicMax(&out[1], c[LK_CTR_NODES]);
+        atomicMax(&out[1], c[LK_CTR_NODES] - ov.hash_cap + c[LK_CTR_ROOTS]);
         atomicMax(&out[2], c[LK_CTR_BLOCKS]);
         atomicMax(&out[3], c[LK_CTR_ROOTS]);
     }

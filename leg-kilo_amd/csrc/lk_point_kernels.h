@@ -233,15 +233,15 @@ __device__ __forceinline__ int find_root(const LkMap& m, int kx, int ky, int kz)
 
 // Batch replay with a per-scan insert overlay (lk_overlay_kernels.h): what the residual pass needs of ONE slot's private map.
 struct LkOvView {
-    const int4* hash;              // the slot's private root table
+    const unsigned long long* keys;   // the slot's private root table: packed keys, entry index = the root's node id
     unsigned int hash_mask;
-    const lk_match_rec* match;     // the slot's private match / node pools (ids are slot-local)
+    const lk_match_rec* match;        // the slot's private match / node pools (ids are slot-local)
     const lk_node_rec* nodes;
-    const unsigned int* bits;      // one bit per base grid cell: the slot has a private root at that key
+    const unsigned int* bits;         // one bit per base grid cell: the slot has a private root at that key
 };
 // Root of a key for the overlay matcher: >= 0 a cell of the base map's frozen grid (match_flat), <= -2 the private root
-// -2 - code of the slot (match_root on the private pools), -1 none.  The bit of the key's cell is requested together with
-// nothing else depending on it; only a set bit (the scan has inserted into that voxel) costs the trip to the private table.
+// -2 - code of the slot (match_root on the private pools), -1 none.  Only a set bit (the scan has inserted into that voxel) costs
+// the trip to the private table.
 __device__ __forceinline__ int find_root_ov(const LkMap& base, const LkOvView& ov, int kx, int ky, int kz) {
     const unsigned int ux = (unsigned int)(kx - base.gmin[0]), uy = (unsigned int)(ky - base.gmin[1]), uz = (unsigned int)(kz - base.gmin[2]);
     const bool in = ux < (unsigned int)base.gdim[0] && uy < (unsigned int)base.gdim[1] && uz < (unsigned int)base.gdim[2];
@@ -250,11 +250,20 @@ __device__ __forceinline__ int find_root_ov(const LkMap& base, const LkOvView& o
         cell = (uz * (unsigned int)base.gdim[1] + uy) * (unsigned int)base.gdim[0] + ux;
         if (!((ov.bits[cell >> 5] >> (cell & 31u)) & 1u)) return (int)(base.grid_base + cell);
     }
-    LkMap pm = {};
-    pm.hash = const_cast<int4*>(ov.hash);
-    pm.hash_mask = ov.hash_mask;
-    const int r = hash_find(pm, kx, ky, kz);
-    if (r >= 0) return -2 - r;
+    const int lim = 1 << 20;
+    if (!(kx < -lim || kx >= lim || ky < -lim || ky >= lim || kz < -lim || kz >= lim)) {
+        const unsigned long long pk = ((unsigned long long)((unsigned int)kx & 0x1fffffu)) | ((unsigned long long)((unsigned int)ky & 0x1fffffu) << 21) |
+                                      ((unsigned long long)((unsigned int)kz & 0x1fffffu) << 42);
+        unsigned int s = lk_hash3(kx, ky, kz) & ov.hash_mask;
+        for (unsigned int probe = 0; probe <= ov.hash_mask; probe += 2) {
+            const unsigned long long e0 = ov.keys[s], e1 = ov.keys[(s + 1) & ov.hash_mask];
+            if (e0 == pk) return -2 - (int)s;
+            if (e0 == 0x8000000000000000ull) break;
+            if (e1 == pk) return -2 - (int)((s + 1) & ov.hash_mask);
+            if (e1 == 0x8000000000000000ull) break;
+            s = (s + 2) & ov.hash_mask;
+        }
+    }
     return in ? (int)(base.grid_base + cell) : -1;
 }
 

@@ -898,6 +898,10 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
             o.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30))
             o.set_times(tb, tb)
             o.process_scan(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=3100 + k, seed_noise=3200 + k), tb)
+    # the shared map in the form a blob round trip leaves it in: the oracle's import does not restore the DEAD points of a cut voxel's
+    # inner node (never read again; the live oracle still counts them in npts), so the checker, which starts every slot from
+    # map_import(blob), and the device, which copies the blob's records, must both start from the re-imported form
+    o.map_import(o.map_export())
     blob = o.map_export()
     g.map_import(blob)
     g.init_process_cov_q()
@@ -924,6 +928,14 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
     g.batch_set_priors(np.array(xs), np.array(Ps))
     frozen = g.batch_replay_dev(d_pts, S, n_pts, 0.0, off, dt)
     n_eff_frozen = [int(p.n_effect) for p in frozen]
+    if case == "scattered":
+        # pools too small for what a scan touches: a loud LK_ERR_CAPACITY that names the slot and the sizes, never a fault; the
+        # handle stays usable
+        g.overlay_reserve(64, 128, 64)
+        g.batch_set_priors(np.array(xs), np.array(Ps))
+        with pytest.raises(hip_lib.LegKiloError, match="overlay pool overflow"):
+            g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
+        g.overlay_reserve(16384, 32768, 16384)   # a young map: a scattered 30 000-point scan touches most of its voxels
     g.batch_set_priors(np.array(xs), np.array(Ps))
     poses = g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
     Xall, Pall = g.batch_get_states(0, S)
