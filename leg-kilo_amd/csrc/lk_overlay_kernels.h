@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(LK_WAVE)
 // ids (ONE bump of the node counter for all of them) are requested together; then everything is stored.  Child and block ids are
 // renumbered.  The root (L == 0) keeps the queue fields the re-projection pass has filled in (list_head, pad_[]).
 template <int L>
-__device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base, const int src, const int dst) {
+__device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base, const int src, const int dst, const int pre_block = -2) {
     const int lane = threadIdx.x & 63;
     // ---- trip 1
     int4 rec = make_int4(0, 0, 0, 0);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base,
     }
     int nblock = -1, cbase = -1;
     if (lane == 0) {
-        if (s_block >= 0) nblock = pop_or_bump_block(pm);
+        if (s_block >= 0) nblock = pre_block != -2 ? pre_block : pop_or_bump_block(pm);   // pre_block: allocated by the caller for a whole chunk of roots
         if (n_child > 0) {
             unsigned int nn = atomicAdd(&pm.counters[LK_CTR_NODES], (unsigned int)n_child);
             if (nn + (unsigned int)n_child > pm.max_nodes) {
@@ -364,34 +364,52 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             my_base = (int)nd->pad_[LK_PAD_BASE];
             my_key = keys[my_root];
         }
-        unsigned long long todo = __ballot(need);
+        // every lane looks at the base voxel of ITS root: does it own a point block?  One bump of the block counter then serves the
+        // whole chunk (a returning device-scope atomic is a ~2 us round trip; one per root made this pass 3 x slower)
+        int s_block = -1;
+        if (need && my_base > 0) s_block = base.nodes[my_base - 1].block;
+        const unsigned long long blk_mask = __ballot(need && s_block >= 0);
+        int blk_base = 0;
+        if (blk_mask) {
+            const int total = __popcll(blk_mask);
+            if (lane == 0) {
+                unsigned int bb = atomicAdd(&pm.counters[LK_CTR_BLOCKS], (unsigned int)total);
+                if (bb + (unsigned int)total > pm.max_blocks) {
+                    atomicOr(&pm.counters[LK_CTR_ERR], LK_E_BLOCKS_FULL);
+                    bb = pm.max_blocks - (unsigned int)total;   // memory-safe; the error flag fails the call
+                }
+                blk_base = (int)bb;
+            }
+            blk_base = bcast0(blk_base);
+        }
+        const int my_block = (need && s_block >= 0) ? blk_base + __popcll(blk_mask & ((1ull << lane) - 1ull)) : -1;
+        int key[3] = {0, 0, 0};
+        if (need) ov_unpack_key(my_key, key);
+        // roots the base map has no voxel for: an empty root voxel each, written by the root's own lane
+        if (need && my_base == 0) {
+            lk_node_rec* nd = &pm.nodes[my_root];
+            const double vs = (double)pr.voxel_size_f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) nd->child[c] = -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nd->voxel_center[c] = (0.5 + key[c]) * vs, nd->key[c] = key[c];  // voxel_map.cc:355-357
+            nd->quater_length = pr.voxel_size_f / 4;                                                        // voxel_map.cc:354
+            nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = LK_NODE_UPDATE_ENABLE, nd->block = -1;
+            pm.planes[my_root].flags = 0;
+            pm.match[my_root].flags = 0;
+        }
+        // copy-on-write of the others, one after the other, all lanes on one voxel
+        unsigned long long todo = __ballot(need && my_base > 0);
         while (todo) {
             const int src_lane = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
-            const int root = __builtin_amdgcn_readlane(my_root, src_lane);
-            const int broot = __builtin_amdgcn_readlane(my_base, src_lane) - 1;
-            int key[3];
-            ov_unpack_key(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(my_key >> 32), src_lane) << 32) |
-                              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(my_key & 0xffffffffull), src_lane), key);
-            lk_node_rec* nd = &pm.nodes[root];
-            if (broot >= 0) {
-                ov_copy_node<0>(pm, base, broot, root);
-            } else if (lane == 0) {
-                const double vs = (double)pr.voxel_size_f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) nd->child[c] = -1;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) nd->voxel_center[c] = (0.5 + key[c]) * vs, nd->key[c] = key[c];  // voxel_map.cc:355-357
-                nd->quater_length = pr.voxel_size_f / 4;                                                        // voxel_map.cc:354
-                nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = LK_NODE_UPDATE_ENABLE, nd->block = -1;
-                pm.planes[root].flags = 0;
-                pm.match[root].flags = 0;
-            }
-            if (lane == 0) {
-                nd->pad_[LK_PAD_LIVE] = 1;
-                unsigned int cell;
-                if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
-            }
+            ov_copy_node<0>(pm, base, __builtin_amdgcn_readlane(my_base, src_lane) - 1, __builtin_amdgcn_readlane(my_root, src_lane),
+                            __builtin_amdgcn_readlane(my_block, src_lane));
+        }
+        if (need) {
+            pm.nodes[my_root].pad_[LK_PAD_LIVE] = 1;
+            unsigned int cell;
+            if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
         }
         const int n_new = __popcll(__ballot(need));
         if (lane == 0 && n_new) atomicAdd(&pm.counters[LK_CTR_ROOTS], (unsigned int)n_new);
