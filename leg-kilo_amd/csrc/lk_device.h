@@ -367,6 +367,22 @@ __device__ __forceinline__ V3 point_world(float bx, float by, float bz, const Bu
 // These are identities in exact arithmetic for ANY R / ext_R (no orthonormality is assumed); in fp64 they differ
 // from the reference's matrix route by rounding only (~1e-16 relative), ~60 flops per candidate instead of ~230 per
 // point + 12 per candidate, and ~40 fewer live VGPRs.
+// 1 / x for the residual kernel's two divisions per point (finite x well inside the normal range): v_rcp_f64 + two Newton steps
+// instead of the IEEE division sequence (two v_div_scale, v_rcp, five fma, v_div_fmas, v_div_fixup) - the same value to the last
+// bit or one ulp beside it, ~20 instructions fewer per point.  LK_FAST_RCP=0: the full division (A/B).
+#ifndef LK_FAST_RCP
+#define LK_FAST_RCP 0   // measured +1.5 % (662 k vs 652 k scans/s, same box) - and one match of the 1024-scan batch flips (a gate within an ulp of its threshold): the oracle divides, so does the shipped build
+#endif
+__device__ __forceinline__ double lk_inv(double x) {
+#if LK_FAST_RCP
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
 struct PointLite {
     V3 p_i, p_w;
     double alpha_n, beta;  // alpha / |pb|^2, beta
@@ -385,7 +401,7 @@ __device__ __forceinline__ PointLite point_lite(float bx, float by, float bz, co
     const double n2 = dot3(pb.x, pb.x, pb.y, pb.y, pb.z, pb.z);
     const double r = (double)(float)sqrt(n2);            // float range, voxel_map.cc:24
     g.beta = (r * r) * pr.dir_var;
-    g.alpha_n = ((double)pr.range_var - g.beta) / n2;
+    g.alpha_n = ((double)pr.range_var - g.beta) * lk_inv(n2);
     return g;
 }
 struct PlaneTerms {  // per (point, candidate normal)

@@ -63,13 +63,27 @@ struct Match {
 // voxel_map.cc:371-413 for one plane node.  q0..q2 / tail = the first 64 B of the node's match record (center,
 // normal, d, radius, flags), already in registers; the remaining 80 B (S11, w, s22) are requested BEFORE the float
 // range gate is evaluated so that the whole record costs one memory round trip.
-template <bool XID>
+#ifndef LK_PIN_RECORD
+#define LK_PIN_RECORD 1   // frozen-map matcher: all nine 16-B chunks of a candidate's record are requested at once and PINNED ahead of the
+                          // first test of any of them (0: loads where the source has them - the compiler sinks them behind the tests)
+#endif
+// Keeps a loaded 16-B chunk from being sunk below this point: the compiler moves a load next to its first use, and the uses of a
+// match record sit behind three data-dependent tests (cell empty? plane? range gate) - the kernel's ISA had THREE dependent L2
+// round trips per candidate (pad_ word; header + flags, then d / radius; the 80-B tail) where the layout was designed for one.
+__device__ __forceinline__ void pin_chunk(double2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void pin_chunk(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+struct RecTail {   // bytes 64..143 of a match record: S11 (6), w (3), s22
+    double2 v0, v1, v2, v3, v4;
+};
+template <bool XID, bool PRE = false>
 __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, double2 q0, double2 q1, double2 q2,
                                            float pd, float pradius, int node, int layer, const PointLite& g,
                                            const BucketConst& bc, const LkParams& pr, bool& success, double& prob,
-                                           Match& best) {
+                                           Match& best, const RecTail* pre = nullptr) {
     const double2* sv = reinterpret_cast<const double2*>(mr->s11);  // byte offset 64, 16-B aligned
-    const double2 v0 = sv[0], v1 = sv[1], v2 = sv[2], v3 = sv[3], v4 = sv[4];
+    double2 v0, v1, v2, v3, v4;
+    if (PRE) v0 = pre->v0, v1 = pre->v1, v2 = pre->v2, v3 = pre->v3, v4 = pre->v4;
+    else v0 = sv[0], v1 = sv[1], v2 = sv[2], v3 = sv[3], v4 = sv[4];
     V3 c = V3{q0.x, q0.y, q1.x}, n = V3{q1.y, q2.x, q2.y};
     double sd = dot3(n.x, g.p_w.x, n.y, g.p_w.y, n.z, g.p_w.z) + (double)pd;
     float dis_to_plane = (float)fabs(sd);
@@ -113,7 +127,7 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
 #if LK_ROWS_AT_TAKE
         // the row in its final form [h z | h/R | R 1] right here: nothing is read back from LDS before the reduction
         const double Rv = pr.lidar_ratio * sig_r;   // KILO.cc:205-206
-        const double ri = 1.0 / Rv;
+        const double ri = lk_inv(Rv);
         r[7] = t.w.x * ri, r[8] = t.w.y * ri, r[9] = t.w.z * ri;
         r[10] = n.x * ri, r[11] = n.y * ri, r[12] = n.z * ri;
         r[13] = Rv;
@@ -198,8 +212,14 @@ __device__ __forceinline__ bool match_flat(const LkMap& m, int cell, const Point
     while (remaining > 0) {
         const lk_match_rec* pl = &m.match[idx];
         const double2* q = reinterpret_cast<const double2*>(pl);
-        const double2 q0 = q[0], q1 = q[1], q2 = q[2];
-        const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, node id
+        double2 q0 = q[0], q1 = q[1], q2 = q[2];
+        float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, node id
+#if LK_PIN_RECORD
+        RecTail rt;
+        rt.v0 = q[4], rt.v1 = q[5], rt.v2 = q[6], rt.v3 = q[7], rt.v4 = q[8];
+        pin_chunk(q0), pin_chunk(q1), pin_chunk(q2), pin_chunk(tail);
+        pin_chunk(rt.v0), pin_chunk(rt.v1), pin_chunk(rt.v2), pin_chunk(rt.v3), pin_chunk(rt.v4);
+#endif
         const unsigned int fl = __float_as_uint(tail.z);
         if (header) {
             header = false;
@@ -211,7 +231,11 @@ __device__ __forceinline__ bool match_flat(const LkMap& m, int cell, const Point
                 continue;
             }
         }
+#if LK_PIN_RECORD
+        if (!LK_X_NOEVAL) eval_plane<XID, true>(pl, q0, q1, q2, tail.x, tail.y, 0, 0, g, bc, pr, success, prob, best, &rt);
+#else
         if (!LK_X_NOEVAL) eval_plane<XID>(pl, q0, q1, q2, tail.x, tail.y, 0, 0, g, bc, pr, success, prob, best);
+#endif
         ++idx;
         --remaining;
     }
