@@ -459,13 +459,26 @@ __host__ __device__ __forceinline__ unsigned int lk_hash3(int x, int y, int z) {
     h ^= h >> 16;
     return h;
 }
+// Keeps a loaded 16-B chunk from being sunk below this point: the compiler moves a load next to its first use, and the uses of a
+// match record sit behind three data-dependent tests (cell empty? plane? range gate) - the kernel's ISA had THREE dependent L2
+// round trips per candidate (pad_ word; header + flags, then d / radius; the 80-B tail) where the layout was designed for one.
+__device__ __forceinline__ void pin_chunk(double2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void pin_chunk(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin_chunk(int4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+#ifndef LK_PIN_RECORD
+#define LK_PIN_RECORD 1   // records and table entries are requested whole and PINNED ahead of the first test of any part of them (0: loads
+                          // where the source has them - the compiler sinks them behind the tests; A/B)
+#endif
 // Linear probing, two consecutive slots per round trip: a wave waits for its slowest lane, and with ~14 distinct keys
 // per wave at load factor 0.3 some lane almost always needs a second probe; both slots are requested together.
 __device__ __forceinline__ int hash_find(const LkMap& m, int kx, int ky, int kz) {
     unsigned int s = lk_hash3(kx, ky, kz) & m.hash_mask;
     for (unsigned int probe = 0; probe <= m.hash_mask; probe += 2) {
-        const int4 e0 = m.hash[s];
-        const int4 e1 = m.hash[(s + 1) & m.hash_mask];
+        int4 e0 = m.hash[s];
+        int4 e1 = m.hash[(s + 1) & m.hash_mask];
+#if LK_PIN_RECORD
+        pin_chunk(e0), pin_chunk(e1);   // really ONE round trip: left alone, the compiler fetches e0.w, then e0's key, then e1
+#endif
         if (e0.w == LK_EMPTY) return -1;
         if (e0.w >= 0 && e0.x == kx && e0.y == ky && e0.z == kz) return e0.w;
         if (e1.w == LK_EMPTY) return -1;

@@ -63,15 +63,6 @@ struct Match {
 // voxel_map.cc:371-413 for one plane node.  q0..q2 / tail = the first 64 B of the node's match record (center,
 // normal, d, radius, flags), already in registers; the remaining 80 B (S11, w, s22) are requested BEFORE the float
 // range gate is evaluated so that the whole record costs one memory round trip.
-#ifndef LK_PIN_RECORD
-#define LK_PIN_RECORD 1   // frozen-map matcher: all nine 16-B chunks of a candidate's record are requested at once and PINNED ahead of the
-                          // first test of any of them (0: loads where the source has them - the compiler sinks them behind the tests)
-#endif
-// Keeps a loaded 16-B chunk from being sunk below this point: the compiler moves a load next to its first use, and the uses of a
-// match record sit behind three data-dependent tests (cell empty? plane? range gate) - the kernel's ISA had THREE dependent L2
-// round trips per candidate (pad_ word; header + flags, then d / radius; the 80-B tail) where the layout was designed for one.
-__device__ __forceinline__ void pin_chunk(double2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
-__device__ __forceinline__ void pin_chunk(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 struct RecTail {   // bytes 64..143 of a match record: S11 (6), w (3), s22
     double2 v0, v1, v2, v3, v4;
 };
@@ -157,14 +148,24 @@ __device__ __forceinline__ bool match_root(const LkMap& m, int root, const bool 
             const lk_match_rec* pl = &m.match[node];
             const double2* q = reinterpret_cast<const double2*>(pl);
             double2 q0 = q[0], q1 = q[1], q2 = q[2];
-            const float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad (grid cells: node id)
+            float4 tail = *reinterpret_cast<const float4*>(&pl->d);  // d, radius, flags, pad (grid cells: node id)
+#if LK_PIN_RECORD
+            RecTail rt;   // the whole record in one round trip (see pin_chunk)
+            rt.v0 = q[4], rt.v1 = q[5], rt.v2 = q[6], rt.v3 = q[7], rt.v4 = q[8];
+            pin_chunk(q0), pin_chunk(q1), pin_chunk(q2), pin_chunk(tail);
+            pin_chunk(rt.v0), pin_chunk(rt.v1), pin_chunk(rt.v2), pin_chunk(rt.v3), pin_chunk(rt.v4);
+#endif
             if (grid_cell && level == 0) {
                 const unsigned int id = __float_as_uint(tail.w);
                 if (id == LK_GRID_EMPTY) return false;  // no root voxel at this key
                 n0 = node = (int)id;
             }
             if (!LK_X_NOEVAL && (__float_as_uint(tail.z) & LK_PLANE_IS_PLANE)) {
+#if LK_PIN_RECORD
+                eval_plane<XID, true>(pl, q0, q1, q2, tail.x, tail.y, node, level, g, bc, pr, success, prob, best, &rt);
+#else
                 eval_plane<XID>(pl, q0, q1, q2, tail.x, tail.y, node, level, g, bc, pr, success, prob, best);
+#endif
                 --level;
                 fresh = false;
                 continue;
@@ -177,7 +178,10 @@ __device__ __forceinline__ bool match_root(const LkMap& m, int root, const bool 
             cis &= ~(15u << (4 * level));
         }
         const int4* ch = reinterpret_cast<const int4*>(m.nodes[node].child);
-        const int4 ca = ch[0], cb = ch[1];
+        int4 ca = ch[0], cb = ch[1];
+#if LK_PIN_RECORD
+        pin_chunk(ca), pin_chunk(cb);
+#endif
         unsigned int ci = (cis >> (4 * level)) & 15u;
         int child = -1;
         while (ci < 8u && child < 0) {
@@ -718,6 +722,27 @@ __device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkPa
         bool ignore = false;
         for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
             const lk_node_rec* nr = &map.nodes[node];
+#if LK_PIN_RECORD
+            // the node's record (children, centre, layer, state: bytes 0..79) and its plane flags in ONE round trip
+            int4 n0 = reinterpret_cast<const int4*>(nr)[0], n1 = reinterpret_cast<const int4*>(nr)[1], n2 = reinterpret_cast<const int4*>(nr)[2],
+                 n3 = reinterpret_cast<const int4*>(nr)[3], n4 = reinterpret_cast<const int4*>(nr)[4];
+            unsigned int pf = map.planes[node].flags;
+            pin_chunk(n0), pin_chunk(n1), pin_chunk(n2), pin_chunk(n3), pin_chunk(n4);
+            asm volatile("" : "+v"(pf));
+            const unsigned int st = (unsigned int)n4.z;
+            if (!(st & LK_NODE_INIT_OCTO)) break;
+            const bool is_plane = (pf & LK_PLANE_IS_PLANE) != 0;
+            const int layer = n3.w;
+            if (is_plane || layer >= pr.max_layer) {
+                ignore = !(st & LK_NODE_UPDATE_ENABLE);
+                break;
+            }
+            const double cx = __hiloint2double(n2.y, n2.x), cy = __hiloint2double(n2.w, n2.z), cz = __hiloint2double(n3.y, n3.x);
+            const int oct = ((g.p_w.x > cx) ? 4 : 0) + ((g.p_w.y > cy) ? 2 : 0) + ((g.p_w.z > cz) ? 1 : 0);
+            const int child = oct == 0 ? n0.x : oct == 1 ? n0.y : oct == 2 ? n0.z : oct == 3 ? n0.w : oct == 4 ? n1.x : oct == 5 ? n1.y : oct == 6 ? n1.z : n1.w;
+            if (child < 0) break;
+            node = child;
+#else
             const unsigned int st = nr->state;
             const unsigned int pf = map.planes[node].flags;
             if (!(st & LK_NODE_INIT_OCTO)) break;
@@ -732,6 +757,7 @@ __device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkPa
             const int child = nr->child[oct];
             if (child < 0) break;
             node = child;
+#endif
         }
         if (ignore) return;
     }
