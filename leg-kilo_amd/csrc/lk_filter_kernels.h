@@ -12,6 +12,9 @@
 #include "lk_device.h"
 
 #define LK_FB 256  // threads per filter block
+#ifndef LK_MFMA_COV
+#define LK_MFMA_COV 0   // 1 (A/B build): the covariance update P -= P[:,0:6] X of the one-wave update core on v_mfma_f64_16x16x4_f64
+#endif
 #ifndef LK_X_P
 #define LK_X_P 0   // perf attribution only (never set in the product build): bit 1 skip the rotations of the wave predict, 2 the
 #endif             // covariance products, 4 the Q term, 8 the Gauss-Jordan sweep of the wave update, 16 its P update, 32 its (+)
@@ -500,6 +503,65 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         for (int m = 0; m < 6; ++m) dxv += sm.P[i * 30 + m] * lane_bcast_u(col[m], 36);
         asm volatile("" : "+v"(dxv));  // finished here: keeps its six operands from living across the loop below
     }
+#if LK_MFMA_COV
+    // -- P -= P[:,0:6] X[:,0:30] on the matrix pipe (A/B build, -DLK_MFMA_COV=1): the 30 x 30 result as 2 x 2 tiles of
+    // v_mfma_f64_16x16x4_f64, K = 6 padded to 8 -> eight instructions.  Operand layout measured on gfx950
+    // (tools/probes/mfma_f64_16x16x4_layout.hip): lane l feeds A[l % 16][l / 16] and B[l / 16][l % 16]; d[v] of lane l is
+    // D[l / 16 + 4 v][l % 16].  A = -P[:,0:6] from LDS, B = X gathered from the lanes that hold its columns (X[m][c] = col[m] of lane
+    // 6 + c), C = P.  A different summation order than the VALU form below (k = 0..3, then 4..7): not bit-identical to it.
+    {
+        typedef double lk_d4 __attribute__((ext_vector_type(4)));
+        const int r16 = lane & 15, k4 = lane >> 4;
+        double Bop[2][2], Aop[2][2];   // [k-step][tile]
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int j = 16 * tj + r16;
+            const int src = 6 + (j < 30 ? j : 0);
+            double t[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) t[m] = __shfl(col[m], src, LK_WAVE);
+            Bop[0][tj] = j < 30 ? (k4 == 0 ? t[0] : k4 == 1 ? t[1] : k4 == 2 ? t[2] : t[3]) : 0.0;
+            Bop[1][tj] = (j < 30 && k4 < 2) ? (k4 == 0 ? t[4] : t[5]) : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int i = 16 * ti + r16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int k = 4 * ks + k4;
+                Aop[ks][ti] = (i < 30 && k < 6) ? -sm.P[i * 30 + k] : 0.0;
+            }
+        }
+        lk_d4 acc[2][2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * ti + k4 + 4 * v, j = 16 * tj + r16;
+                    acc[ti][tj][v] = (i < 30 && j < 30) ? sm.P[i * 30 + j] : 0.0;
+                }
+        core_sync<MW>();   // every operand has been read before any entry of P is rewritten
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[0][ti], Bop[0][tj], acc[ti][tj], 0, 0, 0);
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[1][ti], Bop[1][tj], acc[ti][tj], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * ti + k4 + 4 * v, j = 16 * tj + r16;
+                    if (i < 30 && j < 30) sm.P[i * 30 + j] = acc[ti][tj][v];
+                }
+        core_sync<MW>();
+    }
+#else
     // -- P -= P[:,0:6] X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...  A row's new values depend on
     // that row only, so five rows at a time are read, then written.
     {
@@ -526,6 +588,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
             core_sync<MW>();
         }
     }
+#endif
     // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
     const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0 && !(LK_X_P & 32)) {
