@@ -68,6 +68,8 @@ struct lk_handle {
     unsigned int epoch = 16;      // bucket sequence number: stamps of LkMap::dirty / newroot, value of spec[LK_SPEC_DONE]
     unsigned int spec_base = 16;  // first epoch of the open window (stamps below it belong to inserts that were joined)
     bool spec_open = false;       // inserts may still be running on `ins`
+    int gridscan_mode = 1;        // scans of large buckets as one grid-resident launch (lk_scan_grid_kernel): 0 never, 1 when every bucket holds
+                                  // 513 .. LK_GRIDSCAN_AUTO_MAX points (where it measures faster than the launches), 2 whenever it applies; LEGKILO_GRIDSCAN / lk_stream_grid
     bool resident_enable = true;  // scans of small buckets as one resident launch (lk_scan_stream_kernel); LEGKILO_RESIDENT=0 / lk_stream_resident(h, 0): per-bucket launches
     bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
@@ -305,6 +307,7 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_I, hipEventDisableTiming));
     if (const char* e = getenv("LEGKILO_SPEC")) h->spec_enable = atoi(e) != 0;
     if (const char* e = getenv("LEGKILO_RESIDENT")) h->resident_enable = atoi(e) != 0;
+    if (const char* e = getenv("LEGKILO_GRIDSCAN")) h->gridscan_mode = std::min(std::max(atoi(e), 0), 2);
     HIPCHK(h, hipMalloc(&h->d_snap, sizeof(LkFilter) * 2));
     HIPCHK(h, hipMemsetAsync(h->d_snap, 0, sizeof(LkFilter) * 2, h->stream));
     HIPCHK(h, hipMalloc(&h->d_ids, sizeof(int2) * (size_t)m.max_scan));
@@ -997,6 +1000,127 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     if (lane == 0) {
         f->last_update_t = t_upd, f->last_predict_t = t_pred;
         f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
+    }
+}
+extern "C" {
+
+// ------------------------------------------------------------------ grid-resident stream kernel (large buckets)
+// The bucket loop of KILO::process (KILO.cc:375-395) for a scan of LARGE buckets as ONE launch of G co-resident workgroups: the phases
+// that are separate launches on the stream path - residual tiles | update + snapshot + bookkeeping | re-projection (workgroup 0 runs
+// the next bucket's predict beside it) | root pass | emitted groups | fallback items - separated by GRID BARRIERS instead of kernel
+// boundaries, and the last two phases only entered when the device counters say there is work for them (the host cannot know that
+// without a synchronisation, the launch version always pays both).  Same device functions in the same order as enqueue_bucket():
+// identical bits.  A barrier is the placement-independent hand-off of the CDNA guide: every wave drains its stores, the workgroup
+// meets, thread 0 issues ONE agent-scope release, arrives on a global counter, polls it (relaxed), issues ONE agent-scope acquire
+// (+ scalar-cache invalidate), the workgroup meets again.  Every wait is bounded: a timeout raises the abort word, every workgroup
+// leaves, the call fails with LK_ERR_TIMEOUT.  Off by default (lk_stream_grid / LEGKILO_GRIDSCAN=1): measured in DESIGN.md section 6.
+#define LK_GRIDSCAN_WG_MAX 128
+}  // extern "C" (a kernel template follows)
+template <bool XID>
+__global__ void __launch_bounds__(LK_FB)
+    lk_scan_grid_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
+                        LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort */, unsigned int timeout_ms) {
+    __shared__ FilterSmem sm;
+    __shared__ double red[8][LK_NPART];
+    __shared__ double tot[LK_NPART];
+    __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
+    __shared__ int s_abort;
+    const int G = (int)gridDim.x, wg = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nbk = rag_nb(rg, 0);
+    if (nbk == 0) return;
+    const double* T = rag_t(rg, 0);
+    const unsigned long long* po = rag_pt_off(rg, 0);
+    const unsigned long long timeout_ticks = (unsigned long long)timeout_ms * 100000ull;
+    unsigned int phase = 0;
+    if (tid == 0) s_abort = 0;
+    auto grid_barrier = [&]() -> bool {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        phase += 1;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int need = (unsigned int)G * phase;
+            unsigned long long t0 = 0;
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    s_abort = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 255u) == 0u) {
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > timeout_ticks) {
+                        __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicOr(&map.counters[LK_CTR_ERR], LK_E_SPEC_TIMEOUT);
+                        s_abort = 1;
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_s_dcache_inv();
+        }
+        __syncthreads();
+        return s_abort == 0;
+    };
+    __syncthreads();
+    if (wg == 0) dev_predict(&filters[0], Q, T[0], sm);   // KILO.cc:111-115 for the first bucket
+    if (!grid_barrier()) return;
+    for (int b = 0; b < nbk; ++b) {
+        const unsigned long long base = po[b];
+        const int n = (int)(po[b + 1] - base);
+        const int ntiles = (n + LK_WAVE - 1) / LK_WAVE;
+        const lk_point* bp = pts + base;
+        float* bw = world ? world + 4 * base : nullptr;
+        {   // residual pass: tile t by wave t of the grid (lk_residual_kernel's body, one partial record per tile)
+            BucketConst bc;
+            load_bucket_const<false>(&filters[0], pr, bc);
+            ResidualOut ro;
+            ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = bw, ro.ids = nullptr;
+            for (int tile = wg * (LK_FB / LK_WAVE) + wv; tile < ntiles; tile += G * (LK_FB / LK_WAVE)) {
+                __builtin_amdgcn_wave_barrier();
+                const double acc = residual_tile<false, 0, XID, false>(map, pr, bc, reinterpret_cast<const float4*>(bp), tile * LK_WAVE + lane, n, &rows[wv][0], lane, ro, (size_t)0);
+                if (lane < LK_NPART) partials[(size_t)tile * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
+            }
+        }
+        if (!grid_barrier()) return;
+        if (wg == 0) {   // lk_update_snap_kernel: fixed-order sum of the tiles' records, update, posterior snapshot, pool bookkeeping
+            dev_update_reduce(&filters[0], partials, ntiles, T[b], Q, 0.0, 0, sm, red, tot);
+            dev_snapshot_posterior(&filters[0], snap);
+            dev_bucket_begin(map);
+        }
+        if (!grid_barrier()) return;
+        // re-projection + root hashing from the snapshot; workgroup 0 propagates the live filter to the next bucket meanwhile
+        if (wg == 0 && G > 1) {
+            if (b + 1 < nbk) dev_predict(&filters[0], Q, T[b + 1], sm);
+        } else {
+            const int w0 = G > 1 ? wg - 1 : 0, nw = G > 1 ? G - 1 : 1;
+            for (int i = w0 * LK_FB + tid; i < n; i += nw * LK_FB) dev_reproject_point(map, pr, snap, bp, bw, 1, i);
+            if (G == 1 && b + 1 < nbk) {
+                __syncthreads();
+                dev_predict(&filters[0], Q, T[b + 1], sm);
+            }
+        }
+        if (!grid_barrier()) return;
+        const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_touched > 0) {
+            dev_insert_root<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+            if (!grid_barrier()) return;
+            const unsigned int n_groups = __hip_atomic_load(&map.counters[LK_CTR_GROUPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_groups) {
+                dev_insert_apply<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+                if (!grid_barrier()) return;
+            }
+            const unsigned int n_fb = __hip_atomic_load(&map.counters[LK_CTR_FALLBACK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_fb) {
+                dev_insert_fallback<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+                if (!grid_barrier()) return;
+            }
+        }
     }
 }
 extern "C" {
@@ -1961,27 +2085,89 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
                                                 h->d_ids, epoch0, timeout_ms));
     return LK_OK;
 }
+// The bucket loop of a scan of LARGE buckets as one grid-resident launch (lk_scan_grid_kernel); same table layout as run_scan_resident.
+static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<unsigned long long>& bstart, const std::vector<double>& btime,
+                         size_t biggest, float* d_world) {
+    const size_t nb = btime.size();
+    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_nb = o_t + 8 * nb, o_io = o_nb + 8, o_sync = o_io + 8, bytes = o_sync + 16;
+    int rc = rag_reserve(h, bytes);
+    if (rc) return rc;
+    unsigned char* stage = static_cast<unsigned char*>(h->h_rag);
+    memcpy(stage + o_po, bstart.data(), 8 * (nb + 1));
+    memcpy(stage + o_t, btime.data(), 8 * nb);
+    const unsigned int nbu[2] = {(unsigned int)nb, 0u}, io[2] = {0u, 0u}, zero4[4] = {0u, 0u, 0u, 0u};
+    memcpy(stage + o_nb, nbu, 8);
+    memcpy(stage + o_io, io, 8);
+    memcpy(stage + o_sync, zero4, 16);
+    HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
+    LkRagged rg;
+    memset(&rg, 0, sizeof(rg));
+    rg.pt_off = reinterpret_cast<const unsigned long long*>(dr + o_po);
+    rg.t = reinterpret_cast<const double*>(dr + o_t);
+    rg.nb = reinterpret_cast<const unsigned int*>(dr + o_nb);
+    rg.ldb = (int)nb;
+    rg.bstart = nullptr;
+    rg.imu_off = reinterpret_cast<const unsigned int*>(dr + o_io);
+    rg.q_diag = h->q_diag ? 1 : 0;
+    h->grid_valid = false;   // the map changes
+    static const bool xid_en = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const bool xid = h->pr.ext_identity && xid_en;
+    static const unsigned int timeout_ms = getenv("LEGKILO_RESIDENT_TIMEOUT_MS") ? (unsigned int)std::max(1, atoi(getenv("LEGKILO_RESIDENT_TIMEOUT_MS"))) : LK_RESIDENT_TIMEOUT_MS;
+    static const int wg_env = getenv("LEGKILO_GRIDSCAN_WG") ? atoi(getenv("LEGKILO_GRIDSCAN_WG")) : 0;
+    const int tiles = (int)((biggest + LK_WAVE - 1) / LK_WAVE);
+    int G = wg_env > 0 ? wg_env : std::max(8, (tiles + 3) / 4 + 4);   // a wave per tile of the largest bucket and a few more for the per-root passes; every
+                                                                      // further workgroup makes each barrier dearer (51 x 1 960 points: 12 workgroups 2.33 ms, 32: 2.43, 128: 2.81)
+    G = std::min(G, LK_GRIDSCAN_WG_MAX);                             // 128 workgroups of 4 waves are resident on 256 CUs whatever else is true
+    const auto k = xid ? lk_scan_grid_kernel<true> : lk_scan_grid_kernel<false>;
+    LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
+                                              h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms));
+    return LK_OK;
+}
 // a scan is taken by the resident kernel when all its buckets are small (LEGKILO_RESIDENT=0: always per-bucket launches)
 static bool resident_enabled(const lk_handle* h) { return h->resident_enable && !h->profiling && !h->spec_enable; }
+#define LK_GRIDSCAN_AUTO_MAX 4096   // largest bucket of a scan the grid-resident kernel takes by default: 51 x 1 960 points 2.53 -> 2.34 ms per scan, 5 x 20 000 0.43 -> 0.54 (it runs on G <= 128 workgroups)
+static bool grid_enabled(const lk_handle* h) { return h->gridscan_mode != 0 && !h->profiling && !h->spec_enable; }
+static bool grid_takes(const lk_handle* h, size_t smallest, size_t biggest) {
+    return grid_enabled(h) && smallest > (size_t)LK_SMALL_MAX && (h->gridscan_mode == 2 || biggest <= (size_t)LK_GRIDSCAN_AUTO_MAX);
+}
 
 static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n, double t_begin, const lk_imu* imus,
                     size_t n_imu, const lk_kin_imu* kins, size_t n_kin, float* xyz_world_out, lk_pose* out) {
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
-    if (resident_enabled(h)) {
+    if (resident_enabled(h) || grid_enabled(h)) {
         std::vector<unsigned long long> bstart;
         std::vector<double> btime;
-        size_t biggest = 0;
+        size_t biggest = 0, smallest = n;
         for (size_t i = 0; i < n;) {   // runs of equal curvature = buckets (KILO.cc:375-378)
             size_t j = i + 1;
             while (j < n && pts[i].curvature == pts[j].curvature) j++;
             bstart.push_back(i);
             btime.push_back(t_begin + pts[i].curvature);
             biggest = std::max(biggest, j - i);
+            smallest = std::min(smallest, j - i);
             i = j;
         }
         bstart.push_back(n);
-        if (biggest <= LK_RESIDENT_MAX) {
+        if (grid_takes(h, smallest, biggest) && n_imu == 0 && n_kin == 0) {   // every bucket takes the large-bucket kernels: one grid-resident launch
+            rc = run_scan_grid(h, d_pts, bstart, btime, biggest, xyz_world_out ? h->d_world : nullptr);
+            if (rc) return rc;
+            std::vector<float> w;
+            if (xyz_world_out) {
+                w.resize(4 * n);
+                HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+            }
+            lk_pose pose;
+            if ((rc = fetch_poses(h, &pose, 1))) return rc;
+            if ((rc = check_map_errors(h))) return rc;
+            if (xyz_world_out)
+                for (size_t i = 0; i < n; ++i)
+                    for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
+            if (out) *out = pose;
+            return LK_OK;
+        }
+        if (resident_enabled(h) && biggest <= LK_RESIDENT_MAX) {
             rc = run_scan_resident(h, d_pts, bstart, btime, n_kin ? (const void*)kins : (const void*)imus, n_kin ? n_kin : n_imu, n_kin ? 2 : (n_imu ? 1 : 0),
                                    xyz_world_out ? h->d_world : nullptr);
             if (rc) return rc;
@@ -2062,18 +2248,27 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     }
     int rc = zero_scan_counters(h, 0, 1);
     if (rc) return rc;
-    if (resident_enabled(h)) {
+    if (resident_enabled(h) || grid_enabled(h)) {
         std::vector<unsigned long long> bstart;
         std::vector<double> btime;
-        uint32_t biggest = 0;
+        uint32_t biggest = 0, smallest = 0xffffffffu;
         for (size_t b = 0; b < n_buckets; ++b) {
             if (bucket_off[b + 1] <= bucket_off[b]) continue;
             bstart.push_back(bucket_off[b]);
             btime.push_back(t_begin + bucket_dt[b]);
             biggest = std::max(biggest, bucket_off[b + 1] - bucket_off[b]);
+            smallest = std::min(smallest, bucket_off[b + 1] - bucket_off[b]);
         }
         bstart.push_back(bucket_off[n_buckets]);
-        if (!btime.empty() && biggest <= LK_RESIDENT_MAX) {
+        if (!btime.empty() && grid_takes(h, smallest, biggest)) {
+            if ((rc = run_scan_grid(h, d_pts, bstart, btime, biggest, nullptr))) return rc;
+            lk_pose pose;
+            if ((rc = fetch_poses(h, &pose, 1))) return rc;
+            if ((rc = check_map_errors(h))) return rc;
+            if (out) *out = pose;
+            return LK_OK;
+        }
+        if (!btime.empty() && resident_enabled(h) && biggest <= LK_RESIDENT_MAX) {
             if ((rc = run_scan_resident(h, d_pts, bstart, btime, nullptr, 0, 0, nullptr))) return rc;
             lk_pose pose;
             if ((rc = fetch_poses(h, &pose, 1))) return rc;
@@ -3043,6 +3238,11 @@ int lk_stream_pipeline(lk_handle* h, int on) {
 int lk_stream_resident(lk_handle* h, int on) {
     CHECK_H(h);
     h->resident_enable = on != 0;
+    return LK_OK;
+}
+int lk_stream_grid(lk_handle* h, int on) {
+    CHECK_H(h);
+    h->gridscan_mode = std::min(std::max(on, 0), 2);
     return LK_OK;
 }
 int lk_stream_stats(lk_handle* h, uint64_t* out4) {

@@ -652,6 +652,42 @@ def test_scan_resident_kernel_edge_buckets(scene, oracle_lib, hip_lib):
         obj.close()
 
 
+@pytest.mark.parametrize("nb", [5, 51])
+def test_scan_grid_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_lib, nb):
+    """The grid-resident stream kernel (lk_scan_grid_kernel: the whole bucket loop of a scan of LARGE buckets as one launch of
+    co-resident workgroups, grid barriers instead of kernel boundaries, lk_stream_grid) against the per-bucket launches on a second
+    handle: state, covariance, re-projected cloud and map bit for bit over three consecutive 100 000-point scans (5 buckets of
+    20 000 / 51 two-ms bins of ~1 960) on a young map - inits, refits, cuts, emitted leaf groups and fallback items all occur - and
+    both equal to the oracle (counts exact, state 1e-6)."""
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg())
+    g_seq = hip_lib.LegKiloHip(scene.cfg())
+    g.stream_grid(2)       # any bucket size (the default takes buckets up to 4 096 points)
+    g_seq.stream_grid(0)
+    t0 = 13.0
+    for obj in (o, g, g_seq):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, dense=20000)
+    for k in range(3):
+        tb = t0 + 0.1 * k
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=nb, seed_scan=9300 + k, seed_noise=9400 + k)
+        po, _ = o.process_scan(pts, tb)
+        pg, wg = g.process_scan(pts, tb, want_world=True)
+        ps, ws = g_seq.process_scan(pts, tb, want_world=True)
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (pg.n_buckets, pg.n_updates, int(pg.n_effect)) == (ps.n_buckets, ps.n_updates, int(ps.n_effect)), \
+            (k, po.n_effect, pg.n_effect, ps.n_effect)
+        xo, _ = o.get_state()
+        xg, Pg = g.get_state()
+        xs, Ps = g_seq.get_state()
+        assert np.abs(xo - xg).max() < 1e-6, (k, np.abs(xo - xg).max())
+        assert np.array_equal(xg, xs) and np.array_equal(Pg, Ps), (k, np.abs(xg - xs).max())
+        assert np.array_equal(wg, ws), k
+    scenes.maps_identical(g.map_export(), g_seq.map_export())
+    assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
+    for obj in (g, g_seq, o):
+        obj.close()
+
+
 def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
     """The pipelined stream path (insert of bucket k on its own stream beside predict + residual of bucket k+1, verify pass,
     legkilo_hip.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
