@@ -163,6 +163,8 @@ def main():
     # step; `--step-sweep`: elapsed(K) = 0.15 + 1.685 K ms once warm); `extra.sustained_*` is the >= 1 s figure
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--ramp-steps", type=int, default=30, help="untimed steps BEFORE the warm-up steps (clocks up after the idle set-up phase): the driver's "
+                    "--warmup 5 left ~3 %% of ramp inside its 20-step region; not counted as warm-up, never timed")
     ap.add_argument("--scans-per-gpu", type=int, default=1024, help="weak scaling: a batch of 1024 scans per GPU (fits one GPU)")
     ap.add_argument("--total-scans", type=int, default=0, help="strong scaling: this many scans in total, block-sharded over the GPUs "
                     "(BASELINE config 5 as worded: 1024 -> 128 per GPU at N=8); 0 = weak scaling")
@@ -346,6 +348,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    for k in range(args.ramp_steps):   # untimed: brings the clocks up (the sustained rate is what the timed region should see)
+        step(k)
+    finish(min(args.ramp_steps, ring_rows))
     for k in range(args.warmup):
         step(k)
     finish(args.warmup)
@@ -461,6 +466,10 @@ def main():
     l2_GBs = pmc["tcc_req_per_point"] * 128.0 * pts_per_launch / (launch_ms * 1e-3) / 1e9 if pmc and pmc.get("tcc_req_per_point") else None
     valu_frac = (pmc["valu_insts_per_wave"] * 4.0 * (pts_per_launch / 64.0) / (SIMDS * CLK_GHZ * 1e9 * launch_ms * 1e-3)
                  if pmc and pmc.get("valu_insts_per_wave") else None)
+    # the same with the issue cost of each instruction class on a SIMD-16 pipe: 4 cycles per fp64 wave instruction (half rate), 2 per other VALU
+    fp64_pw = pmc.get("fp64_insts_per_wave") if pmc else None
+    valu_frac_class = (((fp64_pw * 4.0 + (pmc["valu_insts_per_wave"] - fp64_pw) * 2.0) * (pts_per_launch / 64.0) / (SIMDS * CLK_GHZ * 1e9 * launch_ms * 1e-3))
+                       if pmc and fp64_pw and pmc.get("valu_insts_per_wave") else None)
     alg_GBs = ALG_BYTES_RESIDUAL * pts_per_launch / (launch_ms * 1e-3) / 1e9
     roofline = {
         "kernel": "lk_residual_kernel<false>",
@@ -474,6 +483,8 @@ def main():
         "hbm_bytes_per_point_counters": hbm_bpp,
         "l2_GBs": None if l2_GBs is None else round(l2_GBs, 1), "l2_frac": None if l2_GBs is None else round(l2_GBs / L2_PEAK_GBS, 4),
         "valu_issue_frac": None if valu_frac is None else round(valu_frac, 3),
+        "valu_issue_frac_by_class": None if valu_frac_class is None else round(valu_frac_class, 3),
+        "valu_issue_cost_model": "valu_issue_frac charges 4 cycles to every VALU wave instruction; _by_class charges 4 to fp64 (half rate on the 16-lane pipe) and 2 to the others",
         # the roofline the kernel lives on: fp64 vector FLOP/s (counter-derived: 2 FMA + ADD + MUL + TRANS wave instructions x 64 lanes)
         "fp64_flops": None if fp64_flops is None else round(fp64_flops), "fp64_TFLOPs": None if fp64_tflops is None else round(fp64_tflops, 2),
         "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS, "fp64_frac": None if fp64_tflops is None else round(fp64_tflops / FP64_PEAK_TFLOPS, 4),
@@ -531,6 +542,7 @@ def main():
             extra["overlay_error"] = f"{type(e).__name__}: {str(e)[:300]}"
             warnings.append("overlay replay failed: " + extra["overlay_error"])
 
+    extra["ramp_steps_before_warmup"] = args.ramp_steps
     extra.update({"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
                   "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok, "rccl_map_broadcast_ms": bcast_ms,
                   "rccl_map_scatter_allgather_ms": bcast2_ms})
