@@ -1,5 +1,6 @@
 // Minimal use of the C++ mirror, written the way KILO.cc drives the reference classes: first-frame
-// BuildVoxelMap on a synthetic floor + wall, one predictUpdatePoint bucket, then a two-scan recorded-run replay.  Needs a gfx950 device
+// BuildVoxelMap on a synthetic floor + wall, one predictUpdatePoint bucket, then a two-scan recorded-run replay (frozen map) and the same
+// two scans with the per-scan map insert (overlay replay).  Needs a gfx950 device
 // to RUN (exit code 3 otherwise); tests/test_abi_and_host.py only checks that it compiles and links.  With a path as argv[1] it
 // dumps its inputs and results (a flat binary: counts, the two clouds, x36 after the bucket, the match count, the replay poses) so
 // that tests/test_golden.py can replay the SAME inputs through the oracle and compare state and counts, not just sanity.
@@ -61,6 +62,11 @@ int main(int argc, char** argv) {
     std::vector<lk_pose> poses = kilo->replayRecordedRun({scan, scan}, {0.02, 0.05}, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
     std::printf("replay: %u / %u buckets, matched %llu / %llu\n", poses[0].n_buckets, poses[1].n_buckets,
                 (unsigned long long)poses[0].n_effect, (unsigned long long)poses[1].n_effect);
+    // and once more WITH the map insert after every bucket, each scan on its own copy-on-write overlay of the map (KILO::process's
+    // own order of events, for a batch): the map itself stays as it is
+    std::vector<lk_pose> ov = kilo->replayWithInsert({scan, scan}, 0.02, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
+    std::printf("replay with insert: matched %llu / %llu\n", (unsigned long long)ov[0].n_effect, (unsigned long long)ov[1].n_effect);
+    poses.insert(poses.end(), ov.begin(), ov.end());
     if (argc > 1) {
         FILE* f = std::fopen(argv[1], "wb");
         if (!f) return 4;
@@ -75,6 +81,6 @@ int main(int argc, char** argv) {
         std::fwrite(poses.data(), sizeof(lk_pose), poses.size(), f);
         std::fclose(f);
     }
-    const bool replay_ok = poses.size() == 2 && poses[0].n_buckets == 2 && poses[1].n_buckets == 2 && poses[1].n_effect > 500;
+    const bool replay_ok = poses.size() == 4 && poses[0].n_buckets == 2 && poses[1].n_buckets == 2 && poses[1].n_effect > 500 && poses[3].n_buckets == 2 && poses[3].n_effect > 500;
     return (updated && n_success > 500 && std::fabs(p[2] - 0.5) < 0.05 && replay_ok) ? 0 : 1;
 }

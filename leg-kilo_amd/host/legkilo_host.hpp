@@ -384,6 +384,48 @@ class KiloPath {
         return out;
     }
 
+    // Many equally shaped scans at once WITH the map insert of KILO::process (KILO.cc:216-233 after every bucket): scan s runs the whole
+    // bucket loop on filter slot s from its own prior and inserts into its OWN copy-on-write overlay of the current map
+    // (lk_batch_replay_overlay_dev); the map itself is not changed.  All scans share their bucket bounds (runs of equal curvature of
+    // scan 0, KILO.cc:375-378) and start time.  Per scan the result equals processSorted() on a private copy of the map.
+    std::vector<lk_pose> replayWithInsert(const std::vector<PointCloudType>& sorted_scans, double t_begin, const std::vector<State>& prior_states,
+                                          const std::vector<StateCov>& prior_covs) {
+        const size_t S = sorted_scans.size();
+        if (S == 0 || prior_states.size() != S || prior_covs.size() != S) throw std::runtime_error("replayWithInsert: one prior state and covariance per scan");
+        const size_t n = sorted_scans[0].size();
+        std::vector<uint32_t> off(1, 0);
+        std::vector<double> dt;
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while (j < n && sorted_scans[0][i].curvature == sorted_scans[0][j].curvature) ++j;
+            dt.push_back((double)sorted_scans[0][i].curvature);
+            off.push_back((uint32_t)j);
+            i = j;
+        }
+        std::vector<lk_point> pts;
+        pts.reserve(S * n);
+        std::vector<double> x36(S * LK_STATE_DOUBLES), P900(S * DIM_STATE * DIM_STATE);
+        for (size_t s = 0; s < S; ++s) {
+            const PointCloudType& sc = sorted_scans[s];
+            if (sc.size() != n) throw std::runtime_error("replayWithInsert: the scans of a batch have one size");
+            for (size_t b = 0; b + 1 < off.size(); ++b)
+                if (sc[off[b]].curvature != sorted_scans[0][off[b]].curvature || sc[off[b + 1] - 1].curvature != sc[off[b]].curvature)
+                    throw std::runtime_error("replayWithInsert: the scans of a batch share their time buckets");
+            for (size_t i = 0; i < n; ++i) pts.push_back(lk_point{sc[i].x, sc[i].y, sc[i].z, sc[i].curvature});
+            prior_states[s].to_x36(&x36[s * LK_STATE_DOUBLES]);
+            std::memcpy(&P900[s * DIM_STATE * DIM_STATE], prior_covs[s].d.data(), sizeof(double) * DIM_STATE * DIM_STATE);
+        }
+        void* d_pts = nullptr;
+        dev_->check(lk_device_malloc(dev_->h(), &d_pts, sizeof(lk_point) * std::max<size_t>(pts.size(), 1)));
+        std::vector<lk_pose> out(S);
+        int rc = lk_memcpy_h2d(dev_->h(), d_pts, pts.data(), sizeof(lk_point) * pts.size());
+        if (!rc) rc = lk_batch_set_priors(dev_->h(), x36.data(), P900.data(), S);
+        if (!rc) rc = lk_batch_replay_overlay_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, n, t_begin, off.data(), dt.data(), dt.size(), out.data());
+        lk_device_free(dev_->h(), d_pts);
+        dev_->check(rc);
+        return out;
+    }
+
    private:
     std::shared_ptr<Device> dev_;
     std::unique_ptr<ESKF> eskf_;

@@ -127,6 +127,17 @@ def test_host_mirror_example_runs(hip_lib, oracle_lib, tmp_path):
         po, _ = o.process_scan(pts, tb)
         assert (int(po.n_buckets), int(po.n_effect)) == (int(poses[k]["n_buckets"]), int(poses[k]["n_effect"])), k
         assert np.abs(np.array(po.pos) - poses[k]["pos"]).max() < 1e-7 and np.abs(np.array(po.rot) - poses[k]["rot"]).max() < 1e-7, k
+    # replayWithInsert: the same two scans, each with KILO::process's insert after every bucket on its OWN copy of the map
+    assert n_poses == 4
+    o.set_map_insert(True)
+    blob = o.map_export()
+    for k, (xs, Ps) in enumerate([(xo, Po), (x0, 1e-6 * np.eye(30))]):
+        o.map_import(blob)
+        o.set_state(xs, Ps)
+        o.set_times(0.02, 0.02)
+        po, _ = o.process_scan(pts, 0.02)
+        assert (int(po.n_buckets), int(po.n_effect)) == (int(poses[2 + k]["n_buckets"]), int(poses[2 + k]["n_effect"])), (k, po.n_effect, poses[2 + k]["n_effect"])
+        assert np.abs(np.array(po.pos) - poses[2 + k]["pos"]).max() < 1e-7 and np.abs(np.array(po.rot) - poses[2 + k]["rot"]).max() < 1e-7, k
     o.close()
 
 

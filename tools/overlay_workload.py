@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--map-warm", type=int, default=20)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="call lk_stream_stats after the replays (a -DLK_DEBUG_INS build prints its insert-phase stamps and histograms there)")
     ap.add_argument("--cache-dir", default="")
     args = ap.parse_args()
     S, U = args.slots, min(args.unique, args.slots)
@@ -80,6 +81,8 @@ def main():
         g.profile_enable(0)
         out["kernel_ms"] = {k: round(g.profile_get(k)[1], 3) for k in ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise",
                                                                           "ov_insert_root", "ov_insert_apply", "ov_insert_fallback")}
+    if args.stats:
+        g.stream_stats()
     print(json.dumps(out))
     g.close()
 
