@@ -59,12 +59,14 @@ int main(int argc, char** argv) {
     // the same bucket twice more as a two-scan "recorded run", each from its own prior, against the (now frozen) map
     PointCloudType scan(bucket.begin(), bucket.end());
     for (size_t i = 0; i < scan.size(); ++i) scan[i].curvature = (i < scan.size() / 2) ? 0.f : 0.002f;   // two time buckets
-    std::vector<lk_pose> poses = kilo->replayRecordedRun({scan, scan}, {0.02, 0.05}, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
+    const auto post_state = kilo->eskf().state();   // copies: the replays below run on the filter slots, slot 0 included
+    const auto post_cov = kilo->eskf().cov();
+    std::vector<lk_pose> poses = kilo->replayRecordedRun({scan, scan}, {0.02, 0.05}, {post_state, s}, {post_cov, P});
     std::printf("replay: %u / %u buckets, matched %llu / %llu\n", poses[0].n_buckets, poses[1].n_buckets,
                 (unsigned long long)poses[0].n_effect, (unsigned long long)poses[1].n_effect);
     // and once more WITH the map insert after every bucket, each scan on its own copy-on-write overlay of the map (KILO::process's
     // own order of events, for a batch): the map itself stays as it is
-    std::vector<lk_pose> ov = kilo->replayWithInsert({scan, scan}, 0.02, {kilo->eskf().state(), s}, {kilo->eskf().cov(), P});
+    std::vector<lk_pose> ov = kilo->replayWithInsert({scan, scan}, 0.02, {post_state, s}, {post_cov, P});
     std::printf("replay with insert: matched %llu / %llu\n", (unsigned long long)ov[0].n_effect, (unsigned long long)ov[1].n_effect);
     poses.insert(poses.end(), ov.begin(), ov.end());
     if (argc > 1) {
