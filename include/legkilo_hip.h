@@ -403,6 +403,11 @@ int lk_stream_resident(lk_handle* h, int on);
  * (51 two-ms bins of a 100 000-point scan: 2.53 -> 2.34 ms); 2: any size (5 x 20 000: slower than the launches); 0: never.
  * LEGKILO_GRIDSCAN sets the initial mode. */
 int lk_stream_grid(lk_handle* h, int mode);
+/* Where the last grid-resident launch of up to 32 workgroups ran: one bit per XCC id its working blocks reported (HW_REG_XCC_ID).  Such a
+ * launch starts 8 x G blocks of which every eighth works - blocks are observed (not promised) to go to XCD b % 8, so the working ones
+ * share one XCD and its L2, and their barriers then need no L2 write-back.  The kernel does not rely on it: the barriers drop the
+ * write-back only when this mask, collected on the device behind a full barrier, has exactly one bit.  LEGKILO_GRIDSCAN_XCD=0: G blocks, any XCD. */
+int lk_stream_grid_placement(lk_handle* h, uint32_t* xcc_mask);
 int lk_stream_stats(lk_handle* h, uint64_t* out4);
 void* lk_stream(lk_handle* h);                                         /* the handle's hipStream_t */
 

@@ -1015,30 +1015,43 @@ extern "C" {
 // (+ scalar-cache invalidate), the workgroup meets again.  Every wait is bounded: a timeout raises the abort word, every workgroup
 // leaves, the call fails with LK_ERR_TIMEOUT.  Off by default (lk_stream_grid / LEGKILO_GRIDSCAN=1): measured in DESIGN.md section 6.
 #define LK_GRIDSCAN_WG_MAX 128
+#define LK_CTR_GRID_XCC 15   // LkMap.counters[15]: XCC ids (one bit each) the working blocks of the last one-XCD launch ran on
 }  // extern "C" (a kernel template follows)
 template <bool XID>
 __global__ void __launch_bounds__(LK_FB)
     lk_scan_grid_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
-                        LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort */, unsigned int timeout_ms) {
+                        LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort, [2] XCC ids seen */, unsigned int timeout_ms,
+                        int stride) {
     __shared__ FilterSmem sm;
     __shared__ double red[8][LK_NPART];
     __shared__ double tot[LK_NPART];
     __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
-    __shared__ int s_abort;
-    const int G = (int)gridDim.x, wg = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_abort, s_one_xcd;
+    // stride 8: only the blocks b % 8 == 0 work, the others leave at once.  Blocks are OBSERVED to run on XCD b % 8 (no contract), so
+    // the working ones normally share one XCD and its L2; whether they really do is checked on the device (HW_REG_XCC_ID of every
+    // working block, below) and only then the barriers drop their L2 write-back
+    if ((int)blockIdx.x % stride) return;
+    const int G = (int)gridDim.x / stride, wg = (int)blockIdx.x / stride, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nbk = rag_nb(rg, 0);
     if (nbk == 0) return;
     const double* T = rag_t(rg, 0);
     const unsigned long long* po = rag_pt_off(rg, 0);
     const unsigned long long timeout_ticks = (unsigned long long)timeout_ms * 100000ull;
     unsigned int phase = 0;
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) {
+        s_abort = 0, s_one_xcd = 0;
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&sync[2], 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     auto grid_barrier = [&]() -> bool {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         phase += 1;
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // workgroups of ONE XCD share its L2: their drained stores (write-through from the CU) are what the others' L2 requests
+            // see, no write-back of the L2 is needed - the acquire below (invalidate of this CU's vector L1) always is
+            if (!s_one_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int need = (unsigned int)G * phase;
@@ -1063,6 +1076,11 @@ __global__ void __launch_bounds__(LK_FB)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __builtin_amdgcn_s_dcache_inv();
+            if (phase == 1u && stride > 1) {   // every working block has arrived, so has its XCC id
+                const unsigned int seen = __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_one_xcd = (seen & (seen - 1u)) == 0u;
+                if (wg == 0) map.counters[LK_CTR_GRID_XCC] = seen;
+            }
         }
         __syncthreads();
         return s_abort == 0;
@@ -2119,9 +2137,12 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     int G = wg_env > 0 ? wg_env : std::max(8, (tiles + 3) / 4 + 4);   // a wave per tile of the largest bucket and a few more for the per-root passes; every
                                                                       // further workgroup makes each barrier dearer (51 x 1 960 points: 12 workgroups 2.33 ms, 32: 2.43, 128: 2.81)
     G = std::min(G, LK_GRIDSCAN_WG_MAX);                             // 128 workgroups of 4 waves are resident on 256 CUs whatever else is true
+    // up to one workgroup per CU of an XCD: launch 8 G blocks and let only every eighth work (LEGKILO_GRIDSCAN_XCD=0: all G blocks, any XCD)
+    static const bool one_xcd_en = getenv("LEGKILO_GRIDSCAN_XCD") == nullptr || atoi(getenv("LEGKILO_GRIDSCAN_XCD")) != 0;
+    const int stride = (one_xcd_en && G <= 32) ? 8 : 1;
     const auto k = xid ? lk_scan_grid_kernel<true> : lk_scan_grid_kernel<false>;
-    LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                              h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms));
+    LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
+                                              h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride));
     return LK_OK;
 }
 // a scan is taken by the resident kernel when all its buckets are small (LEGKILO_RESIDENT=0: always per-bucket launches)
@@ -3130,7 +3151,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
         const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
         LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
-        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         if (k + 1 < live.size())
@@ -3325,6 +3346,13 @@ int lk_stream_stats(lk_handle* h, uint64_t* out4) {
     h->res_redo_total += (uint64_t)(redo[2] - h->res_redo_seen);
     h->res_redo_seen = redo[2];
     out4[0] = h->spec_buckets, out4[1] = h->spec_tiles, out4[2] = h->spec_redo_total, out4[3] = h->res_redo_total;
+    return LK_OK;
+}
+int lk_stream_grid_placement(lk_handle* h, uint32_t* xcc_mask) {
+    CHECK_H(h);
+    if (!xcc_mask) return fail(h, LK_ERR_INVALID, "xcc_mask is null");
+    HIPCHK(h, hipMemcpyAsync(xcc_mask, h->map.counters + LK_CTR_GRID_XCC, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return LK_OK;
 }
 void* lk_stream(lk_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -757,10 +757,15 @@ __device__ __forceinline__ void insert_defer(const LkMap& map, int leaf, int do_
 // that is always enough to reach the freeze of a leaf (npts <= max_points_num + 1 <= 64), after which the rest of the group is
 // ignored anyway; in the other cases the remainder goes to the per-point state machine (lk_insert_fallback_kernel), for which
 // store_idx(base) must first put the group's indices into map.gidx[base .. base + g) when `off` < 0 (they are not there yet).
+// cow_src (overlay replay only, lk_overlay_kernels.h): the leaf is a THIN private root - its record is private, its li.npts old points
+// still sit in the BASE map's block cow_src.  They are read from there and ALL node points (old + new) are stored to the private block;
+// the return value says whether that happened (false: the leaf did not take the register path, the caller copies the old points).
 template <typename PointAt, typename StoreIdx>
-__device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr, const int Tn, const int Tp, const int To, const int g,
-                                           const int root, const LeafInfo& li, int off, PointAt point_at, StoreIdx store_idx) {
+__device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr, const int Tn, const int Tp, const int To, const int g,
+                                           const int root, const LeafInfo& li, int off, PointAt point_at, StoreIdx store_idx,
+                                           const lk_pt_rec* cow_src = nullptr) {
     const int lane = threadIdx.x & 63;
+    bool cow_done = false;
 #ifdef LK_DEBUG_INS
     unsigned long long t0_ = wall_clock64();
     const unsigned long long ta_ = t0_;
@@ -804,14 +809,14 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
     const bool live = (r.state & LK_NODE_UPDATE_ENABLE) != 0;
     const bool maxnp = !uninit && !lplane && L >= pr.max_layer;
     INS_STAMP(0);
-    if (!uninit && !live && (lplane || maxnp)) return;  // frozen leaf ignores its points
+    if (!uninit && !live && (lplane || maxnp)) return false;  // frozen leaf ignores its points
     int consumed = 0;
     bool need_init = false;
     if ((uninit || ((lplane || maxnp) && live)) && !(r.state & LK_NODE_PTS_DROPPED) && r.npts < LK_WAVE) {
         const int n0 = r.npts;
         const int gs = min(g, LK_WAVE - n0);
         double ppw[3] = {0, 0, 0}, pvar[6] = {0, 0, 0, 0, 0, 0};
-        if (lane < n0) load_pt(map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
+        if (lane < n0) load_pt(cow_src ? cow_src : map.blocks[r.block].pts, nullptr, lane, ppw, pvar);
 #ifdef LK_DEBUG_INS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         INS_STAMP(8);
@@ -878,7 +883,8 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
         if (fitted && fit.is_plane) nev_ |= 8;
 #endif
         if (cur > n0 && r.block < 0) r.block = alloc_block(map);
-        if (lane >= n0 && lane < cur) {
+        cow_done = cow_src != nullptr;
+        if ((cow_src ? true : lane >= n0) && lane < cur) {
             lk_pt_rec* dst = &map.blocks[r.block].pts[lane];
 #pragma unroll
             for (int c = 0; c < 3; ++c) dst->pw[c] = ppw[c];
@@ -946,13 +952,14 @@ __device__ __forceinline__ void apply_leaf(const LkMap& map, const LkParams& pr,
             base = bcast0(base);
             if (base + g > (int)map.max_scan) {
                 if (lane == 0) atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
-                return;
+                return cow_done;
             }
             store_idx(base);
             off = base;
         }
         insert_defer(map, leaf, need_init ? 1 : 0, off + consumed, g - consumed, 2, root, L);
     }
+    return cow_done;
 }
 
 // Does a touched root only need its m queued points appended (no plane of its subtree can change in this bucket)?  An un-initialised
@@ -968,9 +975,15 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 // (Round 3, measured and not kept - profiles/r03i_insert_chain_experiments.txt: waves taking roots from a queue counter instead of
 // striding cost 0.60 against 0.44 ms per 5 x 20k scan - thousands of same-address atomics at launch; larger grids leave the kernel
 // at 40 us: its duration is its slowest single root, 8-12 us typically with a tail to 30 us in the memory phases, see the histograms.)
-template <bool FROM_PV>
+// OV (overlay replay, lk_overlay_kernels.h): `map` is a scan's private map and some touched roots are THIN - childless voxels whose
+// records the copy-on-write pass has made private while their old points still sit in the base map's block (pad_[LK_PAD_LIVE] == 2,
+// pad_[LK_PAD_COWBLK] = 1 + that block).  This pass reads those points where they are and stores old + new points to the private
+// block in one go (light roots and roots that are one in-place leaf group: nearly all); any other path copies them first.
+#define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 0 not in the slot's map yet, 1 complete, 2 thin
+#define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin private root: 1 + id of the BASE map's point block that holds its old points
+template <bool FROM_PV, bool OV = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                                                const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves) {
+                                                const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
     LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
@@ -994,6 +1007,29 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         const int rnpts = bcast0(nd->npts), rnewp = bcast0(nd->new_points), rblock = bcast0(nd->block), rlayer = bcast0(nd->layer);
         int cur_list = bcast0(nd->list_head);
         const int slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
+        const lk_pt_rec* cow_src = nullptr;
+        if (OV) {
+            const unsigned int live = (unsigned int)bcast0((int)nd->pad_[LK_PAD_LIVE]);
+            const int cow_blk = bcast0((int)nd->pad_[LK_PAD_COWBLK]) - 1;
+            if (live == 2u && cow_blk >= 0) cow_src = cow_base->blocks[cow_blk].pts;
+            if (live == 2u && lane == 0) nd->pad_[LK_PAD_LIVE] = 1;   // complete when this wave is done with it (nothing reads the word before the next bucket)
+        }
+        // thin root leaving the fused paths: its old points go to the private block first, then it is a root like any other
+        auto cow_finalise = [&]() {
+            if (OV && cow_src) {
+                if (lane < rnpts) {
+                    double qw[3], qv[6];
+                    load_pt(cow_src, nullptr, lane, qw, qv);
+                    lk_pt_rec* dst = &map.blocks[rblock].pts[lane];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dst->pw[c] = qw[c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) dst->var[c] = qv[c];
+                }
+                wave_fence();
+                cow_src = nullptr;
+            }
+        };
         if (lane == 0) nd->pad_[0] = 0, nd->list_head = -1;   // the root's bucket-local queue is consumed
         // ---- light root: append only (one lane per point, input order = ascending index)
         const bool light = !FROM_PV && root_is_light(pr, m, rst, rpf, rnpts, rnewp);
@@ -1004,6 +1040,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             for (int j = 0; j < 8; ++j) rank += (j < m && __builtin_amdgcn_readlane(idx, j) < idx) ? 1 : 0;
             int block = rblock;
             if (block < 0) block = alloc_block(map);
+            cow_finalise();   // (a thin root owns its private block already)
             if (lane < m) {
                 const float4 p = reinterpret_cast<const float4*>(pts)[idx];
                 const PointGeom gm = point_geom(p.x, p.y, p.z, bc, pr);
@@ -1036,6 +1073,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             wave_fence();
         }
         if (m > LK_WAVE) {  // very long list: handed over whole
+            cow_finalise();
             insert_defer(map, root, 0, base, m, 1, root, 0);
             ROOT_HIST(3, tr_);
             continue;
@@ -1101,6 +1139,10 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
 #ifndef LK_X_NOINLINE
 #define LK_X_NOINLINE 0   // debug / A-B only: 1 = every root hands its groups to lk_insert_apply_kernel
 #endif
+        if (OV && cow_src) {   // fused only when the root itself is the one leaf all its points go to
+            const int l0 = __ffsll((long long)__ballot(mine)) - 1;
+            if (ngroups != 1 || LK_X_NOINLINE || __builtin_amdgcn_readlane(tnode, l0 < 0 ? 0 : l0) != root) cow_finalise();
+        }
         ROOT_HIST(5, tr_);
 #ifndef LK_INLINE_GROUPS
 #define LK_INLINE_GROUPS 3   // roots with at most this many leaf groups are finished by their own wave, group after group (>= 1)
@@ -1139,7 +1181,11 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                 auto store_idx = [&](int gb) {
                     if (lane < g) map.gidx[gb + lane] = cidx;
                 };
-                apply_leaf(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx);
+                const bool cow_done = apply_leaf(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx, OV ? cow_src : nullptr);
+                if (OV && cow_src) {
+                    if (cow_done) cow_src = nullptr;
+                    else cow_finalise();
+                }
             }
             ROOT_HIST(ngroups == 1 ? 1 : 2, tr_);
             continue;

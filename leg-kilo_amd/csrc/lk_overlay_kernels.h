@@ -25,7 +25,9 @@
 #include "lk_point_kernels.h"
 
 #define LK_PAD_QCOUNT 0   // lk_node_rec::pad_[0]: points queued on a root in the current bucket (queue_point_on_root)
-#define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 1 once the root exists in the slot's map (0: its key may have been claimed in this bucket)
+// LK_PAD_LIVE (pad_[3]) / LK_PAD_COWBLK (pad_[5]) of a PRIVATE root record: lk_map_kernels.h (dev_insert_root<.., OV> reads them).  LIVE: 0 the key may
+// have been claimed in this bucket but the root does not exist in the slot's map yet; 1 it exists; 2 "thin": it exists, only its old points are still
+// the base map's (block COWBLK - 1) - a state that lasts from the copy-on-write pass to the root pass of the same bucket.
 #define LK_PAD_BASE 4     // lk_node_rec::pad_[4] of a private root record that does not exist yet: 1 + id of the base map's voxel of that key (0: none)
 #define LK_OV_EMPTY 0x8000000000000000ull   // empty entry of a slot's key table (a packed key never has bit 63 set)
 
@@ -339,8 +341,15 @@ __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base,
             if (child[c] >= 0) ov_copy_node<L + 1>(pm, base, child[c], nchild[c]);
     }
 }
-// One wave per touched root that does not exist in the slot's map yet: the base voxel of its key is copied (copy-on-write), or - the
-// base map has none - an empty root voxel is created (voxel_map.cc:345-357).  Then the key's bit is set for the residual pass.
+// Copy-on-write of the touched roots that do not exist in the slot's map yet.  A wave takes 64 of them, ONE LANE EACH:
+//   * no voxel of that key in the base map: an empty root voxel is created (voxel_map.cc:345-357);
+//   * a CHILDLESS base voxel (a leaf: nearly all of them): the lane copies the node record, all lanes together copy the plane and match
+//     records of the chunk's voxels as one flat list of 16-B pieces (25 per voxel, independent loads), and the voxel's points are NOT
+//     copied here: the root becomes "thin" (LK_PAD_LIVE = 2) and the root pass of this bucket, which has to read those points anyway,
+//     reads them from the base block and writes old + new points to the private block (dev_insert_root<.., OV>).  Copying every leaf's
+//     points in this pass (one voxel after the other, two dependent round trips each) took 7.1 ms of a 33 ms batch;
+//   * a base voxel WITH children (a cut voxel): its octree is copied node by node (ov_copy_node), all lanes on one voxel.
+// Point blocks are allocated with ONE bump of the block counter per chunk.  Then the key's bit is set for the residual pass.
 __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
@@ -351,8 +360,6 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
     const int wave = (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * LK_MB) >> 6);
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     for (int t0 = wave * LK_WAVE; t0 < n_touched; t0 += nwaves * LK_WAVE) {
-        // a wave takes 64 consecutive touched roots: their ids, flags and keys are fetched by one lane each (three round trips for all
-        // 64 instead of three per root), then the roots that need it are materialised one after the other
         const int tt = t0 + lane;
         int my_root = -1, my_base = 0;
         bool need = false;
@@ -364,10 +371,20 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             my_base = (int)nd->pad_[LK_PAD_BASE];
             my_key = keys[my_root];
         }
-        // every lane looks at the base voxel of ITS root: does it own a point block?  One bump of the block counter then serves the
-        // whole chunk (a returning device-scope atomic is a ~2 us round trip; one per root made this pass 3 x slower)
-        int s_block = -1;
-        if (need && my_base > 0) s_block = base.nodes[my_base - 1].block;
+        // the base voxel's node record, whole (six 16-B pieces per lane, one round trip for the chunk)
+        const bool has_base = need && my_base > 0;
+        int4 rec[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) rec[c] = make_int4(-1, -1, -1, -1);
+        if (has_base) {
+            const int4* bp = reinterpret_cast<const int4*>(&base.nodes[my_base - 1]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rec[c] = bp[c];
+        }
+        const int s_block = has_base ? rec[4].w : -1, s_npts = has_base ? rec[4].x : 0;   // bytes 64..79: npts, new_points, state, block
+        const bool childless = rec[0].x < 0 && rec[0].y < 0 && rec[0].z < 0 && rec[0].w < 0 && rec[1].x < 0 && rec[1].y < 0 && rec[1].z < 0 && rec[1].w < 0;
+        const bool thin = has_base && childless;
+        // one bump of the block counter serves the whole chunk (a returning device-scope atomic is a ~2 us round trip)
         const unsigned long long blk_mask = __ballot(need && s_block >= 0);
         int blk_base = 0;
         if (blk_mask) {
@@ -398,8 +415,49 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             pm.planes[my_root].flags = 0;
             pm.match[my_root].flags = 0;
         }
-        // copy-on-write of the others, one after the other, all lanes on one voxel
-        unsigned long long todo = __ballot(need && my_base > 0);
+        // childless base voxels: the node record by the root's own lane (the queue fields list_head / pad_[] are the re-projection pass's) ...
+        const bool pending = thin && s_block >= 0 && s_npts > 0;
+        if (thin) {
+            int4* drec = reinterpret_cast<int4*>(&pm.nodes[my_root]);
+            drec[0] = rec[0], drec[1] = rec[1], drec[2] = rec[2], drec[3] = rec[3];
+            drec[4] = make_int4(rec[4].x, rec[4].y, rec[4].z, my_block);
+            pm.nodes[my_root].key[0] = rec[5].x, pm.nodes[my_root].key[1] = rec[5].y, pm.nodes[my_root].key[2] = rec[5].z;
+            pm.nodes[my_root].pad_[LK_PAD_COWBLK] = pending ? (unsigned int)(s_block + 1) : 0u;
+        }
+        // ... and their plane (16 pieces) + match (9 pieces) records as one flat list over the chunk's thin voxels, five loads in flight per lane
+        {
+            const unsigned long long thin_mask = __ballot(thin);
+            const int n_thin = __popcll(thin_mask);
+            const int pos = thin ? __popcll(thin_mask & ((1ull << lane) - 1ull)) : 63;   // n_thin == 64: every lane is a member
+            const int c_src = __builtin_amdgcn_ds_permute(pos << 2, my_base - 1), c_dst = __builtin_amdgcn_ds_permute(pos << 2, my_root);
+            constexpr int PIECES = 25, U = 5;
+            const int total = n_thin * PIECES;
+            for (int j0 = 0; j0 < total; j0 += 64 * U) {
+                uint4 v[U];
+                int dsts[U], cs[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = j0 + 64 * u + lane;
+                    const int r = idx / PIECES;
+                    cs[u] = idx - r * PIECES;
+                    const int src = __shfl(c_src, r & 63, LK_WAVE);
+                    dsts[u] = __shfl(c_dst, r & 63, LK_WAVE);
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (idx < total)
+                        v[u] = cs[u] < 16 ? reinterpret_cast<const uint4*>(&base.planes[src])[cs[u]] : reinterpret_cast<const uint4*>(&base.match[src])[cs[u] - 16];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = j0 + 64 * u + lane;
+                    if (idx < total) {
+                        if (cs[u] < 16) reinterpret_cast<uint4*>(&pm.planes[dsts[u]])[cs[u]] = v[u];
+                        else reinterpret_cast<uint4*>(&pm.match[dsts[u]])[cs[u] - 16] = v[u];
+                    }
+                }
+            }
+        }
+        // cut voxels: the whole octree, one voxel after the other, all lanes on one voxel
+        unsigned long long todo = __ballot(has_base && !thin);
         while (todo) {
             const int src_lane = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -407,7 +465,7 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
                             __builtin_amdgcn_readlane(my_block, src_lane));
         }
         if (need) {
-            pm.nodes[my_root].pad_[LK_PAD_LIVE] = 1;
+            pm.nodes[my_root].pad_[LK_PAD_LIVE] = pending ? 2u : 1u;
             unsigned int cell;
             if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
         }
@@ -421,11 +479,11 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 // ~10^6 roots, each a chain of dependent round trips - concurrency, not the single wave's speed, sets its duration
 template <int W>
 __global__ void __launch_bounds__(LK_MB, W)
-    lk_ov_insert_root_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
+    lk_ov_insert_root_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    dev_insert_root<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
-                           (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+    dev_insert_root<false, true>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
+                                 (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base);
 }
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {

@@ -65,6 +65,6 @@ for rep in range(args.reps):
             tl.append(time.perf_counter() - tc)
             o += sc.nbytes
         g.device_free(d)
-    print(f"kind {args.kind} spec {args.spec} rep {rep}: ms/scan median {1e3 * float(np.median(tl[1:])):.3f} min {1e3 * min(tl[1:]):.3f} "
+    print(f"kind {args.kind} spec {args.spec} xcc_mask {g.stream_grid_placement():#x} rep {rep}: ms/scan median {1e3 * float(np.median(tl[1:])):.3f} min {1e3 * min(tl[1:]):.3f} "
           f"buckets/scan {len(synth.buckets_of(scans[-1])[0]) - 1} points {len(scans[-1])} stats {g.stream_stats()}")
 g.close()
