@@ -535,7 +535,7 @@ def main():
             g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)
             g.profile_enable(0)
             extra["overlay_kernel_ms_per_batch"] = {k: round(g.profile_get(k)[1], 3) for k in
-                                                    ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root",
+                                                    ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_fit_lane",
                                                      "ov_insert_apply", "ov_insert_fallback")}
             ov = ov_p
         except Exception as e:  # noqa: BLE001

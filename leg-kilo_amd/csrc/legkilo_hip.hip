@@ -3019,7 +3019,7 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
 static void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
     void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits};
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs};
     for (void* q : ptrs)
         if (q) hipFree(q);
     memset(&o, 0, sizeof(o));
@@ -3067,6 +3067,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
     if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -3133,8 +3134,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
     LkFilter* fl = h->d_filters;
     double* parts = h->d_partials;
-    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 2;
+    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // without the fit: 184 VGPRs at 2 waves, 168 at 3
     const auto root_kernel = root_waves >= 4 ? lk_ov_insert_root_kernel<4> : root_waves == 3 ? lk_ov_insert_root_kernel<3> : lk_ov_insert_root_kernel<2>;
+    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
     for (size_t k = 0; k < live.size(); ++k) {
         const size_t b = live[k];
@@ -3151,7 +3153,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
         const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
         LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+        // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
         LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, S), dim3(LK_WAVE), 0, st, ov, h->pr));
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         if (k + 1 < live.size())

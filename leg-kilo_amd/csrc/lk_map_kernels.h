@@ -20,6 +20,10 @@
 
 #define LK_MB 256  // threads per block in the per-root kernels (4 waves = 4 roots in flight)
 #ifndef LK_X_CHILD_CONST
+#ifndef LK_X_ATTR
+#define LK_X_ATTR 0   // attribution builds only (results WRONG by construction): 1 no plane_var, 2 no eigen-decomposition in the full fit, 4 no
+                      // point_geom for the new points, 8 no refit-event tests, 16 no index sort - tools/gpu_ov_attr.sh times the overlay root pass on each
+#endif
 #define LK_X_CHILD_CONST 1   // apply_leaf: a child it has just created is known without reading it back (0: node_load, A/B)
 #endif
 
@@ -406,8 +410,9 @@ __device__ __forceinline__ void plane_var_regs(const PlaneFit& f, const double* 
 }
 // lane 0 writes the plane and its compact match copy, both from registers (the match record is derived from the values, not read
 // back from the plane record just stored).  No fence: nothing in the apply pass reads a plane it has committed.
+template <bool ALL_LANES = false>   // ALL_LANES: every lane commits ITS OWN plane (lk_ov_insert_lane_kernel: one root voxel per lane)
 __device__ __forceinline__ void plane_commit(lk_plane_rec* pl, lk_match_rec* mr, const PlaneFit& f, const double* acc, int count) {
-    if ((threadIdx.x & 63) == 0) {
+    if (ALL_LANES || (threadIdx.x & 63) == 0) {
         pl->points_size = count;
         if (f.is_plane) {
             lk_plane_rec t;   // in registers
@@ -709,6 +714,15 @@ struct LkGroup {       // 64 B
     int is_plane, pad2[2];
 };
 static_assert(sizeof(LkGroup) == 64, "group descriptor must be 64 B");
+#ifndef LK_INLINE_GROUPS
+#define LK_INLINE_GROUPS 3   // roots with at most this many leaf groups are finished by their own wave, group after group (>= 1)
+#endif
+struct LkFitJob {   // 96 B: a plane fit the overlay replay's root pass leaves to lk_ov_fit_lane_kernel (apply_leaf<DEFER>)
+    int leaf, block, cnt, decided;   // cnt = points of the leaf's last refit event (0: no fit), block = where they are, decided = is_plane of that event
+    double s9[9];                    // its moment sums (sum p, sum p p^T)
+    double pad_;
+};
+static_assert(sizeof(LkFitJob) == 96, "fit job must be 96 B");
 struct LeafInfo {
     int npts, new_points, block, layer;
     unsigned int state;
@@ -760,10 +774,12 @@ __device__ __forceinline__ void insert_defer(const LkMap& map, int leaf, int do_
 // cow_src (overlay replay only, lk_overlay_kernels.h): the leaf is a THIN private root - its record is private, its li.npts old points
 // still sit in the BASE map's block cow_src.  They are read from there and ALL node points (old + new) are stored to the private block;
 // the return value says whether that happened (false: the leaf did not take the register path, the caller copies the old points).
-template <typename PointAt, typename StoreIdx>
+// DEFER (overlay replay): the leaf's one full plane fit is not made here - lane 0 writes a job (leaf, block, the last event's count,
+// decision and moment sums) and lk_ov_fit_lane_kernel, one lane per job, does the eigen-decomposition, plane_var and the commit.
+template <bool DEFER = false, typename PointAt, typename StoreIdx>
 __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr, const int Tn, const int Tp, const int To, const int g,
                                            const int root, const LeafInfo& li, int off, PointAt point_at, StoreIdx store_idx,
-                                           const lk_pt_rec* cow_src = nullptr) {
+                                           const lk_pt_rec* cow_src = nullptr, LkFitJob* job = nullptr) {
     const int lane = threadIdx.x & 63;
     bool cow_done = false;
 #ifdef LK_DEBUG_INS
@@ -851,7 +867,13 @@ __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr,
             const int k = max(min(rem, lim), 1);
             cur += k, newp += k, consumed += k;
             if (m0 == 0 ? cur > thr : newp > 5) {
+#if LK_X_ATTR & 8
+                fit.is_plane = true;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) fit.s9[q] = ppw[q % 3] + (double)cur;
+#else
                 fit = plane_test_regs<true>(ppw, lane < cur, cur, pr.planer_threshold);
+#endif
                 fit_count = cur, fitted = true, newp = 0;
                 if (m0 == 0) {
                     if (fit.is_plane) {
@@ -899,21 +921,40 @@ __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr,
         } else {
             r.new_points = newp;
             if (fitted) {
+                if (DEFER) {
+                    if (lane == 0) {
+                        job->leaf = leaf, job->block = r.block, job->decided = fit.is_plane ? 1 : 0;
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) job->s9[q] = fit.s9[q];
+                        job->cnt = fit_count;
+                    }
+                } else {
                 // the one full fit of this leaf in this bucket: the state of its LAST refit event
                 const bool decided = fit.is_plane;
                 const PlaneFit last = fit;   // the last event tested exactly these fit_count points: its sums are reused
                 INS_STAMP(3);
+#if LK_X_ATTR & 2
+                fit = plane_test_regs<true, true>(ppw, lane < fit_count, fit_count, pr.planer_threshold, &last);
+                fit.vmin[2] = fit.vmid[1] = fit.vmax[0] = 1.0, fit.emin = 1e-3, fit.emid = 1.0, fit.emax = 2.0;
+#else
                 fit = plane_test_regs<false, true>(ppw, lane < fit_count, fit_count, pr.planer_threshold, &last);
+#endif
                 INS_STAMP(4);
                 fit.is_plane = decided;  // control flow above already followed the event's decision
                 double acc21[21];
+#if LK_X_ATTR & 1
+#pragma unroll
+                for (int q = 0; q < 21; ++q) acc21[q] = 1e-6;
+#else
                 if (fit.is_plane) plane_var_regs(fit, ppw, pvar, lane < fit_count, fit_count, acc21);
+#endif
                 INS_STAMP(5);
                 plane_commit(&map.planes[leaf], &map.match[leaf], fit, acc21, fit_count);
                 INS_STAMP(6);
 #ifdef LK_DEBUG_INS
                 if (lane == 0) atomicAdd(&lk_ins_dbg[14], 1ull);
 #endif
+                }
                 r.state = (r.state | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
                 if (flipped_to_tree) node_drop_block(map, r);  // its own points are never read again
             }
@@ -983,7 +1024,8 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 #define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin private root: 1 + id of the BASE map's point block that holds its old points
 template <bool FROM_PV, bool OV = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
-                                                const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr) {
+                                                const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr,
+                                                LkFitJob* jobs = nullptr, const size_t job_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
     LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
@@ -1008,6 +1050,10 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         int cur_list = bcast0(nd->list_head);
         const int slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
         const lk_pt_rec* cow_src = nullptr;
+        // this root's fit jobs (apply_leaf<DEFER>): none yet.  Entry [g][t] = its g-th inline leaf group: nearly every root is ONE group, so
+        // plane 0 is dense for lk_ov_fit_lane_kernel's lanes (job_stride = entries per plane)
+        if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + t].cnt = 0;
+        int job_i = 0;
         if (OV) {
             const unsigned int live = (unsigned int)bcast0((int)nd->pad_[LK_PAD_LIVE]);
             const int cow_blk = bcast0((int)nd->pad_[LK_PAD_COWBLK]) - 1;
@@ -1081,7 +1127,11 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         // sort the root's indices in registers: rank = number of smaller indices, then a forward permute
         const int myidx = (lane < m) ? (in_slots ? slot_idx : map.scratch[base + lane]) : 0x7fffffff;
         int rank = 0;
+#if LK_X_ATTR & 16
+        rank = lane;
+#else
         for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
+#endif
         const int sidx = __builtin_amdgcn_ds_permute(((lane < m) ? rank : lane) << 2, myidx);  // lane j: j-th smallest
         const bool mine = lane < m;
         // every lane walks (read-only) to the node its point would be pushed into: down through initialised non-planar nodes
@@ -1144,9 +1194,6 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             if (ngroups != 1 || LK_X_NOINLINE || __builtin_amdgcn_readlane(tnode, l0 < 0 ? 0 : l0) != root) cow_finalise();
         }
         ROOT_HIST(5, tr_);
-#ifndef LK_INLINE_GROUPS
-#define LK_INLINE_GROUPS 3   // roots with at most this many leaf groups are finished by their own wave, group after group (>= 1)
-#endif
         if (ngroups <= LK_INLINE_GROUPS && !LK_X_NOINLINE) {
             // ---- one leaf group (98 % of the roots) or a few: applied here, from registers, one after the other.  A group's points are
             // compacted to lanes 0 .. g-1 in lane (= input) order - the identity when the root is one group.  The launch for the emitted
@@ -1175,13 +1222,22 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                         if (valid) load_pt(pv, nullptr, idx, pt.pw, pt.var);
                     } else {
                         const float qx = __shfl(cx, rr, LK_WAVE), qy = __shfl(cy, rr, LK_WAVE), qz = __shfl(cz, rr, LK_WAVE);
+#if LK_X_ATTR & 4
+                        if (valid) {
+                            pt.pw[0] = qx, pt.pw[1] = qy, pt.pw[2] = qz;
+                            pt.var[0] = pt.var[3] = pt.var[5] = 1e-4, pt.var[1] = pt.var[2] = pt.var[4] = 0.0;
+                        }
+#else
                         if (valid) geom_to_pt(point_geom(qx, qy, qz, bc, pr), pt);
+#endif
                     }
                 };
                 auto store_idx = [&](int gb) {
                     if (lane < g) map.gidx[gb + lane] = cidx;
                 };
-                const bool cow_done = apply_leaf(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx, OV ? cow_src : nullptr);
+                const bool cow_done = apply_leaf<OV>(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx, OV ? cow_src : nullptr,
+                                                     OV ? &jobs[(size_t)job_i * job_stride + t] : nullptr);
+                ++job_i;
                 if (OV && cow_src) {
                     if (cow_done) cow_src = nullptr;
                     else cow_finalise();

@@ -56,6 +56,7 @@ struct LkOverlay {
     unsigned int* newroot;       // one shared dummy table (epoch 0: only ever written with 0)
     unsigned int* spec;          // one shared dummy
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
+    struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
     unsigned int hash_cap, nodes_cap, blocks_cap, scan_cap, bit_words;
 };
 
@@ -474,6 +475,104 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
     }
 }
 
+// ---------------------------------------------------------------- the plane fits of the root pass, ONE LANE PER FIT
+// The wave-per-root pass (dev_insert_root<.., OV>, lk_map_kernels.h) spreads a leaf's points over the lanes - right for the per-point work
+// and for coalesced access - but the fit that ends a leaf's bucket is serial work every lane repeats for ONE leaf: the eigen-decomposition
+// of its scatter matrix (23 % of the pass's time by switching pieces off), the 21 wave-reduced sums of plane_var (12 %), the commit.  In a
+// batch replay a launch holds ~10^6 such fits, so the root pass only DECIDES (apply_leaf<DEFER>: the refit events' is_plane tests, which is
+// all its control flow needs) and leaves a 96-B job per fit - the leaf, its block, the event's point count, decision and moment sums.  Here
+// a LANE takes a job: init_plane (voxel_map.cc:42-117) from the sums - plane_test_regs' / plane_var_regs' / plane_commit's expressions,
+// the points read back from the leaf's block (a block retired by a freeze is not handed out again before the next bucket).
+// (Measured and not kept: the whole root pass one lane per root - queue, sums, state machine - is bound by memory TRANSACTIONS, every
+// lane's 8-B access its own: 9.4 + 2.2 ms against 10.8 ms for the wave-per-root pass, 512 scans; profiles/EXPERIMENTS.md.)
+#ifndef LK_FIT_WAVES
+#define LK_FIT_WAVES 2
+#endif
+// (Sorting a workgroup's jobs by point count, so that a wave's lanes run similar loop lengths, changes nothing: 4.04 vs 3.99 ms per 1024
+// scans - the pass moves 1.7 KB per fit in 16-B pieces, 2 TB/s.)
+__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(LkOverlay ov, LkParams pr) {
+    const unsigned int slot = blockIdx.y;
+    const LkMap pm = ov_slot_map(ov, slot);
+    if (pm.counters[LK_CTR_ERR]) return;
+    const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
+    const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;   // entry [g][t]: inline leaf group g of touched root t
+    for (int i = blockIdx.x * LK_WAVE + threadIdx.x; i < n_touched * LK_INLINE_GROUPS; i += gridDim.x * LK_WAVE) {
+        const int g = i / n_touched, t = i - g * n_touched;
+        const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
+        const int4 hd = *reinterpret_cast<const int4*>(job);
+        const int root = hd.x /* the leaf's node id */, block = hd.y, cnt = hd.z;
+        if (cnt <= 0) continue;
+        PlaneFit ev;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ev.s9[q] = job->s9[q];
+        PlaneFit fit = plane_test_regs<false, true>(nullptr, false, cnt, pr.planer_threshold, &ev);
+        fit.is_plane = hd.w != 0;   // the lane pass already followed the event's decision
+        double acc21[21];
+#pragma unroll
+        for (int q = 0; q < 21; ++q) acc21[q] = 0.0;
+        if (fit.is_plane) {
+            double rhsA[9], rhsB[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    rhsA[3 * r + cc] = fit.vmid[r] * fit.vmin[cc] + fit.vmin[r] * fit.vmid[cc];
+                    rhsB[3 * r + cc] = fit.vmax[r] * fit.vmin[cc] + fit.vmin[r] * fit.vmax[cc];
+                }
+            const double denA = cnt * (fit.emin - fit.emid), denB = cnt * (fit.emin - fit.emax);
+            const double invn = 1.0 / cnt;
+            const lk_pt_rec* __restrict__ bp = pm.blocks[block].pts;
+            double nw[3], nv[6];   // the next point is requested while this one is worked on
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nw[c] = bp[0].pw[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) nv[c] = bp[0].var[c];
+            for (int j = 0; j < cnt; ++j) {
+                double pw[3], var[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pw[c] = nw[c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) var[c] = nv[c];
+                if (j + 1 < cnt) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) nw[c] = bp[j + 1].pw[c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) nv[c] = bp[j + 1].var[c];
+                }
+                double q[3] = {pw[0] - fit.c[0], pw[1] - fit.c[1], pw[2] - fit.c[2]};
+                double la[3] = {q[0] / denA, q[1] / denA, q[2] / denA};
+                double lb[3] = {q[0] / denB, q[1] / denB, q[2] / denB};
+                double FA[3], FB[3];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    FA[cc] = la[0] * rhsA[cc] + la[1] * rhsA[3 + cc] + la[2] * rhsA[6 + cc];
+                    FB[cc] = lb[0] * rhsB[cc] + lb[1] * rhsB[3 + cc] + lb[2] * rhsB[6 + cc];
+                }
+                double J[6][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        J[r][cc] = fit.vmid[r] * FA[cc] + fit.vmax[r] * FB[cc];
+                        J[3 + r][cc] = (r == cc) ? invn : 0.0;
+                    }
+                double Sv[3][3] = {{var[0], var[1], var[2]}, {var[1], var[3], var[4]}, {var[2], var[4], var[5]}};
+                double JV[6][3];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) JV[r][cc] = J[r][0] * Sv[0][cc] + J[r][1] * Sv[1][cc] + J[r][2] * Sv[2][cc];
+                int kk = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int cc = r; cc < 6; ++cc) acc21[kk++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
+            }
+        }
+        plane_commit<true>(&pm.planes[root], &pm.match[root], fit, acc21, cnt);
+    }
+}
+
 // ---------------------------------------------------------------- the ordered insert, slot = blockIdx.y
 // W = waves per SIMD the register allocation aims at (2: the stream path's 216 VGPRs; 3: <= 168): this launch is a throughput pass over
 // ~10^6 roots, each a chain of dependent round trips - concurrency, not the single wave's speed, sets its duration
@@ -483,7 +582,8 @@ __global__ void __launch_bounds__(LK_MB, W)
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
     dev_insert_root<false, true>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
-                                 (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base);
+                                 (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base,
+                                 ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
 }
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
