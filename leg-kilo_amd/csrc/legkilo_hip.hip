@@ -3136,6 +3136,8 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     double* parts = h->d_partials;
     static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // without the fit: 184 VGPRs at 2 waves, 168 at 3
     const auto root_kernel = root_waves >= 4 ? lk_ov_insert_root_kernel<4> : root_waves == 3 ? lk_ov_insert_root_kernel<3> : lk_ov_insert_root_kernel<2>;
+    static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
+    static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
     static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
     for (size_t k = 0; k < live.size(); ++k) {
@@ -3152,9 +3154,12 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
         const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
-        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+        // (measured at 1024 slots x 20 000-point buckets, workgroups per slot: copy-on-write 2.8 / 6.6 / 12.2 ms per batch at 4 / 16 / 32 - a wave takes 64
+        // roots, more waves only find nothing to do; root pass 12.8 / 11.0 / 11.7 - a wave works through its roots one after the other)
+        const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
+        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, S), dim3(LK_WAVE), 0, st, ov, h->pr));
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));

@@ -1035,28 +1035,65 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
     const unsigned long long tw_ = wall_clock64();
     bool any_ = false;
 #endif
+    // OV: a wave of the batch replay works through ~100 roots one after the other, each a chain of dependent round trips (its id from the
+    // touched list; its record, plane flags and slot line; its scan points; its leaf's points).  The first two are requested ahead: the id
+    // TWO roots ahead, the record ONE root ahead (lane k holds 16-B piece k of the 128-B record, fields are picked with readlane) - they
+    // land while the current root is worked on.  Roots of one touched list are distinct, so nothing requested ahead is changed meanwhile.
+    int pf_root1 = -1, pf_root2 = -1, pf_flags = 0, pf_slot = 0x7fffffff;
+    int4 pf_rec = make_int4(0, 0, 0, 0);
+    auto prefetch_record = [&](int r) {
+        if (r >= 0) {
+            if (lane < 8) pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane];
+            pf_flags = (int)map.planes[r].flags;
+            pf_slot = (lane < LK_SLOTS) ? map.slots[(size_t)r * LK_SLOTS + lane] : 0x7fffffff;
+        }
+    };
+    if (OV) {
+        pf_root1 = wave < n_touched ? bcast0(map.touched[wave]) : -1;
+        pf_root2 = wave + nwaves < n_touched ? bcast0(map.touched[wave + nwaves]) : -1;
+        prefetch_record(pf_root1);
+    }
     for (int t = wave; t < n_touched; t += nwaves) {
 #ifdef LK_DEBUG_INS
         const unsigned long long tr_ = wall_clock64();
         if (any_) ROOT_HIST(4, tw_);   // a wave with a second root: its time so far
         any_ = true;
 #endif
-        const int root = bcast0(map.touched[t]);
+        int root, m, rnpts, rnewp, rblock, rlayer, cur_list, slot_idx, ov_live = 0, ov_cowblk = 0;
+        unsigned int rst, rpf;
+        if (OV) {
+            root = pf_root1;
+            rlayer = __builtin_amdgcn_readlane(pf_rec.w, 3);
+            rnpts = __builtin_amdgcn_readlane(pf_rec.x, 4), rnewp = __builtin_amdgcn_readlane(pf_rec.y, 4);
+            rst = (unsigned int)__builtin_amdgcn_readlane(pf_rec.z, 4), rblock = __builtin_amdgcn_readlane(pf_rec.w, 4);
+            cur_list = __builtin_amdgcn_readlane(pf_rec.w, 5);
+            m = __builtin_amdgcn_readlane(pf_rec.x, 6), ov_live = __builtin_amdgcn_readlane(pf_rec.w, 6);   // pad_[0], pad_[LK_PAD_LIVE]
+            ov_cowblk = __builtin_amdgcn_readlane(pf_rec.y, 7);                                              // pad_[LK_PAD_COWBLK]
+            rpf = (unsigned int)bcast0(pf_flags);
+            slot_idx = pf_slot;
+            pf_root1 = pf_root2;
+            prefetch_record(pf_root1);
+            pf_root2 = t + 2 * nwaves < n_touched ? bcast0(map.touched[t + 2 * nwaves]) : -1;
+        } else {
+            root = bcast0(map.touched[t]);
+        }
         lk_node_rec* nd = &map.nodes[root];
-        // one batch of loads: the root's record, its plane flags, its slot line
-        const int m = bcast0((int)nd->pad_[0]);
-        const unsigned int rst = (unsigned int)bcast0((int)nd->state), rpf = (unsigned int)bcast0((int)map.planes[root].flags);
-        const int rnpts = bcast0(nd->npts), rnewp = bcast0(nd->new_points), rblock = bcast0(nd->block), rlayer = bcast0(nd->layer);
-        int cur_list = bcast0(nd->list_head);
-        const int slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
+        if (!OV) {
+            // one batch of loads: the root's record, its plane flags, its slot line
+            m = bcast0((int)nd->pad_[0]);
+            rst = (unsigned int)bcast0((int)nd->state), rpf = (unsigned int)bcast0((int)map.planes[root].flags);
+            rnpts = bcast0(nd->npts), rnewp = bcast0(nd->new_points), rblock = bcast0(nd->block), rlayer = bcast0(nd->layer);
+            cur_list = bcast0(nd->list_head);
+            slot_idx = (lane < LK_SLOTS) ? map.slots[(size_t)root * LK_SLOTS + lane] : 0x7fffffff;
+        }
         const lk_pt_rec* cow_src = nullptr;
         // this root's fit jobs (apply_leaf<DEFER>): none yet.  Entry [g][t] = its g-th inline leaf group: nearly every root is ONE group, so
         // plane 0 is dense for lk_ov_fit_lane_kernel's lanes (job_stride = entries per plane)
         if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + t].cnt = 0;
         int job_i = 0;
         if (OV) {
-            const unsigned int live = (unsigned int)bcast0((int)nd->pad_[LK_PAD_LIVE]);
-            const int cow_blk = bcast0((int)nd->pad_[LK_PAD_COWBLK]) - 1;
+            const unsigned int live = (unsigned int)ov_live;
+            const int cow_blk = ov_cowblk - 1;
             if (live == 2u && cow_blk >= 0) cow_src = cow_base->blocks[cow_blk].pts;
             if (live == 2u && lane == 0) nd->pad_[LK_PAD_LIVE] = 1;   // complete when this wave is done with it (nothing reads the word before the next bucket)
         }
