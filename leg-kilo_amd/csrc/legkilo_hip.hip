@@ -3019,7 +3019,7 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
 static void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
     void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs};
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen};
     for (void* q : ptrs)
         if (q) hipFree(q);
     memset(&o, 0, sizeof(o));
@@ -3067,6 +3067,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.frozen, (size_t)n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
     if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
     if (e != hipSuccess) {
@@ -3130,6 +3131,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
         LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
     }
+    HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
+    static const bool frozen_bits = getenv("LEGKILO_OV_FROZEN_BITS") == nullptr || atoi(getenv("LEGKILO_OV_FROZEN_BITS")) != 0;   // 0: every point through the probes and the walk (A/B)
+    if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
     LkFilter* fl = h->d_filters;

@@ -56,6 +56,7 @@ struct LkOverlay {
     unsigned int* newroot;       // one shared dummy table (epoch 0: only ever written with 0)
     unsigned int* spec;          // one shared dummy
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
+    unsigned int* frozen;        // [bit_words], shared by all slots: bit c = the BASE map's voxel at grid cell c is a frozen leaf (lk_ov_frozen_bits_kernel)
     struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
     unsigned int hash_cap, nodes_cap, blocks_cap, scan_cap, bit_words;
 };
@@ -220,6 +221,23 @@ __device__ __forceinline__ bool ov_cell_of(const LkMap& base, const int* key, un
     return true;
 }
 
+// Which voxels of the base map are frozen leaves (a plane, or a non-planar leaf at max_layer, with update_enable_ == false,
+// voxel_map.cc:199,232): UpdateOctoTree ignores every point that lands in one, for good - so no scan ever gets a private copy of such
+// a voxel, and the re-projection pass can drop those points (half of a scan on the bench's mature map) after ONE bit test instead of
+// the private-table probe, the base table probe and the walk.  One thread per entry of the base map's root table, once per replay.
+__global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsigned int n_hash, int max_layer, unsigned int* __restrict__ frozen) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hash) return;
+    const int4 e = base.hash[i];
+    if (e.w < 0) return;
+    const unsigned int st = base.nodes[e.w].state, pf = base.planes[e.w].flags;
+    if (!(st & LK_NODE_INIT_OCTO) || (st & LK_NODE_UPDATE_ENABLE)) return;
+    if (!((pf & LK_PLANE_IS_PLANE) != 0 || base.nodes[e.w].layer >= max_layer)) return;   // the leaf test of ov_walk_ignored at the root
+    const int key[3] = {e.x, e.y, e.z};
+    unsigned int cell;
+    if (ov_cell_of(base, key, &cell)) atomicOr(&frozen[cell >> 5], 1u << (cell & 31u));
+}
+
 // KILO.cc:216-230 + the hashing half of UpdateVoxelMap (voxel_map.cc:343-358) for bucket point i of slot blockIdx.y, on the
 // slot's overlay.  A private root that exists (created by an earlier bucket: LK_PAD_LIVE) is walked itself; otherwise the base
 // voxel of the key, if any, is still the truth - the insert's first phase is read-only on every tree.  A point that is not ignored
@@ -243,6 +261,10 @@ __global__ void __launch_bounds__(LK_WAVE)
     if (!ov_pack_key(key[0], key[1], key[2], &pk)) {
         atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
         return;
+    }
+    {   // the base voxel of this key is a frozen leaf: the point is ignored, and no private voxel of that key can exist
+        unsigned int cell;
+        if (ov_cell_of(base, key, &cell) && ((ov.frozen[cell >> 5] >> (cell & 31u)) & 1u)) return;
     }
     const unsigned int hk = ov_slot_hash(key[0], key[1], key[2]);
     int root = ov_key_find(keys, pm.hash_mask, pk, hk);
