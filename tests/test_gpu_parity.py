@@ -684,6 +684,10 @@ def test_scan_grid_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_lib,
         assert np.array_equal(wg, ws), k
     scenes.maps_identical(g.map_export(), g_seq.map_export())
     assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
+    if nb == 51:   # at most 32 workgroups: launched as every eighth block of 8 G - where they ran is reported, whatever it was the bits above are equal
+        mask = g.stream_grid_placement()
+        assert mask != 0, "the one-XCD launch of the grid-resident kernel did not report its XCC ids"
+        print(f"grid-resident kernel, 51 buckets: XCC ids of the working blocks {mask:#x} ({'one XCD: barriers without the L2 write-back' if mask & (mask - 1) == 0 else 'several XCDs: full barriers'})")
     for obj in (g, g_seq, o):
         obj.close()
 
