@@ -909,6 +909,69 @@ def test_config5_full_size_batch(big, oracle_lib, hip_lib):
     o.close()
 
 
+@pytest.mark.gpu
+def test_batch_replay_overlay_follows_the_map(scene, oracle_lib, hip_lib):
+    """The overlay replay reads derived structures of the shared map - the frozen-map grid, and a bitmap of the base voxels that are
+    frozen leaves (their points are dropped after one bit test) - and both must follow the map: replay a batch, then let the HANDLE'S map
+    change through the stream path (three scans with insert: new voxels, leaves that fill up and freeze), then replay the same batch
+    again.  Each time every scan must match the oracle on a private copy of the map AS IT IS THEN (counts exact, state 1e-6), and the
+    second replay must differ from the first (the map really changed under it)."""
+    S, n_pts, nb = 3, 20000, 4
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    t0 = 31.0
+    x0 = scenes.init_filter(o, scene, t0)
+    scenes.first_frame(o, scene, t0, x0, dense=20000)
+    g.map_import(o.map_export())
+    g.init_process_cov_q()
+    o.map_import(o.map_export())   # both sides from the re-imported form (test_batch_replay_overlay)
+    rng = np.random.default_rng(626262)
+    xs, Ps, scans = [], [], []
+    for s in range(S):
+        tb = t0 + 0.4 + 0.17 * s
+        scans.append(synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=8105 + s, seed_noise=8206 + s))
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+    off, dt = synth.buckets_of(scans[0])
+    allpts = np.concatenate(scans)
+    d_pts = g.device_malloc(allpts.nbytes)
+    g.h2d(d_pts, allpts)
+    g.overlay_reserve(16384, 32768, 16384)
+
+    def replay_and_check(tag):
+        blob = g.map_export()
+        g.batch_set_priors(np.array(xs), np.array(Ps))
+        poses = g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
+        X, _ = g.batch_get_states(0, S)
+        counts = []
+        for s in range(S):
+            o.map_import(blob)
+            o.set_map_insert(True)
+            o.set_state(xs[s], Ps[s])
+            o.set_times(0.0, 0.0)
+            po, _ = o.process_scan(scans[s], 0.0)
+            xo, _ = o.get_state()
+            assert (po.n_buckets, int(po.n_effect)) == (poses[s].n_buckets, int(poses[s].n_effect)), (tag, s, po.n_effect, poses[s].n_effect)
+            assert np.abs(xo - X[s]).max() < 1e-6, (tag, s, np.abs(xo - X[s]).max())
+            counts.append(int(po.n_effect))
+        return counts
+
+    first = replay_and_check("young map")
+    # the handle's own map moves on: dense scans with insert through the stream path (and through the oracle, only to keep its filter in step)
+    for k in range(3):
+        tb = t0 + 0.1 * (k + 1)
+        pts = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=5, seed_scan=8300 + k, seed_noise=8400 + k)
+        g.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30))
+        g.set_times(tb, tb)
+        g.process_scan(pts, tb)
+    second = replay_and_check("after three more scans")
+    assert first != second, (first, second)
+    print(f"overlay follows the map: n_effect {first} on the young map, {second} after three more scans with insert")
+    g.device_free(d_pts)
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("case", ["scattered", "sectors", "tiny"])
 def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
     """Batch replay WITH the map insert (lk_batch_replay_overlay_dev, SURVEY 8d config 5 "scan-local insert overlay"): every scan
