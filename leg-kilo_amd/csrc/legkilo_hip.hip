@@ -3096,6 +3096,24 @@ int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per
     return LK_OK;
 }
 
+}  // extern "C"
+// the overlay pools as a group of slots starting at slot s0 sees them: every per-slot array advanced by s0 slots (the kernels index by blockIdx.y)
+static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
+    LkOverlay r = o;
+    r.keys += s0 * o.hash_cap;
+    r.planes += s0 * o.nodes_cap, r.match += s0 * o.nodes_cap, r.nodes += s0 * o.nodes_cap;
+    r.blocks += s0 * o.blocks_cap;
+    r.counters += s0 * LK_CTR_COUNT;
+    r.touched += s0 * o.scan_cap, r.next += s0 * o.scan_cap, r.scratch += s0 * o.scan_cap, r.gidx += s0 * o.scan_cap;
+    r.groups += s0 * o.scan_cap * 32;
+    r.slots += s0 * o.hash_cap * LK_SLOTS;
+    r.free_list += s0 * o.blocks_cap, r.freed_next += s0 * o.blocks_cap;
+    r.dirty += s0 * o.hash_cap;
+    r.bits += s0 * o.bit_words;
+    r.jobs += s0 * o.hash_cap * LK_INLINE_GROUPS;
+    return r;   // frozen, newroot, spec: shared by all slots
+}
+extern "C" {
 int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin, const uint32_t* bucket_off,
                                 const double* bucket_dt, size_t n_buckets, lk_pose* out) {
     CHECK_H(h);
@@ -3127,29 +3145,48 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     rc = zero_scan_counters(h, 0, (uint32_t)S);
     if (rc) return rc;
     hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, h->d_filters, S, t_begin);
-    {
-        const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
-        LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
-    }
     HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
     static const bool frozen_bits = getenv("LEGKILO_OV_FROZEN_BITS") == nullptr || atoi(getenv("LEGKILO_OV_FROZEN_BITS")) != 0;   // 0: every point through the probes and the walk (A/B)
     if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
-    LkFilter* fl = h->d_filters;
-    double* parts = h->d_partials;
     static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // without the fit: 184 VGPRs at 2 waves, 168 at 3
     const auto root_kernel = root_waves >= 4 ? lk_ov_insert_root_kernel<4> : root_waves == 3 ? lk_ov_insert_root_kernel<3> : lk_ov_insert_root_kernel<2>;
     static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
     static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
-    for (size_t k = 0; k < live.size(); ++k) {
+    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 2): the scans are independent, and the passes of a bucket are of two
+    // kinds - the root pass issues VALU work at 2.8 TB/s of HBM traffic, the others (re-projection, copy-on-write, plane fits) only move
+    // bytes - so one group's root pass runs beside the other group's memory passes.  A group is the same launches with every per-slot
+    // array offset to its first slot (ov_at).  Profiling mode (per-launch events + sync) and small batches stay on one stream.
+    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 2;
+    const int ngroups = (!h->profiling && S >= 64 * ov_groups_env) ? ov_groups_env : 1;
+    hipStream_t streams[lk_handle::kMaxGroups];
+    streams[0] = h->stream;
+    for (int g = 1; g < lk_handle::kMaxGroups; ++g) streams[g] = h->side[g - 1];
+    if (ngroups > 1) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        for (int g = 1; g < ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(streams[g], h->ev_fork, 0));
+    }
+    const LkOverlay ov_all = ov;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int s0 = (int)((long)S * grp / ngroups), sn = (int)((long)S * (grp + 1) / ngroups) - s0;
+        const unsigned int per = std::max(std::max(ov_all.hash_cap, ov_all.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
+        LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, sn), dim3(256), 0, streams[grp], ov_at(ov_all, (size_t)s0)));
+    }
+    for (size_t k = 0; k < live.size(); ++k)
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int s0 = (int)((long)S * grp / ngroups), S = (int)((long)n_scans * (grp + 1) / ngroups) - s0;   // (S: this group's slots from here on)
+        const LkOverlay ov = ov_at(ov_all, (size_t)s0);
+        hipStream_t st = streams[grp];
+        LkFilter* fl = h->d_filters + s0;
+        double* parts = h->d_partials + (size_t)s0 * h->part_stride;
         const size_t b = live[k];
         const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
         const double t = t_begin + bucket_dt[b];
         const int nblk = (nb + LK_RB - 1) / LK_RB;
-        const lk_point* pts = d_pts + bucket_off[b];
+        const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
         if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
         LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb, parts, h->part_stride));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
@@ -3170,6 +3207,11 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         if (k + 1 < live.size())
             LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
                                                     t_begin + bucket_dt[live[k + 1]], 2));
+    }
+    HIPCHK(h, hipGetLastError());
+    for (int g = 1; g < ngroups; ++g) {  // join: everything after this point on h->stream sees every group's results
+        HIPCHK(h, hipEventRecord(h->ev_join[g - 1], streams[g]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[g - 1], 0));
     }
     h->ov_last_slots = (uint32_t)S;
     const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};

@@ -981,7 +981,7 @@ def test_batch_replay_overlay_follows_the_map(scene, oracle_lib, hip_lib):
     o.close()
 
 
-@pytest.mark.parametrize("case", ["scattered", "sectors", "tiny"])
+@pytest.mark.parametrize("case", ["scattered", "sectors", "tiny", "groups"])
 def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
     """Batch replay WITH the map insert (lk_batch_replay_overlay_dev, SURVEY 8d config 5 "scan-local insert overlay"): every scan
     of the batch runs KILO::process's whole bucket loop - predict, residual, update, re-projection + UpdateVoxelMap per bucket
@@ -992,13 +992,18 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
       scattered: the buckets are a random partition of the scan (every bucket's insert refits / creates planes the next bucket
                  matches) on a young map - the overlay lookup path of the residual pass is what decides the counts;
       sectors:   config 5's shape at full size (100 000 points, 5 azimuth sectors of 20 000);
-      tiny:      12 buckets of 40..90 points, one scan of a single bucket's worth of new voxels."""
+      tiny:      12 buckets of 40..90 points, one scan of a single bucket's worth of new voxels;
+      groups:    130 such scans - from 128 on the replay splits its slots into two groups on two HIP streams (each group sees the
+                 pools offset to its first slot); the slots on both sides of the seam and at both ends are checked."""
     if case == "sectors":
         S, n_pts, nb, young = 3, 100000, 5, False
     elif case == "scattered":
         S, n_pts, nb, young = 4, 30000, 5, True
+    elif case == "groups":
+        S, n_pts, nb, young = 130, 800, 12, True
     else:
         S, n_pts, nb, young = 5, 800, 12, True
+    check_slots = list(range(S)) if S <= 8 else [0, S // 2 - 1, S // 2, S - 1]
     o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
     g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
     t0 = 21.0
@@ -1048,6 +1053,8 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
         with pytest.raises(hip_lib.LegKiloError, match="overlay pool overflow"):
             g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
         g.overlay_reserve(16384, 32768, 16384)   # a young map: a scattered 30 000-point scan touches most of its voxels
+    if case == "groups":
+        g.overlay_reserve(2048, 4096, 2048)
     g.batch_set_priors(np.array(xs), np.array(Ps))
     poses = g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
     Xall, Pall = g.batch_get_states(0, S)
@@ -1060,7 +1067,7 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
     assert [int(p.n_effect) for p in poses] == [int(p.n_effect) for p in poses2]
     g.device_free(d_pts)
     differs = 0
-    for s in range(S):
+    for s in check_slots:
         o.map_import(blob)
         o.set_map_insert(True)
         o.set_state(xs[s], Ps[s])
