@@ -3156,11 +3156,11 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
     static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
-    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 2): the scans are independent, and the passes of a bucket are of two
+    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 3): the scans are independent, and the passes of a bucket are of two
     // kinds - the root pass issues VALU work at 2.8 TB/s of HBM traffic, the others (re-projection, copy-on-write, plane fits) only move
     // bytes - so one group's root pass runs beside the other group's memory passes.  A group is the same launches with every per-slot
     // array offset to its first slot (ov_at).  Profiling mode (per-launch events + sync) and small batches stay on one stream.
-    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 2;
+    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 3;
     const int ngroups = (!h->profiling && S >= 64 * ov_groups_env) ? ov_groups_env : 1;
     hipStream_t streams[lk_handle::kMaxGroups];
     streams[0] = h->stream;
@@ -3177,7 +3177,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     }
     for (size_t k = 0; k < live.size(); ++k)
     for (int grp = 0; grp < ngroups; ++grp) {
-        const int s0 = (int)((long)S * grp / ngroups), S = (int)((long)n_scans * (grp + 1) / ngroups) - s0;   // (S: this group's slots from here on)
+        const int s0 = (int)((long)S * grp / ngroups), Sg = (int)((long)S * (grp + 1) / ngroups) - s0;   // this group's slots
         const LkOverlay ov = ov_at(ov_all, (size_t)s0);
         hipStream_t st = streams[grp];
         LkFilter* fl = h->d_filters + s0;
@@ -3187,25 +3187,25 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         const double t = t_begin + bucket_dt[b];
         const int nblk = (nb + LK_RB - 1) / LK_RB;
         const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
-        if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
-        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb, parts, h->part_stride));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
+        if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
+        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, Sg), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb, parts, h->part_stride));
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
         // the bucket's insert into every slot's overlay, from the posterior (KILO.cc:216-233)
-        LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
-        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, ov));
+        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
         const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
         // (measured at 1024 slots x 20 000-point buckets, workgroups per slot: copy-on-write 2.8 / 6.6 / 12.2 ms per batch at 4 / 16 / 32 - a wave takes 64
         // roots, more waves only find nothing to do; root pass 12.8 / 11.0 / 11.7 - a wave works through its roots one after the other)
         const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
-        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
-        LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, S), dim3(LK_WAVE), 0, st, ov, h->pr));
-        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
-        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
+        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         if (k + 1 < live.size())
-            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
+            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
                                                     t_begin + bucket_dt[live[k + 1]], 2));
     }
     HIPCHK(h, hipGetLastError());

@@ -993,17 +993,17 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
                  matches) on a young map - the overlay lookup path of the residual pass is what decides the counts;
       sectors:   config 5's shape at full size (100 000 points, 5 azimuth sectors of 20 000);
       tiny:      12 buckets of 40..90 points, one scan of a single bucket's worth of new voxels;
-      groups:    130 such scans - from 128 on the replay splits its slots into two groups on two HIP streams (each group sees the
-                 pools offset to its first slot); the slots on both sides of the seam and at both ends are checked."""
+      groups:    200 such scans - from 192 on the replay splits its slots into three groups on three HIP streams (each group sees the
+                 pools offset to its first slot); the slots on both sides of the seams and at both ends are checked."""
     if case == "sectors":
         S, n_pts, nb, young = 3, 100000, 5, False
     elif case == "scattered":
         S, n_pts, nb, young = 4, 30000, 5, True
     elif case == "groups":
-        S, n_pts, nb, young = 130, 800, 12, True
+        S, n_pts, nb, young = 200, 800, 12, True
     else:
         S, n_pts, nb, young = 5, 800, 12, True
-    check_slots = list(range(S)) if S <= 8 else [0, S // 2 - 1, S // 2, S - 1]
+    check_slots = list(range(S)) if S <= 8 else [0, S // 3 - 1, S // 3, 2 * S // 3 - 1, 2 * S // 3, S - 1]   # both sides of the seams of three slot groups
     o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
     g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
     t0 = 21.0
