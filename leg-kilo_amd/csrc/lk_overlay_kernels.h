@@ -5,15 +5,19 @@
 // path keeps it: SURVEY 8(d) config 5, "scan-local insert overlay".  The shared (base) map stays read-only.  Scan s (= filter slot s)
 // owns a complete private LkMap - hash table, node / plane / match / point-block pools, per-bucket work lists - that starts EMPTY and
 // only ever holds the root voxels this scan's inserts touch:
-//   * the re-projection pass looks a point's root up in the slot's private table first, then in the base map; a point that the base
-//     (or private) tree would ignore - it lands in a frozen leaf - is dropped right there, as on the stream path.  Otherwise the
-//     point's key is claimed in the slot's table (one relaxed 64-bit CAS; the table index is the root's node id) and the point is
-//     queued on that root record;
-//   * lk_ov_materialise_kernel, one wave per touched root that does not exist yet, copies the base voxel's whole octree - node,
-//     plane, match records and the live leaves' points - into the slot's pools (child / block ids renumbered), or creates an empty
-//     root where the base map has none.  Whole subtrees are copied on first touch, so a private tree never points into the base pools;
-//   * the root / apply / fallback passes of the stream path (dev_insert_root, dev_insert_apply, dev_insert_fallback) then run
-//     UNCHANGED on the private LkMap, with the slot as a second grid dimension: thousands of roots per launch instead of ~1000.
+//   * the re-projection pass drops a point whose base voxel is a frozen leaf after one bit test (lk_ov_frozen_bits_kernel: such a
+//     voxel ignores points for good, so no scan ever owns a copy of it); otherwise it looks the point's root up in the slot's private
+//     table first, then in the base map, drops the point if the tree it finds would ignore it, else claims the key in the slot's
+//     table (one relaxed 64-bit CAS; the table index is the root's node id) and queues the point on that root record;
+//   * lk_ov_materialise_kernel makes the touched roots that do not exist yet private: 64 roots per wave, one lane each - an empty
+//     root where the base map has none; for a leaf voxel the node record by its lane, plane + match records of the chunk as one
+//     flat list of 16-B pieces, the POINTS left to the root pass ("thin" root); only a cut voxel's octree is copied node by node
+//     (child / block ids renumbered).  A private tree never points into the base pools once its bucket is over;
+//   * the root / apply / fallback passes of the stream path (dev_insert_root, dev_insert_apply, dev_insert_fallback) then run on
+//     the private LkMap with the slot as a second grid dimension - 10^6 roots per launch instead of ~1000 - in their batch form
+//     (template flag OV): a thin root's old points are read from the base block and written, with the new ones, to the private
+//     block; the next root's record is requested a root ahead; the plane fit that ends a leaf's bucket is only DECIDED and left as
+//     a 96-B job to lk_ov_fit_lane_kernel, which fits one plane per LANE;
 //   * the residual pass of the next bucket finds a key's root through one bit per base grid cell ("this slot has a private root
 //     here", 12.8 KB per slot for the bench map: L2-resident): clear -> the frozen-map grid cell as before (match_flat); set -> the
 //     slot's private table and the pre-order walk of the private tree (match_root, the stream path's matcher).
