@@ -3060,7 +3060,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.scratch, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.gidx, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.groups, s * n.scan_cap * 2 * sizeof(LkGroup));
-    if (e == hipSuccess) e = get(&o.slots, s * n.hash_cap * LK_SLOTS * sizeof(int));
+    if (e == hipSuccess) e = get(&o.slots, s * n.hash_cap * LK_SLOTS * sizeof(float4));
     if (e == hipSuccess) e = get(&o.free_list, s * n.blocks_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.freed_next, s * n.blocks_cap * sizeof(int));
     if (e == hipSuccess) e = get(&o.dirty, s * n.hash_cap * sizeof(unsigned int));
@@ -3106,7 +3106,7 @@ static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
     r.counters += s0 * LK_CTR_COUNT;
     r.touched += s0 * o.scan_cap, r.next += s0 * o.scan_cap, r.scratch += s0 * o.scan_cap, r.gidx += s0 * o.scan_cap;
     r.groups += s0 * o.scan_cap * 32;
-    r.slots += s0 * o.hash_cap * LK_SLOTS;
+    r.slots += s0 * o.hash_cap * LK_SLOTS * 4;
     r.free_list += s0 * o.blocks_cap, r.freed_next += s0 * o.blocks_cap;
     r.dirty += s0 * o.hash_cap;
     r.bits += s0 * o.bit_words;

@@ -744,6 +744,13 @@ __device__ __forceinline__ void insert_point_pw(const LkParams& pr, const Bucket
         pw[0] = w.x + bc.p[0], pw[1] = w.y + bc.p[1], pw[2] = w.z + bc.p[2];
     }
 }
+__device__ __forceinline__ void insert_point_pw_of(const LkParams& pr, const BucketConst& bc, const float4& p, double* pw) {   // insert_point_pw's transform of a point in hand
+    V3 pb = V3{(double)p.x, (double)p.y, (double)p.z};
+    V3 e = mat3_mul_v(pr.ext_R, pb);
+    V3 pi = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
+    V3 w = mat3_mul_v(bc.R, pi);
+    pw[0] = w.x + bc.p[0], pw[1] = w.y + bc.p[1], pw[2] = w.z + bc.p[2];
+}
 __device__ __forceinline__ void geom_to_pt(const PointGeom& g, PtU& pt) {
     pt.pw[0] = g.p_w.x, pt.pw[1] = g.p_w.y, pt.pw[2] = g.p_w.z;
     pt.var[0] = g.var.xx, pt.var[1] = g.var.xy, pt.var[2] = g.var.xz;
@@ -1039,13 +1046,20 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
     // touched list; its record, plane flags and slot line; its scan points; its leaf's points).  The first two are requested ahead: the id
     // TWO roots ahead, the record ONE root ahead (lane k holds 16-B piece k of the 128-B record, fields are picked with readlane) - they
     // land while the current root is worked on.  Roots of one touched list are distinct, so nothing requested ahead is changed meanwhile.
+    // (OV: a slot-line entry is the queued POINT itself, {x, y, z, index} - lk_ov_reproject_kernel - so the root's scan points arrive
+    // with its record instead of being gathered from the scan in 64-B sectors: 690 B per root for 173 B used)
     int pf_root1 = -1, pf_root2 = -1, pf_flags = 0, pf_slot = 0x7fffffff;
+    float pf_px = 0.f, pf_py = 0.f, pf_pz = 0.f;
     int4 pf_rec = make_int4(0, 0, 0, 0);
     auto prefetch_record = [&](int r) {
         if (r >= 0) {
             if (lane < 8) pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane];
             pf_flags = (int)map.planes[r].flags;
-            pf_slot = (lane < LK_SLOTS) ? map.slots[(size_t)r * LK_SLOTS + lane] : 0x7fffffff;
+            pf_slot = 0x7fffffff;
+            if (lane < LK_SLOTS) {
+                const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)r * LK_SLOTS + lane];
+                pf_px = q.x, pf_py = q.y, pf_pz = q.z, pf_slot = __float_as_int(q.w);
+            }
         }
     };
     if (OV) {
@@ -1061,6 +1075,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
 #endif
         int root, m, rnpts, rnewp, rblock, rlayer, cur_list, slot_idx, ov_live = 0, ov_cowblk = 0;
         unsigned int rst, rpf;
+        const float cpx = pf_px, cpy = pf_py, cpz = pf_pz;   // OV: this root's queued points (lane k: the k-th queued), before the next root's are requested
         if (OV) {
             root = pf_root1;
             rlayer = __builtin_amdgcn_readlane(pf_rec.w, 3);
@@ -1125,7 +1140,9 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             if (block < 0) block = alloc_block(map);
             cow_finalise();   // (a thin root owns its private block already)
             if (lane < m) {
-                const float4 p = reinterpret_cast<const float4*>(pts)[idx];
+                float4 p;
+                if (OV) p = make_float4(cpx, cpy, cpz, 0.f);
+                else p = reinterpret_cast<const float4*>(pts)[idx];
                 const PointGeom gm = point_geom(p.x, p.y, p.z, bc, pr);
                 lk_pt_rec* dst = &map.blocks[block].pts[rnpts + rank];
                 dst->pw[0] = gm.p_w.x, dst->pw[1] = gm.p_w.y, dst->pw[2] = gm.p_w.z;
@@ -1178,9 +1195,17 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         int t_npts = 0, t_newp = 0, t_block = -1, t_layer = 0, t_plane = 0;
         unsigned int t_state = 0;
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool pts_in_hand = OV && in_slots;
+        if (pts_in_hand) {   // the points came in queue order: the same forward permute as the indices
+            const int dstl = ((lane < m) ? rank : lane) << 2;
+            p4.x = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpx)));
+            p4.y = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpy)));
+            p4.z = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpz)));
+        }
         if (mine) {
             double pw[3];
-            insert_point_pw<FROM_PV>(pr, bc, pts, pv, sidx, pw, p4);
+            if (pts_in_hand) insert_point_pw_of(pr, bc, p4, pw);
+            else insert_point_pw<FROM_PV>(pr, bc, pts, pv, sidx, pw, p4);
             int node = root;
             unsigned int st = rst, pf = rpf;
             int npts = rnpts, newp = rnewp, block = rblock, layer = rlayer;

@@ -53,7 +53,7 @@ struct LkOverlay {
     int* scratch;                // [S][scan_cap]
     int* gidx;                   // [S][scan_cap]
     int* groups;                 // [S][2 * scan_cap * 16]  (LkGroup = 16 ints)
-    int* slots;                  // [S][hash_cap][LK_SLOTS]: only roots queue points
+    int* slots;                  // [S][hash_cap][LK_SLOTS] x float4 {x, y, z, index}: the points queued on a root in the current bucket (only roots queue points)
     int* free_list;              // [S][blocks_cap]
     int* freed_next;             // [S][blocks_cap]
     unsigned int* dirty;         // [S][hash_cap] (roots only; epoch 0)
@@ -77,7 +77,7 @@ __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int s
     m.touched = ov.touched + s * ov.scan_cap;
     m.heavy = nullptr;
     m.next = ov.next + s * ov.scan_cap;
-    m.slots = ov.slots + s * ov.hash_cap * LK_SLOTS;
+    m.slots = ov.slots + s * ov.hash_cap * LK_SLOTS * 4;   // 16-B entries (dev_insert_root<.., OV> reads them as float4)
     m.scratch = ov.scratch + s * ov.scan_cap;
     m.groups = ov.groups + s * ov.scan_cap * 32;
     m.gidx = ov.gidx + s * ov.scan_cap;
@@ -289,7 +289,18 @@ __global__ void __launch_bounds__(LK_WAVE)
             if (claimed) pm.nodes[root].pad_[LK_PAD_BASE] = (unsigned int)(broot + 1);
         }
     }
-    queue_point_on_root(pm, root, i);
+    // queue_point_on_root with the POINT in the slot line ({x, y, z, index}): the root pass gets a root's points with one coalesced read
+    // of its line instead of a gather from the scan (only the overflow of a root with more than LK_SLOTS points is kept by index)
+    const unsigned int k = atomicAdd(&pm.nodes[root].pad_[0], 1u);
+    if (k < (unsigned int)LK_SLOTS) {
+        reinterpret_cast<float4*>(pm.slots)[(size_t)root * LK_SLOTS + k] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    } else {
+        pm.next[i] = atomicExch(&pm.nodes[root].list_head, i);
+    }
+    if (k == 0) {
+        const unsigned int t = atomicAdd(&pm.counters[LK_CTR_TOUCHED], 1u);
+        pm.touched[t] = root;
+    }
 }
 
 // ---------------------------------------------------------------- copy-on-write of a base voxel's octree
