@@ -56,18 +56,72 @@ N_BUCKETS = 5
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X datasheet: peak fp64 vector = fp64 matrix = 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 row; 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6)
 COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
+OV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_overlay_pmc.json")
+OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_root_fast", "ov_fit_lane",
+              "ov_insert_apply", "ov_insert_fallback")
+OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
 
 
-def kernel_sources_sha16():
+def kernel_sources_sha16(files=KERNEL_SOURCES):
     """Fingerprint of the batch residual kernel's sources: tools/collect_r03.py stores it beside the counters it collects, and the
     bench line warns when the kernel has changed since (the counters then describe an older kernel)."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in files:
         h.update(open(os.path.join(ROOT, "leg-kilo_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def overlay_roofline(kernel_ms, launches, n_scans, warnings):
+    """Counter-derived roofline object of the batch WITH insert (extra.overlay_roofline).  profiles/latest_overlay_pmc.json (tools/collect_overlay_pmc.py,
+    from separate `rocprofv3 --pmc` passes of tools/overlay_prof.py) holds, per lk_ov_* kernel and launch: HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, the guide's
+    gfx950 correction), VALU instructions, waves, VGPRs / scratch / waves per SIMD.  The launch durations are THIS run's (HIP events, one stream).  The dominant
+    kernel is the one with the most time in this run."""
+    out = {"bound": "hbm+latency", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if not os.path.exists(OV_PMC_FILE):
+        out["pmc_source"] = None
+        warnings.append("profiles/latest_overlay_pmc.json missing: extra.overlay_roofline has durations only (tools/gpu_prof_overlay.sh)")
+        pmc = {}
+    else:
+        pmc = json.load(open(OV_PMC_FILE))
+        out["pmc_source"] = f"profiles/latest_overlay_pmc.json (tag {pmc.get('tag')}, commit {pmc.get('commit')}, {pmc.get('slots')} slots)"
+        if pmc.get("kernel_sources_sha16") != kernel_sources_sha16(OV_KERNEL_SOURCES):
+            warnings.append(f"overlay counters (profiles/latest_overlay_pmc.json, tag {pmc.get('tag')}) were collected on a different version of "
+                            f"{', '.join(OV_KERNEL_SOURCES)}: re-run tools/gpu_prof_overlay.sh")
+    per = {}
+    tot_bytes, tot_ms = 0.0, 0.0
+    for k, ms in kernel_ms.items():
+        if not k.startswith("ov_") or not launches.get(k):
+            continue
+        c = (pmc.get("kernels") or {}).get(k)
+        e = {"ms_per_batch": ms, "launches": launches[k], "ms_per_launch": round(ms / launches[k], 4)}
+        if c:
+            scale = n_scans / float(pmc.get("slots") or n_scans)   # counters are per launch of the profiled batch
+            gb = c["hbm_bytes_per_launch"] * scale / 1e9
+            e.update({"hbm_GB_per_launch": round(gb, 3), "achieved_GBs": round(gb / (ms / launches[k] * 1e-3), 1),
+                      "frac": round(gb / (ms / launches[k] * 1e-3) / HBM_PEAK_GBS, 4),
+                      "valu_issue_frac": None if not c.get("valu_insts_per_launch") else round(c["valu_insts_per_launch"] * scale * 4.0 / (SIMDS * CLK_GHZ * 1e9 * ms / launches[k] * 1e-3), 3),
+                      "vgprs": c.get("vgprs"), "scratch_bytes": c.get("scratch"), "waves_per_simd": c.get("waves_per_simd")})
+            tot_bytes += gb * launches[k]
+            tot_ms += ms
+        per[k] = e
+    if per:
+        dom = max(per, key=lambda k: per[k]["ms_per_batch"])
+        out["kernel"] = "lk_" + dom + "_kernel"
+        out.update({k: v for k, v in per[dom].items() if k in ("achieved_GBs", "frac", "hbm_GB_per_launch", "valu_issue_frac", "vgprs", "scratch_bytes", "waves_per_simd", "ms_per_launch")})
+        out["achieved"] = per[dom].get("achieved_GBs")
+        out["traffic"] = None if "hbm_GB_per_launch" not in per[dom] else round(per[dom]["hbm_GB_per_launch"] * 1e9)
+    out["per_kernel"] = per
+    if tot_ms > 0:
+        out["all_overlay_kernels"] = {"hbm_GB_per_batch": round(tot_bytes, 2), "achieved_GBs_over_kernel_time": round(tot_bytes / (tot_ms * 1e-3), 1),
+                                      "frac": round(tot_bytes / (tot_ms * 1e-3) / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def pts_per_launch_of(S):
+    return S * (N_PTS // N_BUCKETS)
 
 
 class Frozen:
@@ -163,8 +217,9 @@ def main():
     # step; `--step-sweep`: elapsed(K) = 0.15 + 1.685 K ms once warm); `extra.sustained_*` is the >= 1 s figure
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--ramp-steps", type=int, default=30, help="untimed steps BEFORE the warm-up steps (clocks up after the idle set-up phase): the driver's "
-                    "--warmup 5 left ~3 %% of ramp inside its 20-step region; not counted as warm-up, never timed")
+    ap.add_argument("--ramp-steps", type=int, default=0, help="untimed steps BEFORE the warm-up steps (clocks up after the idle set-up phase): with --warmup 5 "
+                    "~3 %% of ramp sits inside a 20-step region.  Default 0 = exactly the protocol the driver asks for (W warm-up steps, K timed steps), as in "
+                    "rounds 1-3; round 4's line had 30 (disclosed); `extra.sustained_*` is the clocks-up figure")
     ap.add_argument("--scans-per-gpu", type=int, default=1024, help="weak scaling: a batch of 1024 scans per GPU (fits one GPU)")
     ap.add_argument("--total-scans", type=int, default=0, help="strong scaling: this many scans in total, block-sharded over the GPUs "
                     "(BASELINE config 5 as worded: 1024 -> 128 per GPU at N=8); 0 = weak scaling")
@@ -176,6 +231,8 @@ def main():
     ap.add_argument("--config1-scans", type=int, default=2048, help="scans of the ragged config-1 batch measured as an extra (0 = skip)")
     ap.add_argument("--sustained-s", type=float, default=1.2, help="length of the sustained run reported in extra (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
+    ap.add_argument("--shuffle-check", type=int, default=24, help="extra.shuffled_in_bucket_*: the same batch with a random permutation inside every time bucket (curvature kept) - "
+                    "the headline's scans come in voxel-grid cell order inside a bucket; this many of its scans are replayed by the oracle (0 = skip the extra)")
     ap.add_argument("--overlay-scans", type=int, default=1024, help="scans of the batch replayed WITH the map insert (per-scan overlay, extra.overlay_*; 0 = skip)")
     ap.add_argument("--overlay-check", type=int, default=24, help="of those, scans the oracle replays (insert on, private copy of the map) for extra.overlay_parity")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
@@ -332,8 +389,8 @@ def main():
     ring = torch.zeros((ring_rows, S_max * pose_sz), dtype=torch.uint8).pin_memory()   # S_max columns: equal bytes on every rank
     gathered = [None]
 
-    def step(k):
-        g.batch_replay_async_dev(d_batch.data_ptr(), (k % max(2, args.in_flight)) * S_max, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(),
+    def step(k, batch_ptr=None):
+        g.batch_replay_async_dev(d_batch.data_ptr() if batch_ptr is None else batch_ptr, (k % max(2, args.in_flight)) * S_max, S, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(),
                                  d_P900=d_P.data_ptr(), host_out_ptr=ring[k % ring_rows].data_ptr())
 
     def finish(k_steps):
@@ -436,6 +493,53 @@ def main():
             sweep[K] = round((time.perf_counter() - ts) * 1e3, 3)
         extra["step_sweep_ms"] = sweep
 
+    # ---- input-order sensitivity: the SAME batch with a random permutation inside every time bucket.  The headline's scans come, inside a
+    # bucket, in voxel-grid cell order (synth.dense_scan(layout="cell"): the order pcl::VoxelGrid leaves its output in, KILO.cc:356-360), which
+    # puts neighbouring lanes into neighbouring voxels; a recorded scan that was not voxel-filtered has no such order.
+    shuf = None
+    if rank == 0 and world_size == 1 and args.shuffle_check > 0:
+        pts_i = d_batch.view(torch.int32).view(S, N_PTS, 4)
+        d_shuf = torch.empty_like(pts_i)
+        gen_t = torch.Generator(device=dev)
+        gen_t.manual_seed(4242)
+        for b in range(len(dt)):
+            a_, e_ = int(off[b]), int(off[b + 1])
+            if e_ <= a_:
+                continue
+            perm = torch.rand((S, e_ - a_), device=dev, generator=gen_t).argsort(dim=1)
+            d_shuf[:, a_:e_] = torch.gather(pts_i[:, a_:e_], 1, perm[..., None].expand(-1, -1, 4))
+            del perm
+        torch.cuda.synchronize()
+        for k in range(max(args.warmup, 3)):
+            step(k, d_shuf.data_ptr())
+        finish(min(max(args.warmup, 3), ring_rows))
+        sync_all()
+        ts = time.perf_counter()
+        for k in range(args.steps):
+            step(k, d_shuf.data_ptr())
+        finish(args.steps)
+        sync_all()
+        el_sh = time.perf_counter() - ts
+        sh_last = ring[(args.steps - 1) % ring_rows][: S * pose_sz].numpy().view(_abi.pose_dtype()).copy()
+        n_sh = min(args.shuffle_check, S)
+        sh_host = d_shuf[:n_sh].cpu().numpy().view(scans[0].dtype).reshape(n_sh, N_PTS)
+        extra["shuffled_in_bucket_ms_per_step"] = round(el_sh / args.steps * 1e3, 3)
+        extra["shuffled_in_bucket_ps_per_point"] = round(el_sh / args.steps / N_BUCKETS * 1e12 / pts_per_launch_of(S), 2)
+        extra["shuffled_in_bucket_scans_per_s"] = round(S * args.steps / el_sh, 1)
+        extra["shuffled_in_bucket_over_cell_order"] = round((el_sh / args.steps) / (elapsed / args.steps), 3)
+        extra["shuffled_in_bucket_mean_n_effect"] = float(sh_last["n_effect"].astype(np.float64).mean())
+        pmc_sh = os.path.join(ROOT, "profiles", "latest_shuffled_pmc.json")
+        if os.path.exists(pmc_sh):
+            try:
+                j_ = json.load(open(pmc_sh))
+                extra["shuffled_in_bucket_tcc_req_per_point"] = j_.get("tcc_req_per_point")
+                extra["shuffled_in_bucket_hbm_bytes_per_point"] = j_.get("hbm_bytes_per_point")
+                extra["shuffled_in_bucket_pmc_source"] = f"profiles/latest_shuffled_pmc.json (tag {j_.get('tag')}, commit {j_.get('commit')})"
+            except Exception as e:  # noqa: BLE001
+                warnings.append(f"profiles/latest_shuffled_pmc.json unreadable: {e}")
+        shuf = (sh_host, sh_last)
+        del d_shuf, pts_i
+
     # ---- kernel-level timing pass (HIP events on the handle's stream, whole-batch launches on ONE stream), outside the timed region
     g.profile_reset()
     g.profile_enable(1)
@@ -506,37 +610,57 @@ def main():
     # ---- extra: the same batch WITH the map insert - every scan on its own copy-on-write overlay of the shared map (SURVEY 8d config 5,
     # "scan-local insert overlay"; KILO.cc:216-233 after every bucket): what KILO::process computes per scan, for the whole batch
     ov = None
-    S_ov = min(args.overlay_scans, S) if rank == 0 else 0
+    S_ov = min(args.overlay_scans, S)   # every rank replays its own shard with insert (an overlay is private to its scan: no collective on the data path)
     if S_ov > 0:
         try:
             g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
             g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)   # warm (allocates the overlay pools)
+            g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
+            g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)   # second warm run: pools re-made at the first run's high-water marks + 25 %
             tov = []
             for _ in range(3):
                 g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
-                g.synchronize()
+                sync_all()                                  # N > 1: every rank starts its batch together, the slowest rank's time counts
                 tc = time.perf_counter()
                 ov_poses = g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt)
-                tov.append(time.perf_counter() - tc)
+                t_one = time.perf_counter() - tc
+                if dist is not None:
+                    tt = torch.tensor([t_one], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t_one = float(tt.item())
+                tov.append(t_one)
             t_ov = float(np.median(tov))
             ov_p = np.frombuffer(ov_poses, dtype=_abi.pose_dtype()).copy()
-            extra["overlay_scans"] = S_ov
+            S_ov_all = S_ov
+            if dist is not None:   # shards may differ by one scan in the strong-scaling mode
+                tt = torch.tensor([S_ov], dtype=torch.int64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                S_ov_all = int(tt.item())
+                # the per-scan results of every rank's overlay batch, all-gathered (what a sharded replay returns: replay.replay_batch_overlay)
+                rows_all = replay.gather_results(dist, replay.pose_rows(ov_p), world_size, dev)
+                extra["overlay_rows_gathered"] = int(rows_all.shape[0])
+            extra["overlay_scans"] = S_ov_all
+            extra["overlay_scans_per_gpu"] = S_ov
             extra["overlay_ms_per_batch"] = round(t_ov * 1e3, 3)
-            extra["overlay_scans_per_s"] = round(S_ov / t_ov, 1)
-            extra["overlay_alg_GBs"] = round(ALG_BYTES_FULL * N_PTS * S_ov / t_ov / 1e9, 1)
-            extra["overlay_alg_frac_of_hbm_peak"] = round(ALG_BYTES_FULL * N_PTS * S_ov / t_ov / 1e9 / HBM_PEAK_GBS, 4)
+            extra["overlay_scans_per_s"] = round(S_ov_all / t_ov, 1)
+            # SURVEY 8(d)'s contract bytes (288 + 728 B per point entering the path), for reference only: half of the bench's points land in
+            # frozen leaves and are dropped after one bit test (the reference ignores them too), so this is NOT an achieved HBM rate - the
+            # counter-derived figure is extra.overlay_roofline
+            extra["overlay_contract_bytes_for_reference"] = {"bytes_per_point": ALG_BYTES_FULL, "GBs_if_every_point_moved_them": round(ALG_BYTES_FULL * N_PTS * S_ov_all / t_ov / 1e9, 1)}
             extra["overlay_mean_n_effect"] = round(float(ov_p["n_effect"].astype(np.float64).mean()), 1)
             r_, n_, b_ = g.overlay_stats()
             extra["overlay_private_per_scan_max"] = {"roots": r_, "nodes": n_, "point_blocks": b_}
+            pb_, pe_, pc_, pk_ = g.overlay_pool_bytes()
+            extra["overlay_pool_bytes"] = int(pb_)
+            extra["overlay_pool_per_scan"] = {"root_entries": pe_, "child_nodes": pc_, "point_blocks": pk_, "MB": round(pb_ / max(S_ov, 1) / 1e6, 1)}
             # where the time goes: the same replay once more with an event pair around every launch
             g.profile_reset()
             g.profile_enable(1)
             g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S_ov)
             g.batch_replay_overlay_dev(d_batch.data_ptr(), S_ov, N_PTS, 0.0, off, dt, want_poses=False)
             g.profile_enable(0)
-            extra["overlay_kernel_ms_per_batch"] = {k: round(g.profile_get(k)[1], 3) for k in
-                                                    ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_fit_lane",
-                                                     "ov_insert_apply", "ov_insert_fallback")}
+            extra["overlay_kernel_ms_per_batch"] = {k: round(g.profile_get(k)[1], 3) for k in OV_KERNELS if g.profile_get(k)[0]}
+            extra["overlay_roofline"] = overlay_roofline(extra["overlay_kernel_ms_per_batch"], {k: g.profile_get(k)[0] for k in OV_KERNELS}, S_ov, warnings)
             ov = ov_p
         except Exception as e:  # noqa: BLE001
             extra["overlay_error"] = f"{type(e).__name__}: {str(e)[:300]}"
@@ -727,6 +851,18 @@ def main():
             extra["config1_speedup_vs_cpu_port"] = round(extra["config1_ragged_scans_per_s"] / extra["config1_cpu_port_scans_per_s"], 1)
             parity["config1_ragged"] = {"n": len(t1s), "counts_equal": c1_eq, "max_pos_delta_m": c1_dpos}
             parity["ok"] = bool(parity["ok"] and c1_dpos <= 1e-7)
+        if shuf is not None:   # the shuffled batch's own parity sample: same oracle, same map, the scans as the device got them (the sort is stable)
+            sh_host, sh_last = shuf
+            sh_eq, sh_dpos = 0, 0.0
+            for s_ in range(len(sh_host)):
+                o.set_state(xs[s_], Ps[s_])
+                o.set_times(0.0, 0.0)
+                pose, _ = o.process_scan(sh_host[s_], 0.0, with_sort=True)
+                sl_ = sh_last[s_]
+                sh_eq += int((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect)) == (int(sl_["n_buckets"]), int(sl_["n_updates"]), int(sl_["n_effect"])))
+                sh_dpos = max(sh_dpos, float(np.abs(np.array(pose.pos) - sl_["pos"]).max()))
+            parity["shuffled_in_bucket"] = {"n": len(sh_host), "counts_equal": sh_eq, "max_pos_delta_m": sh_dpos, "tolerance_m": 1e-7}
+            parity["ok"] = bool(parity["ok"] and sh_dpos <= 1e-7 and sh_eq >= len(sh_host) - max(1, len(sh_host) // 50))
         # and the full config-3 path with insert (the reference's own timed lambda, KILO.cc:367-396)
         o.set_map_insert(True)
         o.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30))
@@ -860,6 +996,12 @@ def reference_literal(ob, cfg, P, traj, c1, blob, tcs_port):
                                           f"{Ncal} x {Ncal} inverse on this host; memory N^2 x 8 B = {Nb * Nb * 8 / 1e9:.1f} GB per bucket",
             "port_100k_s_per_scan": round(float(np.median(tcs_port)), 4),
         }
+        lit51 = os.path.join(ROOT, "profiles", "r05_cpu_literal_51.json")
+        if os.path.exists(lit51):   # BASELINE.md section 2 figure (i), MEASURED once (tools/cpu_literal_51.py: minutes per scan), quoted here
+            j = json.load(open(lit51))
+            out["literal_51_buckets_s_per_scan_measured"] = j.get("literal_51_buckets_s_per_scan_measured")
+            out["literal_51_buckets_measured_on"] = f"{j.get('cpu_model')}, {j.get('cores_used')} core, oracle port with literal_max_n raised (profiles/r05_cpu_literal_51.json)"
+            out["info6_51_buckets_s_per_scan_same_scan"] = j.get("info6_51_buckets_s_per_scan_measured")
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {str(e)[:200]}"
     return out

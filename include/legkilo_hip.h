@@ -332,14 +332,19 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
  * (the message names the slot and the sizes in use). */
 int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                                 const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
-/* Per-scan overlay capacities: root voxels a scan's inserts may touch or create, octree nodes and live point blocks of those voxels
- * (0 = derived from the scan size: n_pts / 6 roots, 1.5 nodes and 1 block per root).  Releases pools of another shape. */
+/* Per-scan overlay capacities: root voxels a scan's inserts may touch or create, octree nodes and live point blocks of those voxels.
+ * 0 (default) = sized by the library: a first guess from the scan size (n_pts / 16 roots), afterwards the previous replay's high-water
+ * marks + 25 %, and a scan that outgrows such pools makes them grow and the batch run again (no error).  Capacities set HERE are the
+ * caller's word: overflowing them fails the replay with LK_ERR_CAPACITY.  Releases pools of another shape. */
 int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per_scan, uint32_t blocks_per_scan);
 /* The voxels scan `slot` of the LAST overlay replay holds privately - every root voxel its inserts touched or created, whole octrees -
  * as a map blob (lk_map_export's format; blob == NULL: size query).  Voxels not in it are the handle's, unchanged. */
 int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes);
 /* Largest private root / node / point-block count any scan of the last overlay replay reached (any pointer may be NULL). */
 int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks);
+/* What the overlay pools hold right now: total bytes in HBM and the per-scan capacities (root-table entries = root node records,
+ * child nodes, point blocks); all 0 before the first overlay replay / after lk_overlay_reserve released them. */
+int lk_overlay_pool_bytes(lk_handle* h, uint64_t* bytes, uint32_t* root_entries, uint32_t* child_nodes, uint32_t* blocks);
 
 /* Ragged batch: the scans of a recorded run differ in size, in their time buckets (KILO.cc:375-378) and in their start
  * time.  Scan s = d_pts[scan_off[s] .. scan_off[s+1]) (scan_off: n_scans + 1 entries) on filter slot s; n_buckets[s] buckets

@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats",
 ]
 
@@ -356,6 +356,19 @@ class LegKiloHip:
                                                      C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
         return poses
 
+    def batch_replay_overlay(self, scans, t_begin, bucket_off, bucket_dt):
+        """Convenience: equally shaped host scans (lk_point arrays, time-sorted, one bucket table) -> HBM -> overlay replay on slots
+        [0, len(scans)); priors are whatever batch_set_priors put into those slots.  Returns the poses."""
+        allpts = np.ascontiguousarray(np.concatenate(scans))
+        n_pts = len(scans[0])
+        assert all(len(sc) == n_pts for sc in scans), "the overlay batch entry takes equally shaped scans (ragged: lk_batch_replay_overlay_ragged_dev)"
+        d = self.device_malloc(allpts.nbytes)
+        try:
+            self.h2d(d, allpts)
+            return self.batch_replay_overlay_dev(d, len(scans), n_pts, t_begin, bucket_off, bucket_dt)
+        finally:
+            self.device_free(d)
+
     def overlay_reserve(self, roots_per_scan=0, nodes_per_scan=0, blocks_per_scan=0):
         self._chk(self.L.lk_overlay_reserve(self.h, C.c_uint32(roots_per_scan), C.c_uint32(nodes_per_scan), C.c_uint32(blocks_per_scan)))
 
@@ -372,6 +385,12 @@ class LegKiloHip:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._chk(self.L.lk_overlay_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def overlay_pool_bytes(self):
+        """(bytes the overlay pools hold, per-scan root-table entries, child nodes, point blocks)."""
+        n, a, b, c = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.lk_overlay_pool_bytes(self.h, C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
+        return n.value, a.value, b.value, c.value
 
     @staticmethod
     def ragged_tables(scan_off, bucket_offs, bucket_dts, t_begins, imus=None, kins=None):

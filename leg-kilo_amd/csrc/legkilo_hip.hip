@@ -73,6 +73,8 @@ struct lk_handle {
     bool resident_enable = true;  // scans of small buckets as one resident launch (lk_scan_stream_kernel); LEGKILO_RESIDENT=0 / lk_stream_resident(h, 0): per-bucket launches
     bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
+    LkFilter* d_fbackup = nullptr;   // filters[0] as it was when the running scan started: what an LK_ERR_TIMEOUT puts back (grid-resident and pipelined paths)
+    bool fbackup_valid = false;
     int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
     uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0, res_redo_total = 0;
     unsigned int spec_redo_seen = 0, res_redo_seen = 0;
@@ -95,6 +97,11 @@ struct lk_handle {
     uint32_t ov_slots = 0;                                // slots the pools were allocated for
     uint32_t ov_want_roots = 0, ov_want_nodes = 0, ov_want_blocks = 0;   // lk_overlay_reserve (0: derived from the scan size)
     uint32_t ov_last_slots = 0;                           // slots of the last overlay replay (lk_overlay_export / lk_overlay_stats)
+    uint32_t ov_hw_roots = 0, ov_hw_nodes = 0, ov_hw_blocks = 0;   // high-water marks of the last replay (any slot): the next replay's pools are sized from them
+    size_t ov_hw_npts = 0;                                // ... which belong to scans of this size
+    size_t ov_pool_bytes = 0;                             // bytes the overlay pools hold (lk_overlay_pool_bytes)
+    LkFilter* d_ov_priors = nullptr;                      // the batch's priors, kept for the retry after a pool overflow
+    size_t ov_priors_cap = 0;
     unsigned int* d_ov_status = nullptr;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -172,10 +179,18 @@ static int check_map_errors(lk_handle* h) {
         const unsigned int rest = ctr[LK_CTR_ERR] & ~LK_E_SPEC_TIMEOUT;
         HIPCHK(h, hipMemcpyAsync(h->map.counters + LK_CTR_ERR, &rest, sizeof(rest), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        return fail(h, LK_ERR_TIMEOUT, "a wait between the filter and the insert side of the stream path timed out (device fault, or a pre-empted / debugged GPU; "
+        // the filter keeps its PRE-SCAN state on every path: the scan-resident kernel holds x / P in LDS and returns before its write-back;
+        // the grid-resident kernel and the pipelined launches work on filters[0] directly, so their scans start with a copy that is put back here
+        if (h->fbackup_valid) {
+            HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_fbackup, sizeof(LkFilter), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        h->fbackup_valid = false;
+        return fail(h, LK_ERR_TIMEOUT, "a bounded device-side wait of the stream path timed out (device fault, or a pre-empted / debugged GPU; "
                                        "LEGKILO_RESIDENT_TIMEOUT_MS raises the bound): the filter keeps its state from before the scan, the map may hold a partial "
                                        "insert - restore it (lk_map_import) and replay the scan");
     }
+    h->fbackup_valid = false;
     if (ctr[LK_CTR_ERR]) {
         char buf[160];
         snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch, 16 bad blob)", ctr[LK_CTR_ERR]);
@@ -341,7 +356,7 @@ void lk_destroy(lk_handle* h) {
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp,
-                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids};
+                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids, h->d_fbackup, h->d_ov_priors};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -1013,7 +1028,8 @@ extern "C" {
 // identical bits.  A barrier is the placement-independent hand-off of the CDNA guide: every wave drains its stores, the workgroup
 // meets, thread 0 issues ONE agent-scope release, arrives on a global counter, polls it (relaxed), issues ONE agent-scope acquire
 // (+ scalar-cache invalidate), the workgroup meets again.  Every wait is bounded: a timeout raises the abort word, every workgroup
-// leaves, the call fails with LK_ERR_TIMEOUT.  Off by default (lk_stream_grid / LEGKILO_GRIDSCAN=1): measured in DESIGN.md section 6.
+// leaves, the call fails with LK_ERR_TIMEOUT and the filter gets its pre-scan state back (backup_filter).  On by default for scans whose
+// buckets all hold 513 .. LK_GRIDSCAN_AUTO_MAX points (lk_stream_grid / LEGKILO_GRIDSCAN: 0 never, 2 whenever it applies); DESIGN.md section 6.
 #define LK_GRIDSCAN_WG_MAX 128
 #define LK_CTR_GRID_XCC 15   // LkMap.counters[15]: XCC ids (one bit each) the working blocks of the last one-XCD launch ran on
 }  // extern "C" (a kernel template follows)
@@ -1051,7 +1067,10 @@ __global__ void __launch_bounds__(LK_FB)
         if (tid == 0) {
             // workgroups of ONE XCD share its L2: their drained stores (write-through from the CU) are what the others' L2 requests
             // see, no write-back of the L2 is needed - the acquire below (invalidate of this CU's vector L1) always is
+            // (gfx942 / gfx950 behaviour, which is all this library is built for; the workgroup-scope release keeps the ordering in the
+            // compiler's memory model without an L2 write-back)
             if (!s_one_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int need = (unsigned int)G * phase;
@@ -1762,6 +1781,7 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
 // slot's key table is turned into the int4 form the exporter reads (entry index = root node id)
 int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
     CHECK_H(h);
+    if (!h->ov.counters || !h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
     if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
     const LkOverlay& ov = h->ov;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2052,6 +2072,13 @@ static int rag_reserve(lk_handle* h, size_t bytes) {
     return LK_OK;
 }
 
+// filters[0] before a scan that works on it in place (grid-resident kernel, pipelined launches): check_map_errors restores it on LK_ERR_TIMEOUT
+static int backup_filter(lk_handle* h) {
+    if (!h->d_fbackup) HIPCHK(h, hipMalloc(&h->d_fbackup, sizeof(LkFilter)));
+    HIPCHK(h, hipMemcpyAsync(h->d_fbackup, h->d_filters, sizeof(LkFilter), hipMemcpyDeviceToDevice, h->stream));
+    h->fbackup_valid = true;
+    return LK_OK;
+}
 // The bucket loop of KILO::process for a scan of small buckets as ONE launch (lk_scan_stream_kernel).  bstart[k] / btime[k]: first
 // point and absolute time of bucket k (nb buckets, bstart[nb] = n); the messages are the scan's lk_imu or lk_kin_imu records.
 static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vector<unsigned long long>& bstart, const std::vector<double>& btime,
@@ -2118,6 +2145,7 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     memcpy(stage + o_io, io, 8);
     memcpy(stage + o_sync, zero4, 16);
     HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = backup_filter(h))) return rc;
     unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
     LkRagged rg;
     memset(&rg, 0, sizeof(rg));
@@ -2137,6 +2165,20 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     int G = wg_env > 0 ? wg_env : std::max(8, (tiles + 3) / 4 + 4);   // a wave per tile of the largest bucket and a few more for the per-root passes; every
                                                                       // further workgroup makes each barrier dearer (51 x 1 960 points: 12 workgroups 2.33 ms, 32: 2.43, 128: 2.81)
     G = std::min(G, LK_GRIDSCAN_WG_MAX);                             // 128 workgroups of 4 waves are resident on 256 CUs whatever else is true
+    {   // a partitioned / smaller device (CPX: 32 CUs): never more spinning workgroups than can be resident at once
+        static int resident_max = -1;
+        if (resident_max < 0) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lk_scan_grid_kernel<true>, LK_FB, 0) == hipSuccess && per_cu > 0)
+                resident_max = per_cu * prop.multiProcessorCount;
+            else
+                resident_max = LK_GRIDSCAN_WG_MAX;
+            (void)hipGetLastError();
+        }
+        G = std::max(1, std::min(G, resident_max));
+    }
     // up to one workgroup per CU of an XCD: launch 8 G blocks and let only every eighth work (LEGKILO_GRIDSCAN_XCD=0: all G blocks, any XCD)
     static const bool one_xcd_en = getenv("LEGKILO_GRIDSCAN_XCD") == nullptr || atoi(getenv("LEGKILO_GRIDSCAN_XCD")) != 0;
     const int stride = (one_xcd_en && G <= 32) ? 8 : 1;
@@ -2207,6 +2249,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
             return LK_OK;
         }
     }
+    if (h->spec_enable && (rc = backup_filter(h))) return rc;
     size_t qi = 0, qk = 0;
     size_t idx_i = 0;
     bool pre_predicted = false;
@@ -2298,6 +2341,7 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
             return LK_OK;
         }
     }
+    if (h->spec_enable && (rc = backup_filter(h))) return rc;
     bool pre_predicted = false;
     for (size_t b = 0; b < n_buckets; ++b) {
         int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
@@ -3019,35 +3063,70 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
 static void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
     void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen};
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen, o.sums, o.base_sums, o.cplx};
     for (void* q : ptrs)
         if (q) hipFree(q);
     memset(&o, 0, sizeof(o));
     h->ov_slots = 0;
+    h->ov_pool_bytes = 0;
+    h->ov_last_slots = 0;   // nothing of the last replay is left to export / count (lk_overlay_export, lk_overlay_stats)
 }
-static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap) {
-    // per-scan capacities: a 100 000-point scan touches ~13 000 root voxels of a young map, ~4 700 of the bench's mature one, one live
-    // point block each (measured: extra.overlay_private_per_scan_max); lk_overlay_reserve overrides
-    const uint32_t roots = h->ov_want_roots ? h->ov_want_roots : (uint32_t)std::min<size_t>(std::max<size_t>(8192, n_pts_scan / 6), std::max<size_t>(1024, n_pts_scan));
-    const uint32_t nodes = h->ov_want_nodes ? std::max(h->ov_want_nodes, roots + 64u) : roots + roots / 2;
-    const uint32_t blocks = h->ov_want_blocks ? h->ov_want_blocks : roots;
-    const uint32_t hash_cap = next_pow2(2u * roots);          // the roots' records ARE the table entries: node ids [0, hash_cap)
-    const uint32_t nodes_cap = hash_cap + (nodes - roots);    // children from hash_cap upwards
+// Per-scan capacities.  lk_overlay_reserve's numbers if given; else, when an earlier replay of scans of this size has left its
+// high-water marks, those + 25 % (pools more than twice that are released and re-made: round 4 reserved n_pts / 6 roots = 110 MB per scan,
+// 113 GB for 1 024 scans, where the bench's scans use 4 700 roots); else a first guess of n_pts / 16 roots.  `grow` (bits of the slots' error
+// word: 1 private root table, 2 nodes, 4 point blocks) doubles what overflowed - the replay is then run again (lk_batch_replay_overlay_dev).
+static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap, unsigned int grow = 0) {
+    const bool hist = h->ov_hw_roots > 0 && h->ov_hw_npts == n_pts_scan;
+    uint32_t roots, nodes_extra, blocks;
+    if (h->ov_want_roots) {
+        roots = h->ov_want_roots;
+        nodes_extra = h->ov_want_nodes ? std::max(h->ov_want_nodes, roots + 64u) - roots : roots / 2;
+        blocks = h->ov_want_blocks ? h->ov_want_blocks : roots;
+    } else if (hist) {
+        roots = h->ov_hw_roots + h->ov_hw_roots / 4 + 64;
+        const uint32_t child = h->ov_hw_nodes > h->ov_hw_roots ? h->ov_hw_nodes - h->ov_hw_roots : 0u;
+        nodes_extra = child + child / 4 + 256;
+        blocks = h->ov_hw_blocks + h->ov_hw_blocks / 4 + 64;
+    } else {
+        roots = (uint32_t)std::min<size_t>(std::max<size_t>(2048, n_pts_scan / 16), std::max<size_t>(1024, n_pts_scan));
+        nodes_extra = roots / 2;
+        blocks = roots;
+    }
+    uint32_t hash_cap = next_pow2(roots + roots / 2);       // the roots' records ARE the table entries: node ids [0, hash_cap); load <= 2/3
+    LkOverlay& o = h->ov;
+    if (grow) {   // never below what is there; what overflowed is doubled
+        hash_cap = std::max(hash_cap, o.hash_cap), nodes_extra = std::max(nodes_extra, o.nodes_cap - o.hash_cap), blocks = std::max(blocks, o.blocks_cap);
+        if (grow & LK_E_HASH_FULL) hash_cap *= 2;
+        if (grow & LK_E_NODES_FULL) nodes_extra = nodes_extra * 2 + 256;
+        if (grow & LK_E_BLOCKS_FULL) blocks *= 2;
+    }
+    const uint32_t nodes_cap = hash_cap + nodes_extra;        // children from hash_cap upwards
     const uint32_t scan_cap = (uint32_t)((biggest_bucket + 63) & ~(size_t)63);
     const size_t cells = (size_t)fmap.gdim[0] * (size_t)fmap.gdim[1] * (size_t)fmap.gdim[2];
     const uint32_t bit_words = (uint32_t)((cells + 31) / 32);
-    LkOverlay& o = h->ov;
-    if (S <= h->ov_slots && hash_cap == o.hash_cap && nodes_cap <= o.nodes_cap && blocks <= o.blocks_cap && scan_cap <= o.scan_cap && bit_words <= o.bit_words)
-        return LK_OK;
+    const bool fits = S <= h->ov_slots && hash_cap <= o.hash_cap && nodes_cap - hash_cap <= o.nodes_cap - o.hash_cap && blocks <= o.blocks_cap &&
+                      scan_cap <= o.scan_cap && bit_words <= o.bit_words;
+    // far too large for what the scans use (measured by an earlier replay, or asked for explicitly): released and re-made
+    const bool oversized = (hist || h->ov_want_roots) && !grow && (o.hash_cap > 2 * hash_cap || (size_t)o.blocks_cap > 2 * (size_t)blocks + 1024);
+    if (fits && !oversized) return LK_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint32_t S2 = std::max(S, h->ov_slots);
+    const uint32_t S2 = oversized ? S : std::max(S, h->ov_slots);
     LkOverlay n = {};
-    n.hash_cap = hash_cap, n.nodes_cap = std::max(nodes_cap, hash_cap + (o.nodes_cap > o.hash_cap ? o.nodes_cap - o.hash_cap : 0u));
-    n.blocks_cap = std::max(blocks, o.blocks_cap), n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
+    if (oversized) {
+        n.hash_cap = hash_cap, n.nodes_cap = nodes_cap, n.blocks_cap = blocks, n.scan_cap = scan_cap, n.bit_words = bit_words;
+    } else {
+        n.hash_cap = std::max(hash_cap, o.hash_cap);
+        n.nodes_cap = n.hash_cap + std::max(nodes_extra, o.nodes_cap > o.hash_cap ? o.nodes_cap - o.hash_cap : 0u);
+        n.blocks_cap = std::max(blocks, o.blocks_cap), n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
+    }
     ov_free(h);
     h->ov = n;
     const size_t s = S2;
-    auto get = [&](auto** q, size_t bytes) -> hipError_t { return hipMalloc((void**)q, bytes); };
+    size_t total = 0;
+    auto get = [&](auto** q, size_t bytes) -> hipError_t {
+        total += bytes;
+        return hipMalloc((void**)q, bytes);
+    };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = get(&o.keys, s * n.hash_cap * sizeof(unsigned long long));
     if (e == hipSuccess) e = get(&o.planes, s * n.nodes_cap * sizeof(lk_plane_rec));
@@ -3069,16 +3148,20 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.frozen, (size_t)n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
+    if (e == hipSuccess) e = get(&o.sums, s * n.hash_cap * sizeof(LkLeafSum));
+    if (e == hipSuccess) e = get(&o.base_sums, (size_t)h->map.max_nodes * sizeof(LkLeafSum));
+    if (e == hipSuccess) e = get(&o.cplx, s * n.scan_cap * 2 * sizeof(int));
     if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         ov_free(h);
         char buf[256];
-        snprintf(buf, sizeof(buf), "overlay pools for %u scans (%u roots / %u nodes / %u point blocks each) do not fit: %s (lk_overlay_reserve sets smaller per-scan capacities)",
-                 S2, roots, nodes, n.blocks_cap, hipGetErrorString(e));
+        snprintf(buf, sizeof(buf), "overlay pools for %u scans (%u root entries / %u child nodes / %u point blocks each) do not fit: %s (lk_overlay_reserve sets smaller per-scan capacities)",
+                 S2, n.hash_cap, n.nodes_cap - n.hash_cap, n.blocks_cap, hipGetErrorString(e));
         return fail(h, LK_ERR_CAPACITY, buf);
     }
     h->ov_slots = S2;
+    h->ov_pool_bytes = total;
     hipLaunchKernelGGL(lk_ov_init_kernel, dim3((n.hash_cap + 255) / 256, S2), dim3(256), 0, h->stream, h->ov);
     HIPCHK(h, hipGetLastError());
     return LK_OK;
@@ -3111,7 +3194,9 @@ static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
     r.dirty += s0 * o.hash_cap;
     r.bits += s0 * o.bit_words;
     r.jobs += s0 * o.hash_cap * LK_INLINE_GROUPS;
-    return r;   // frozen, newroot, spec: shared by all slots
+    r.sums += s0 * o.hash_cap;
+    r.cplx += s0 * o.scan_cap * 2;
+    return r;   // frozen, base_sums, newroot, spec: shared by all slots
 }
 extern "C" {
 int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin, const uint32_t* bucket_off,
@@ -3140,6 +3225,17 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (!fmap.grid_on) return fail(h, LK_ERR_STATE, "overlay replay needs the frozen-map grid (root keys' bounding box too large, LEGKILO_GRID=0, or out of device memory)");
     rc = ov_reserve(h, (uint32_t)S, n_pts, biggest, fmap);
     if (rc) return rc;
+    // the batch's priors, kept for a second attempt: a scan whose overlay outgrows pools that were sized by this library (first guess, or
+    // the previous replay's high-water marks) makes the pools grow and the whole batch run again - only capacities the caller has set
+    // explicitly (lk_overlay_reserve) fail with LK_ERR_CAPACITY
+    if (h->ov_priors_cap < (size_t)S) {
+        if (h->d_ov_priors) hipFree(h->d_ov_priors), h->d_ov_priors = nullptr, h->ov_priors_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ov_priors, sizeof(LkFilter) * (size_t)S));
+        h->ov_priors_cap = (size_t)S;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_ov_priors, h->d_filters, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, h->stream));
+    unsigned int stt[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int attempt = 0;; ++attempt) {
     const LkOverlay ov = h->ov;
     hipStream_t st = h->stream;
     rc = zero_scan_counters(h, 0, (uint32_t)S);
@@ -3150,8 +3246,15 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
-    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // without the fit: 184 VGPRs at 2 waves, 168 at 3
-    const auto root_kernel = root_waves >= 4 ? lk_ov_insert_root_kernel<4> : root_waves == 3 ? lk_ov_insert_root_kernel<3> : lk_ov_insert_root_kernel<2>;
+    // root pass: the fast path (lk_ov_root_fast_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
+    // (LEGKILO_OV_FAST=0: the generic pass over every touched root, round 4's path; A/B)
+    static const bool ov_fast = getenv("LEGKILO_OV_FAST") == nullptr || atoi(getenv("LEGKILO_OV_FAST")) != 0;
+    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // generic pass without the fit: 184 VGPRs at 2 waves, 168 at 3
+    const auto root_kernel = ov_fast ? (root_waves >= 4 ? lk_ov_insert_root_kernel<4, true> : root_waves == 3 ? lk_ov_insert_root_kernel<3, true> : lk_ov_insert_root_kernel<2, true>)
+                                     : (root_waves >= 4 ? lk_ov_insert_root_kernel<4, false> : root_waves == 3 ? lk_ov_insert_root_kernel<3, false> : lk_ov_insert_root_kernel<2, false>);
+    static const int fast_waves = getenv("LEGKILO_OV_FAST_WAVES") ? atoi(getenv("LEGKILO_OV_FAST_WAVES")) : 4;
+    const auto fast_kernel = fast_waves >= 5 ? lk_ov_root_fast_kernel<5> : fast_waves == 4 ? lk_ov_root_fast_kernel<4> : lk_ov_root_fast_kernel<3>;
+    if (ov_fast) LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
     static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
     static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
@@ -3170,6 +3273,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         for (int g = 1; g < ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(streams[g], h->ev_fork, 0));
     }
     const LkOverlay ov_all = ov;
+    // the enqueue of every group's launches; whatever it returns, the side streams are joined below before this call returns (a failed
+    // launch must not leave them writing filters, partials and pools behind the caller's back)
+    auto enqueue_all = [&]() -> int {
     for (int grp = 0; grp < ngroups; ++grp) {
         const int s0 = (int)((long)S * grp / ngroups), sn = (int)((long)S * (grp + 1) / ngroups) - s0;
         const unsigned int per = std::max(std::max(ov_all.hash_cap, ov_all.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
@@ -3200,7 +3306,12 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
         LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        if (ov_fast) {
+            LAUNCH(h, "ov_root_fast", hipLaunchKernelGGL(fast_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl));
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        } else {
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        }
         LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
@@ -3209,17 +3320,37 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
                                                     t_begin + bucket_dt[live[k + 1]], 2));
     }
     HIPCHK(h, hipGetLastError());
+    return LK_OK;
+    };
+    rc = enqueue_all();
     for (int g = 1; g < ngroups; ++g) {  // join: everything after this point on h->stream sees every group's results
+        if (rc) {
+            (void)hipStreamSynchronize(streams[g]);   // error path: nothing of this call keeps running
+            continue;
+        }
         HIPCHK(h, hipEventRecord(h->ev_join[g - 1], streams[g]));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[g - 1], 0));
     }
+    if (rc) {
+        (void)hipStreamSynchronize(h->stream);
+        return rc;
+    }
     h->ov_last_slots = (uint32_t)S;
     const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
-    unsigned int stt[8];
     HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const bool growable = !h->ov_want_roots && !(stt[0] & ~(LK_E_HASH_FULL | LK_E_NODES_FULL | LK_E_BLOCKS_FULL)) && attempt < 4;
+    if (!stt[0] || !growable) break;
+    HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_ov_priors, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
+    rc = ov_reserve(h, (uint32_t)S, n_pts, biggest, fmap, stt[0]);
+    if (rc) return rc;
+    }   // attempts
+    const LkOverlay& ov = h->ov;
+    hipStream_t st = h->stream;
+    if (!stt[0]) h->ov_hw_roots = stt[3], h->ov_hw_nodes = stt[1], h->ov_hw_blocks = stt[2], h->ov_hw_npts = n_pts;
     if (out) {
         std::vector<lk_pose> tmp(n_scans);
         rc = fetch_poses(h, tmp.data(), S);   // synchronises
@@ -3230,8 +3361,8 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     }
     if (stt[0]) {
         char buf[256];
-        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots of %u / %u / %u per scan (lk_overlay_reserve)",
-                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.nodes_cap - ov.hash_cap / 2, ov.blocks_cap, ov.hash_cap / 2);
+        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots; per-scan pools: %u root entries, %u child nodes, %u blocks (lk_overlay_reserve)",
+                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.hash_cap, ov.nodes_cap - ov.hash_cap, ov.blocks_cap);
         return fail(h, LK_ERR_CAPACITY, buf);
     }
     return LK_OK;
@@ -3239,7 +3370,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
 
 int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks) {
     CHECK_H(h);
-    if (!h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay has run on this handle");
+    if (!h->ov_last_slots || !h->ov.counters) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
     const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
     unsigned int stt[8];
     HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
@@ -3250,6 +3381,15 @@ int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uin
     if (max_nodes) *max_nodes = stt[1];
     if (max_blocks) *max_blocks = stt[2];
     if (max_roots) *max_roots = stt[3];
+    return LK_OK;
+}
+
+int lk_overlay_pool_bytes(lk_handle* h, uint64_t* bytes, uint32_t* root_entries, uint32_t* child_nodes, uint32_t* blocks) {
+    CHECK_H(h);
+    if (bytes) *bytes = (uint64_t)h->ov_pool_bytes;
+    if (root_entries) *root_entries = h->ov.hash_cap;
+    if (child_nodes) *child_nodes = h->ov.nodes_cap - h->ov.hash_cap;
+    if (blocks) *blocks = h->ov.blocks_cap;
     return LK_OK;
 }
 

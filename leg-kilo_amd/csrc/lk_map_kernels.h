@@ -1029,12 +1029,16 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 // block in one go (light roots and roots that are one in-place leaf group: nearly all); any other path copies them first.
 #define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 0 not in the slot's map yet, 1 complete, 2 thin
 #define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin private root: 1 + id of the BASE map's point block that holds its old points
-template <bool FROM_PV, bool OV = false>
+// CPLX (overlay replay): the work list is not the touched list but what the fast root pass (lk_ov_root_fast_kernel) has left over -
+// map.heavy = {root, index in the touched list} pairs, counter LK_CTR_HEAVY; the fit jobs stay indexed by the touched-list position.
+template <bool FROM_PV, bool OV = false, bool CPLX = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                                                 const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr,
                                                 LkFitJob* jobs = nullptr, const size_t job_stride = 0) {
     const int lane = threadIdx.x & 63;
-    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    const int n_touched = CPLX ? (int)min(map.counters[LK_CTR_HEAVY], map.max_scan) : (int)map.counters[LK_CTR_TOUCHED];
+    if (CPLX && n_touched == 0) return;
+    auto item_root = [&](int i) { return CPLX ? map.heavy[2 * i] : map.touched[i]; };
     LkGroup* groups = reinterpret_cast<LkGroup*>(map.groups);
     BucketConst bc;
     if (!FROM_PV) load_bucket_const(&filters[0], pr, bc);
@@ -1063,8 +1067,8 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         }
     };
     if (OV) {
-        pf_root1 = wave < n_touched ? bcast0(map.touched[wave]) : -1;
-        pf_root2 = wave + nwaves < n_touched ? bcast0(map.touched[wave + nwaves]) : -1;
+        pf_root1 = wave < n_touched ? bcast0(item_root(wave)) : -1;
+        pf_root2 = wave + nwaves < n_touched ? bcast0(item_root(wave + nwaves)) : -1;
         prefetch_record(pf_root1);
     }
     for (int t = wave; t < n_touched; t += nwaves) {
@@ -1088,10 +1092,11 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             slot_idx = pf_slot;
             pf_root1 = pf_root2;
             prefetch_record(pf_root1);
-            pf_root2 = t + 2 * nwaves < n_touched ? bcast0(map.touched[t + 2 * nwaves]) : -1;
+            pf_root2 = t + 2 * nwaves < n_touched ? bcast0(item_root(t + 2 * nwaves)) : -1;
         } else {
             root = bcast0(map.touched[t]);
         }
+        const int tix = CPLX ? bcast0(map.heavy[2 * t + 1]) : t;   // the root's position in the touched list = its row of fit jobs
         lk_node_rec* nd = &map.nodes[root];
         if (!OV) {
             // one batch of loads: the root's record, its plane flags, its slot line
@@ -1104,7 +1109,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         const lk_pt_rec* cow_src = nullptr;
         // this root's fit jobs (apply_leaf<DEFER>): none yet.  Entry [g][t] = its g-th inline leaf group: nearly every root is ONE group, so
         // plane 0 is dense for lk_ov_fit_lane_kernel's lanes (job_stride = entries per plane)
-        if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + t].cnt = 0;
+        if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + tix].cnt = 0;
         int job_i = 0;
         if (OV) {
             const unsigned int live = (unsigned int)ov_live;
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                     if (lane < g) map.gidx[gb + lane] = cidx;
                 };
                 const bool cow_done = apply_leaf<OV>(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx, OV ? cow_src : nullptr,
-                                                     OV ? &jobs[(size_t)job_i * job_stride + t] : nullptr);
+                                                     OV ? &jobs[(size_t)job_i * job_stride + tix] : nullptr);
                 ++job_i;
                 if (OV && cow_src) {
                     if (cow_done) cow_src = nullptr;

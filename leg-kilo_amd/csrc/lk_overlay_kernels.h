@@ -35,6 +35,15 @@
 #define LK_PAD_BASE 4     // lk_node_rec::pad_[4] of a private root record that does not exist yet: 1 + id of the base map's voxel of that key (0: none)
 #define LK_OV_EMPTY 0x8000000000000000ull   // empty entry of a slot's key table (a packed key never has bit 63 set)
 
+// Moment sums of the FIRST n points of a leaf's block (sum p, sum p p^T: what every refit event's plane test is made from,
+// voxel_map.cc:46-53).  A leaf's points are append-only until it freezes or is cut, so a prefix stays valid whoever appends; the fast
+// root pass keeps it up to date at every refit event (whose sums it has computed anyway) and only reads the points behind the prefix.
+struct LkLeafSum {   // 80 B = 5 x 16 B
+    double s9[9];
+    int n, pad_;
+};
+static_assert(sizeof(LkLeafSum) == 80, "leaf sums record must be 80 B");
+
 // The overlay pools of all slots, passed by value.  Slot s owns element range [s * cap, (s + 1) * cap) of every array.
 // Private root table of a slot: open addressing over PACKED 64-bit keys (3 x 21 bits), and the root's node id IS its table index -
 // node records [0, hash_cap) of the slot are its roots, children are allocated from hash_cap upwards.  A key is claimed with ONE
@@ -62,6 +71,9 @@ struct LkOverlay {
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
     unsigned int* frozen;        // [bit_words], shared by all slots: bit c = the BASE map's voxel at grid cell c is a frozen leaf (lk_ov_frozen_bits_kernel)
     struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
+    struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_fast_kernel)
+    struct LkLeafSum* base_sums; // [base max_nodes], shared: the same for the BASE map's root leaves, once per replay (lk_ov_base_sums_kernel)
+    int* cplx;                   // [S][2 * scan_cap]: {root, index in the touched list} of the roots the fast root pass leaves to the generic one
     unsigned int hash_cap, nodes_cap, blocks_cap, scan_cap, bit_words;
 };
 
@@ -75,7 +87,7 @@ __host__ __device__ inline LkMap ov_slot_map(const LkOverlay& ov, unsigned int s
     m.blocks = ov.blocks + s * ov.blocks_cap;
     m.counters = ov.counters + s * LK_CTR_COUNT;
     m.touched = ov.touched + s * ov.scan_cap;
-    m.heavy = nullptr;
+    m.heavy = ov.cplx + s * ov.scan_cap * 2;   // the fast root pass's hand-over list (counter LK_CTR_HEAVY)
     m.next = ov.next + s * ov.scan_cap;
     m.slots = ov.slots + s * ov.hash_cap * LK_SLOTS * 4;   // 16-B entries (dev_insert_root<.., OV> reads them as float4)
     m.scratch = ov.scratch + s * ov.scan_cap;
@@ -423,7 +435,10 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
         const bool childless = rec[0].x < 0 && rec[0].y < 0 && rec[0].z < 0 && rec[0].w < 0 && rec[1].x < 0 && rec[1].y < 0 && rec[1].z < 0 && rec[1].w < 0;
         const bool thin = has_base && childless;
         // one bump of the block counter serves the whole chunk (a returning device-scope atomic is a ~2 us round trip)
-        const unsigned long long blk_mask = __ballot(need && s_block >= 0);
+        // (a root the base map has no voxel for gets its block here too: it was created because a point is waiting for it, and a returning
+        // atomic in the root pass is a 2-us round trip on that root's chain)
+        const bool want_block = need && (s_block >= 0 || my_base == 0);
+        const unsigned long long blk_mask = __ballot(want_block);
         int blk_base = 0;
         if (blk_mask) {
             const int total = __popcll(blk_mask);
@@ -437,7 +452,7 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             }
             blk_base = bcast0(blk_base);
         }
-        const int my_block = (need && s_block >= 0) ? blk_base + __popcll(blk_mask & ((1ull << lane) - 1ull)) : -1;
+        const int my_block = want_block ? blk_base + __popcll(blk_mask & ((1ull << lane) - 1ull)) : -1;
         int key[3] = {0, 0, 0};
         if (need) ov_unpack_key(my_key, key);
         // roots the base map has no voxel for: an empty root voxel each, written by the root's own lane
@@ -449,9 +464,21 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 #pragma unroll
             for (int c = 0; c < 3; ++c) nd->voxel_center[c] = (0.5 + key[c]) * vs, nd->key[c] = key[c];  // voxel_map.cc:355-357
             nd->quater_length = pr.voxel_size_f / 4;                                                        // voxel_map.cc:354
-            nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = LK_NODE_UPDATE_ENABLE, nd->block = -1;
+            nd->layer = 0, nd->npts = 0, nd->new_points = 0, nd->state = LK_NODE_UPDATE_ENABLE, nd->block = my_block;
             pm.planes[my_root].flags = 0;
             pm.match[my_root].flags = 0;
+        }
+        // the root's moment-sum prefix (lk_ov_root_fast_kernel): the base leaf's (made once per replay) for a childless base voxel, none otherwise
+        if (need) {
+            LkLeafSum* sr = &ov.sums[(size_t)slot * ov.hash_cap + my_root];
+            if (has_base && childless) {
+                const int4* bs = reinterpret_cast<const int4*>(&ov.base_sums[my_base - 1]);
+                int4* ds = reinterpret_cast<int4*>(sr);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) ds[c] = bs[c];
+            } else {
+                sr->n = 0;
+            }
         }
         // childless base voxels: the node record by the root's own lane (the queue fields list_head / pad_[] are the re-projection pass's) ...
         const bool pending = thin && s_block >= 0 && s_npts > 0;
@@ -610,15 +637,280 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
     }
 }
 
+
+// ---------------------------------------------------------------- the root pass of the batch replay, FAST PATH (round 5)
+// Nearly every touched root of a batch bucket is a leaf that takes its few new points (in input order), maybe passes a refit event or
+// two, maybe freezes.  The generic pass (dev_insert_root<.., OV>) spends its time - 168 VGPRs, three waves per SIMD, 5.5 GB per launch -
+// on what that case does not need: every old point of the leaf re-read (9 doubles at a 72-B stride per lane: 36 cache lines per load
+// instruction for 512 B) and, for a voxel seen for the first time, written back the same way; the per-lane walk, the grouping, the
+// hand-over lists.  This pass does the common case only and leaves everything else UNTOUCHED on a list for the generic pass
+// (map.heavy / LK_CTR_HEAVY -> lk_ov_insert_root_kernel<.., CPLX>):
+//   * the leaf's moment sums are kept per root (LkLeafSum: sums of its first n points, updated at every refit event; for a base voxel
+//     computed once per replay, lk_ov_base_sums_kernel, and copied with the record).  A refit event's plane test needs
+//     prefix + the points behind it - a handful, usually only the new ones.  The old points are not read at all;
+//   * a voxel seen for the first time ("thin": its old points still in the base map's block) gets them as a FLAT copy of n0 x 72 bytes in
+//     16-B pieces, coalesced, independent of everything else the wave does;
+//   * per root: record + plane flags + slot line + sums requested one root ahead (the same pipeline as the generic pass); the simulation
+//     of voxel_map.cc:186-204 is side-effect free, so a root that turns out to need the generic code (a cut: init_octo_tree says "not a
+//     plane"; a plane that stops being one; more than a slot line of points; a tree below the root) is handed over as it was found.
+// The fit that ends a leaf's bucket is left to lk_ov_fit_lane_kernel as before (96-B job).
+__device__ __forceinline__ bool ov_plane_decide(const double* s, int count, float planer_threshold) {   // plane_test_regs<decide_only>: lambda_min < t
+    const double n = (double)count;
+    const double c0 = s[0] / n, c1 = s[1] / n, c2 = s[2] / n;
+    const double t = (double)planer_threshold;
+    const double b11 = (s[3] / n - c0 * c0) - t, bxy = s[4] / n - c0 * c1, bxz = s[5] / n - c0 * c2;
+    const double b22 = (s[6] / n - c1 * c1) - t, byz = s[7] / n - c1 * c2, b33 = (s[8] / n - c2 * c2) - t;
+    const double m2 = b11 * b22 - bxy * bxy;
+    const double m3 = b11 * (b22 * b33 - byz * byz) - bxy * (bxy * b33 - byz * bxz) + bxz * (bxy * byz - b22 * bxz);
+    return !(b11 > 0.0 && m2 > 0.0 && m3 > 0.0);
+}
+#ifndef LK_FAST_X
+#define LK_FAST_X 0   // attribution builds only (results wrong): 1 no point covariance, 2 no wave sums
+#endif
+template <int W>
+__global__ void __launch_bounds__(LK_MB, W)
+    lk_ov_root_fast_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters) {
+    const unsigned int slot = blockIdx.y;
+    const LkMap map = ov_slot_map(ov, slot);
+    if (map.counters[LK_CTR_ERR]) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * LK_MB) >> 6);
+    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
+    const size_t job_stride = ov.hash_cap;
+    LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
+    BucketConst bc;
+    load_bucket_const(&filters[slot], pr, bc);
+    // requested ahead (lane k: 16-B piece k of the node record / of the sums record, point k of the slot line)
+    int pf_root1 = -1, pf_root2 = -1, pf_flags = 0, pf_slot = 0x7fffffff;
+    float pf_px = 0.f, pf_py = 0.f, pf_pz = 0.f;
+    int4 pf_rec = make_int4(0, 0, 0, 0), pf_sum = make_int4(0, 0, 0, 0);
+    auto prefetch_record = [&](int r) {
+        if (r >= 0) {
+            if (lane < 8) pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane];
+            if (lane < 5) pf_sum = reinterpret_cast<const int4*>(&sums[r])[lane];
+            pf_flags = (int)map.planes[r].flags;
+            pf_slot = 0x7fffffff;
+            if (lane < LK_SLOTS) {
+                const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)r * LK_SLOTS + lane];
+                pf_px = q.x, pf_py = q.y, pf_pz = q.z, pf_slot = __float_as_int(q.w);
+            }
+        }
+    };
+    pf_root1 = wave < n_touched ? bcast0(map.touched[wave]) : -1;
+    pf_root2 = wave + nwaves < n_touched ? bcast0(map.touched[wave + nwaves]) : -1;
+    prefetch_record(pf_root1);
+    for (int t = wave; t < n_touched; t += nwaves) {
+        const float cpx = pf_px, cpy = pf_py, cpz = pf_pz;
+        const int slot_idx = pf_slot;
+        const int4 rec = pf_rec, sumv = pf_sum;
+        const int root = pf_root1;
+        const unsigned int rpf = (unsigned int)bcast0(pf_flags);
+        pf_root1 = pf_root2;
+        prefetch_record(pf_root1);
+        pf_root2 = t + 2 * nwaves < n_touched ? bcast0(map.touched[t + 2 * nwaves]) : -1;
+        const int rlayer = __builtin_amdgcn_readlane(rec.w, 3);
+        const int n0 = __builtin_amdgcn_readlane(rec.x, 4), rnewp = __builtin_amdgcn_readlane(rec.y, 4);
+        const unsigned int rst = (unsigned int)__builtin_amdgcn_readlane(rec.z, 4);
+        int rblock = __builtin_amdgcn_readlane(rec.w, 4);
+        const int m = __builtin_amdgcn_readlane(rec.x, 6);                      // pad_[0]: points queued in this bucket
+        const int ov_live = __builtin_amdgcn_readlane(rec.w, 6);               // pad_[LK_PAD_LIVE]
+        const int cow_blk = __builtin_amdgcn_readlane(rec.y, 7) - 1;           // pad_[LK_PAD_COWBLK] - 1
+        int sum_n = __builtin_amdgcn_readlane(sumv.z, 4);
+        const bool thin = ov_live == 2 && cow_blk >= 0;
+        const bool uninit = !(rst & LK_NODE_INIT_OCTO), lplane = (rpf & LK_PLANE_IS_PLANE) != 0, live = (rst & LK_NODE_UPDATE_ENABLE) != 0;
+        // ---- is this the common case?  (everything here is uniform over the wave)
+        bool complex_root = m > LK_SLOTS || m <= 0 || !(uninit || (lplane && live)) || (rst & LK_NODE_PTS_DROPPED) != 0 || n0 + 1 >= LK_BLOCK_PTS || rlayer != 0 ||
+                            (ov_live == 2 && cow_blk < 0 && n0 > 0) || rblock < 0;   // (the copy-on-write pass gives every root it creates a block)
+        if (sum_n < 0 || sum_n > n0) sum_n = 0;
+        const int thr = pr.layer_init_num[0];
+        const bool may_refit = uninit ? (n0 + m > thr) : (rnewp + m > 5);
+        const int U = may_refit ? n0 - sum_n : 0;     // old points behind the sums' prefix: read (pw only) when a refit event may need them
+        if (U + m > LK_WAVE) complex_root = true;
+        int cur = n0, newp = rnewp, consumed = 0, fit_count = 0;
+        bool frozen = false, fitted = false;
+        double ppw[3] = {0.0, 0.0, 0.0};
+        double sev[9];    // moment sums of the last refit event (uniform)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sev[q] = 0.0;
+        if (!complex_root) {
+            // the queued points in input order (= ascending index): rank among the m, then a forward permute - lanes 0 .. m-1 hold the new
+            // points in order, lanes m .. m+U-1 the old points behind the prefix
+            const int myidx = (lane < m) ? slot_idx : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
+            const int dstl = ((lane < m) ? rank : lane) << 2;
+            float4 p4;
+            p4.x = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpx)));
+            p4.y = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpy)));
+            p4.z = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpz)));
+            // ---- stores that do no harm if the root turns out to need the generic pass after all (it writes the same bytes again):
+            // the old points of a voxel seen for the first time, as a FLAT copy of 72 n0 bytes in 16-B pieces (+ one 8-B tail when n0 is
+            // odd); the new points behind them, each by its lane (a freeze ignores the ones past it: they lie beyond npts)
+            lk_pt_rec* dstp = map.blocks[rblock].pts;
+            if (thin && n0 > 0) {
+                const int n16 = (n0 * 72) >> 4;
+                const uint4* sp = reinterpret_cast<const uint4*>(base.blocks[cow_blk].pts);
+                uint4* dp = reinterpret_cast<uint4*>(dstp);
+                for (int j0 = 0; j0 < n16; j0 += 2 * LK_WAVE) {
+                    const int ja = j0 + lane, jb = j0 + LK_WAVE + lane;
+                    uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
+                    if (ja < n16) va = sp[ja];
+                    if (jb < n16) vb = sp[jb];
+                    if (ja < n16) dp[ja] = va;
+                    if (jb < n16) dp[jb] = vb;
+                }
+                if ((n0 & 1) && lane == 0) reinterpret_cast<double*>(dstp)[n0 * 9 - 1] = reinterpret_cast<const double*>(base.blocks[cow_blk].pts)[n0 * 9 - 1];
+            }
+            if (lane < m && n0 + lane < LK_BLOCK_PTS) {
+                // point_geom's expressions (KILO.cc:126-140), evaluated in three phases with the results stored as they come - the
+                // full inline form keeps ~80 registers alive at once and cost this pass its fourth wave per SIMD
+                lk_pt_rec* d = &dstp[n0 + lane];
+                const V3 pb = V3{(double)p4.x, (double)p4.y, (double)p4.z};
+                const V3 e = mat3_mul_v(pr.ext_R, pb);
+                const V3 p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
+                {
+                    const V3 w = mat3_mul_v(bc.R, p_i);
+                    ppw[0] = w.x + bc.p[0], ppw[1] = w.y + bc.p[1], ppw[2] = w.z + bc.p[2];
+                    d->pw[0] = ppw[0], d->pw[1] = ppw[1], d->pw[2] = ppw[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                S3 va = congruence(bc.RE, calc_body_cov(pb, pr));
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    double K[9], RK[9];
+                    skew3(p_i, K);
+                    mat3_mul(bc.R, K, RK);
+                    const S3 vb = congruence(RK, bc.Prr);
+                    va = S3{va.xx + vb.xx + bc.Ppp.xx, va.xy + vb.xy + bc.Ppp.xy, va.xz + vb.xz + bc.Ppp.xz,
+                            va.yy + vb.yy + bc.Ppp.yy, va.yz + vb.yz + bc.Ppp.yz, va.zz + vb.zz + bc.Ppp.zz};
+                }
+                d->var[0] = va.xx, d->var[1] = va.xy, d->var[2] = va.xz, d->var[3] = va.yy, d->var[4] = va.yz, d->var[5] = va.zz;
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (lane >= m && lane < m + U) {
+                const lk_pt_rec* q = (thin ? base.blocks[cow_blk].pts : map.blocks[rblock].pts) + (sum_n + (lane - m));
+                ppw[0] = q->pw[0], ppw[1] = q->pw[1], ppw[2] = q->pw[2];
+            }
+            // ---- the register simulation of voxel_map.cc:186-204 for a root leaf (apply_leaf's loop, modes 0 and 1 only): every refit event
+            // must say "plane", anything else belongs to the generic pass
+            int mode = uninit ? 0 : 1;
+            while (consumed < m && !frozen && !complex_root) {
+                const int rem = m - consumed;
+                const int m0 = mode;
+                const int lim = m0 == 0 ? thr + 1 - cur : min(6 - newp, pr.max_points_num - cur);
+                const int k = max(min(rem, lim), 1);
+                cur += k, newp += k, consumed += k;
+                if (m0 == 0 ? cur > thr : newp > 5) {
+                    const bool act = lane < cur - n0 || (lane >= m && lane < m + U);
+                    double sq[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sq[q] = 0.0;
+                    if (act) {
+                        sq[0] = ppw[0], sq[1] = ppw[1], sq[2] = ppw[2];
+                        sq[3] = ppw[0] * ppw[0], sq[4] = ppw[0] * ppw[1], sq[5] = ppw[0] * ppw[2];
+                        sq[6] = ppw[1] * ppw[1], sq[7] = ppw[1] * ppw[2], sq[8] = ppw[2] * ppw[2];
+                    }
+                    if (sum_n > 0) {   // the prefix: lane k of the request holds doubles 2k, 2k+1 of the record and adds them to its own partial sums
+#pragma unroll
+                        for (int q = 0; q < 9; ++q)
+                            if (lane == (q >> 1)) sq[q] += (q & 1) ? __hiloint2double(sumv.w, sumv.z) : __hiloint2double(sumv.y, sumv.x);
+                    }
+#if !(LK_FAST_X & 2)
+                    wave_sum_n<9>(sq);
+#endif
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sev[q] = sq[q];
+                    if (!ov_plane_decide(sev, cur, pr.planer_threshold)) {
+                        complex_root = true;   // a cut (init_octo_tree on a non-plane) or a plane that stops being one: generic code
+                        break;
+                    }
+                    fit_count = cur, fitted = true, newp = 0;
+                    if (m0 == 0) {
+                        mode = 1;
+                        if (cur > pr.max_points_num) frozen = true;
+                    }
+                }
+                if (m0 == 1 && cur >= pr.max_points_num) frozen = true;
+            }
+        }
+        if (complex_root) {   // its record, queue and sums untouched: the generic pass finds the root as the re-projection and copy-on-write passes left it
+            if (lane == 0) {
+                const unsigned int c = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
+                if (c < map.max_scan) map.heavy[2 * c] = root, map.heavy[2 * c + 1] = t;
+                else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+            }
+            continue;
+        }
+        // ---- commit: counters, state, queue words, the fit job, the sums
+        unsigned int nst = rst;
+        int nnpts = cur, nblock = rblock;
+        if (fitted) nst = (nst | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
+        if (frozen) {   // node_freeze: update_enable_ = false, temp_points_ swapped away, new_points_ = 0 (voxel_map.cc:199-203)
+            nst &= ~LK_NODE_UPDATE_ENABLE;
+            nnpts = 0, newp = 0, nblock = -1;
+            if (lane == 0) retire_block(map, rblock);   // not handed out again before the next bucket: the fit below still reads it
+        }
+        // the record: lanes 4, 5, 6 store their own 16-B piece (counters | key + list head | queue words)
+        {
+            int4 o = rec;
+            if (lane == 4) o = make_int4(nnpts, newp, (int)nst, nblock);
+            else if (lane == 5) o.w = -1;                 // list_head
+            else if (lane == 6) o.x = 0, o.w = 1;         // pad_[0] = 0: queue consumed; pad_[LK_PAD_LIVE] = 1: complete
+            if (lane >= 4 && lane <= 6) reinterpret_cast<int4*>(&map.nodes[root])[lane] = o;
+        }
+        // fit jobs of this root's row: [0] = this leaf's fit (if an event happened), [1 ..] none
+        if (lane < LK_INLINE_GROUPS) {
+            LkFitJob* jb = &jobs[(size_t)lane * job_stride + t];
+            if (lane == 0 && fitted) {
+                jb->leaf = root, jb->block = rblock, jb->decided = 1, jb->cnt = fit_count;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) jb->s9[q] = sev[q];
+            } else {
+                jb->cnt = 0;
+            }
+        }
+        if (fitted && lane == 0) {   // the sums now cover the first fit_count points
+            LkLeafSum* sr = &sums[root];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) sr->s9[q] = sev[q];
+            sr->n = fit_count;
+        }
+    }
+}
+
+// moment sums of the BASE map's root leaves that can still take points, once per replay: one thread per entry of the root table
+__global__ void __launch_bounds__(256) lk_ov_base_sums_kernel(LkMap base, unsigned int n_hash, LkLeafSum* __restrict__ out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hash) return;
+    const int4 e = base.hash[i];
+    if (e.w < 0) return;
+    const lk_node_rec* nd = &base.nodes[e.w];
+    LkLeafSum r;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) r.s9[q] = 0.0;
+    r.n = 0, r.pad_ = 0;
+    const int npts = nd->npts, block = nd->block;
+    if (block >= 0 && npts > 0 && npts <= LK_BLOCK_PTS && !(nd->state & LK_NODE_PTS_DROPPED) && (nd->state & LK_NODE_UPDATE_ENABLE)) {
+        const lk_pt_rec* p = base.blocks[block].pts;
+        for (int j = 0; j < npts; ++j) {
+            const double x = p[j].pw[0], y = p[j].pw[1], z = p[j].pw[2];
+            r.s9[0] += x, r.s9[1] += y, r.s9[2] += z;
+            r.s9[3] += x * x, r.s9[4] += x * y, r.s9[5] += x * z, r.s9[6] += y * y, r.s9[7] += y * z, r.s9[8] += z * z;
+        }
+        r.n = npts;
+    }
+    out[e.w] = r;
+}
+
 // ---------------------------------------------------------------- the ordered insert, slot = blockIdx.y
 // W = waves per SIMD the register allocation aims at (2: the stream path's 216 VGPRs; 3: <= 168): this launch is a throughput pass over
 // ~10^6 roots, each a chain of dependent round trips - concurrency, not the single wave's speed, sets its duration
-template <int W>
+template <int W, bool CPLX>
 __global__ void __launch_bounds__(LK_MB, W)
     lk_ov_insert_root_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    dev_insert_root<false, true>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
+    dev_insert_root<false, true, CPLX>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
                                  (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base,
                                  ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
 }

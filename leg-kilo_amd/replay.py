@@ -5,6 +5,7 @@ The path has no exchange step inside it: scans are independent re
 shared, frozen voxel map.  Communication is therefore exactly
   (1) once per map snapshot: the map blob from the rank that built it to every other rank;
   (2) once per batch: an all-gather of the per-scan results (a few hundred bytes per scan).
+The same holds for the replay WITH the map insert (replay_batch_overlay): every scan's copy-on-write overlay is private to it.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring broadcast is bound by ONE link, so for a
 large blob `scatter_allgather` sends a distinct 1/W slice to every peer (all links of the root carry
 different data) and then all-gathers the slices.
@@ -167,3 +168,39 @@ def replay_recorded_run(engine, dist, rank, world, device, scans, t_begins, xs, 
         rows.append(pose_rows(poses))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 18))
     return gather_results(dist, local, world, device) if world > 1 else local
+
+
+def replay_batch_overlay(engine, dist, rank, world, device, scans, bucket_off, bucket_dt, xs, Ps, max_batch, t_begin=0.0, want_states=False):
+    """Config 5 WITH the map insert, sharded: scans i in [0, n) - equally shaped (same size, same bucket table: lk_batch_replay_overlay_dev)
+    - are block-partitioned over the ranks; every rank replays its block in batches of at most `max_batch` scans (= the engine's filter
+    slots), each scan on its own copy-on-write overlay of the engine's (already distributed) map (KILO.cc:216-233 after every bucket);
+    the per-scan result rows (pose_rows) are all-gathered in scan order.  An overlay is private to its scan, so there is no collective
+    on the data path: exactly the frozen-map replay's communication (map blob once, results once).
+    `scans` is the full list of lk_point arrays on every rank (only the rank's block is uploaded) or, on a GPU, a (device pointer,
+    n_pts) pair addressing the RANK'S OWN block, already resident.  `xs` / `Ps` are the priors of ALL scans ([n, 36] / [n, 900]).
+    want_states: also return the all-gathered (x [n, 36], P [n, 900]) records (every rank's block must then be equally long)."""
+    n = len(xs)
+    start, stop = shard_range(n, rank, world)
+    resident = isinstance(scans, tuple)
+    n_pts = scans[1] if resident else len(scans[0])
+    rows, xl, Pl = [], [], []
+    for a in range(start, stop, max_batch):
+        b = min(a + max_batch, stop)
+        engine.batch_set_priors(np.ascontiguousarray(xs[a:b]), np.ascontiguousarray(Ps[a:b]))
+        if resident:
+            poses = engine.batch_replay_overlay_dev(scans[0] + (a - start) * n_pts * 16, b - a, n_pts, t_begin, bucket_off, bucket_dt)
+        else:
+            poses = engine.batch_replay_overlay(scans[a:b], t_begin, bucket_off, bucket_dt)
+        rows.append(pose_rows(poses))
+        if want_states:
+            x_, P_ = engine.batch_get_states(0, b - a)
+            xl.append(np.asarray(x_).reshape(b - a, 36)), Pl.append(np.asarray(P_).reshape(b - a, 900))
+    local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 18))
+    out = gather_results(dist, local, world, device) if world > 1 else local
+    if not want_states:
+        return out
+    xa = np.concatenate(xl, axis=0) if xl else np.zeros((0, 36))
+    Pa = np.concatenate(Pl, axis=0) if Pl else np.zeros((0, 900))
+    if world > 1:
+        xa, Pa = gather_results(dist, xa, world, device), gather_results(dist, Pa, world, device)
+    return out, xa, Pa

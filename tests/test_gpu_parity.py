@@ -509,9 +509,10 @@ def test_config3_full_size(big):
         assert np.allclose(xo, xg, rtol=1e-6, atol=1e-7)
         # size-independent property: re-projected world points = R (E p + T) + pos of the bucket's posterior
         assert np.isfinite(wg).all()
-    so = scenes.canon_map(o.map_export())
-    sg = scenes.canon_map(g.map_export())
-    assert set(so) == set(sg)
+    # the whole map at full size: tree shape, counters and state bits exactly, planes and stored points to tolerance - the insert's
+    # apply / fallback / long-list paths all run at this size (voxel_map.cc:185-241)
+    st = scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+    assert st["roots"] > 10000, st
 
 
 def test_config3_51_buckets_full_size(big):
@@ -537,7 +538,8 @@ def test_config3_51_buckets_full_size(big):
         xg, _ = g.get_state()
         # every block of the state - rotation, position, velocity, biases, gravity, IMU states, kinematic states - at 1e-6
         assert np.abs(xo - xg).max() < 1e-6, (np.abs(xo - xg).max(), int(np.abs(xo - xg).argmax()))
-    assert set(scenes.canon_map(o.map_export())) == set(scenes.canon_map(g.map_export()))
+    st = scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)   # not only the key set: every voxel's tree, counters, state bits, planes, points
+    assert st["roots"] > 10000, st
 
 
 def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
@@ -567,8 +569,10 @@ def test_config3_soak_full_size(scene, oracle_lib, hip_lib):
         # loop (DESIGN "Closed-loop sensitivity"): measured <= 1.5e-6, asserted at 1e-5
         assert np.abs(xo - xg).max() < 1e-5, (k, np.abs(xo - xg).max(), int(np.abs(xo - xg).argmax()))
     assert worst < 1e-6, worst
-    so, sg = scenes.canon_map(o.map_export()), scenes.canon_map(g.map_export())
-    assert set(so) == set(sg)
+    # after 16 scans x 100 000 points: the maps voxel by voxel (tree shape, counters, state bits exact; planes 1e-5; stored points to the
+    # closed loop's own position tolerance, 1e-6 - measured 1e-8)
+    st = scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-6)
+    assert st["roots"] > 20000, st
     roots, nodes, blocks = g.map_stats()
     assert nodes >= roots > 20000 and blocks > 1000
     g.close()

@@ -250,3 +250,92 @@ def test_world1_and_world2_gather_identical_rows():
         p.join(timeout=60)
     for r in (0, 1):
         assert np.array_equal(res[r], solo), (r, np.abs(res[r] - solo).max())
+
+
+class OracleOverlayEngine(OracleReplayEngine):
+    """TEST-ONLY engine for replay.replay_batch_overlay: answers batch_replay_overlay the way lk_batch_replay_overlay_dev is specified -
+    every scan through KILO::process WITH insert on a PRIVATE copy of the shared map (the oracle re-imports the base blob per scan)."""
+
+    def __init__(self):
+        super().__init__()
+        self.blob = self.o.map_export()
+        self.priors = None
+        self.batches = []
+
+    def overlay_inputs(self, n, n_pts=480, n_b=4):
+        from legkilo_amd import synth
+
+        scans, xs, Ps = [], [], []
+        for k in range(n):
+            tb = 1.0 + 0.1 * k
+            sc = np.array(self.scenes.vlp_scan_input(self.sc, tb, k)[:n_pts], copy=True)
+            assert len(sc) == n_pts
+            sc["curvature"] = (0.025 * (np.arange(n_pts) // (n_pts // n_b))).astype(np.float32)   # one bucket table for the whole batch
+            scans.append(sc)
+            xs.append(synth.initial_state(self.sc.traj, tb, self.sc.P, np.random.default_rng(100 + k), 0.02, 0.5))
+            Ps.append((1e-4 * np.eye(30)).reshape(900))
+        off, dt = synth.buckets_of(scans[0])
+        return scans, off, dt, np.stack(xs), np.stack(Ps)
+
+    def batch_set_priors(self, x36, P900):
+        self.priors = (np.array(x36, copy=True).reshape(-1, 36), np.array(P900, copy=True).reshape(-1, 900))
+
+    def batch_replay_overlay(self, scans, t_begin, bucket_off, bucket_dt):
+        from legkilo_amd import abi
+
+        assert self.priors is not None and len(self.priors[0]) == len(scans)
+        self.batches.append(len(scans))
+        out = np.zeros(len(scans), dtype=abi.pose_dtype())
+        self.states = []
+        for i, sc in enumerate(scans):
+            self.o.map_import(self.blob)
+            self.o.set_map_insert(True)
+            self.o.set_state(self.priors[0][i], self.priors[1][i].reshape(30, 30))
+            self.o.set_times(t_begin, t_begin)
+            pose, _ = self.o.process_scan(sc, t_begin)
+            out["pos"][i], out["vel"][i], out["rot"][i] = pose.pos, pose.vel, pose.rot
+            out["n_effect"][i], out["n_buckets"][i], out["n_updates"][i] = pose.n_effect, pose.n_buckets, pose.n_updates
+            self.states.append(self.o.get_state())
+        return out
+
+    def batch_get_states(self, first_slot, n):
+        x = np.stack([np.asarray(s[0]).reshape(36) for s in self.states[first_slot:first_slot + n]])
+        P = np.stack([np.asarray(s[1]).reshape(30, 30) for s in self.states[first_slot:first_slot + n]])
+        return x, P
+
+
+def _worker_overlay(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = OracleOverlayEngine()
+    scans, off, dt, xs, Ps = eng.overlay_inputs(7)
+    rows, xa, Pa = replay.replay_batch_overlay(eng, dist, rank, world, torch.device("cpu"), scans, off, dt, xs, Ps, max_batch=3, want_states=True)
+    a, b = replay.shard_range(7, rank, world)
+    q.put((rank, rows, xa, Pa, sum(eng.batches) == b - a and max(eng.batches) <= 3))
+    dist.destroy_process_group()
+
+
+def test_overlay_replay_world2_equals_world1():
+    """Config 5 WITH the map insert, sharded (replay.replay_batch_overlay): 7 equally shaped scans replayed unsharded and over 2 gloo
+    ranks, batches of at most 3 - every rank ends up with the same 7 result rows and state records, bit for bit, in scan order; the
+    insert matters (the same scans against the frozen map match a different number of points)."""
+    eng = OracleOverlayEngine()
+    scans, off, dt, xs, Ps = eng.overlay_inputs(7)
+    solo, xs1, Ps1 = replay.replay_batch_overlay(eng, None, 0, 1, torch.device("cpu"), scans, off, dt, xs, Ps, max_batch=3, want_states=True)
+    assert solo.shape == (7, 18) and (solo[:, 15] > 50).all() and (solo[:, 16] == len(dt)).all()
+    assert xs1.shape == (7, 36) and Ps1.shape == (7, 900)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlay, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (rows, xa, Pa, ok) for r, rows, xa, Pa, ok in (q.get(timeout=240) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        rows, xa, Pa, ok = res[r]
+        assert ok
+        assert np.array_equal(rows, solo), (r, np.abs(rows - solo).max())
+        assert np.array_equal(xa, xs1) and np.array_equal(Pa, Ps1)
