@@ -57,7 +57,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X datasheet: peak fp64 vector = fp64 matrix = 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 row; 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6)
 COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
 OV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_overlay_pmc.json")
-OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_root_fast", "ov_fit_lane",
+OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_root_fast", "ov_point_geom", "ov_root_lane", "ov_fit_eig", "ov_fit_lane",
               "ov_insert_apply", "ov_insert_fallback")
 OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)

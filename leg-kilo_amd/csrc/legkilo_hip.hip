@@ -1784,6 +1784,9 @@ int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
     if (!h->ov.counters || !h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
     if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
     const LkOverlay& ov = h->ov;
+    // leaves the fast root pass left split (old points still in the handle's blocks) are made whole first
+    hipLaunchKernelGGL(lk_ov_merge_split_kernel, dim3(64), dim3(LK_MB), 0, h->stream, h->map, ov, slot);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<unsigned long long> keys(ov.hash_cap);
     HIPCHK(h, hipMemcpy(keys.data(), ov.keys + (size_t)slot * ov.hash_cap, sizeof(unsigned long long) * ov.hash_cap, hipMemcpyDeviceToHost));
@@ -3063,7 +3066,7 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
 static void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
     void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen, o.sums, o.base_sums, o.cplx};
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen, o.sums, o.base_sums, o.cplx, o.ptroot};
     for (void* q : ptrs)
         if (q) hipFree(q);
     memset(&o, 0, sizeof(o));
@@ -3092,7 +3095,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
         nodes_extra = roots / 2;
         blocks = roots;
     }
-    uint32_t hash_cap = next_pow2(roots + roots / 2);       // the roots' records ARE the table entries: node ids [0, hash_cap); load <= 2/3
+    uint32_t hash_cap = next_pow2(roots + roots / 4);       // the roots' records ARE the table entries: node ids [0, hash_cap); load <= 0.8 (0.57 for the bench's scans)
     LkOverlay& o = h->ov;
     if (grow) {   // never below what is there; what overflowed is doubled
         hash_cap = std::max(hash_cap, o.hash_cap), nodes_extra = std::max(nodes_extra, o.nodes_cap - o.hash_cap), blocks = std::max(blocks, o.blocks_cap);
@@ -3151,6 +3154,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.sums, s * n.hash_cap * sizeof(LkLeafSum));
     if (e == hipSuccess) e = get(&o.base_sums, (size_t)h->map.max_nodes * sizeof(LkLeafSum));
     if (e == hipSuccess) e = get(&o.cplx, s * n.scan_cap * 2 * sizeof(int));
+    if (e == hipSuccess) e = get(&o.ptroot, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -3196,6 +3200,7 @@ static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
     r.jobs += s0 * o.hash_cap * LK_INLINE_GROUPS;
     r.sums += s0 * o.hash_cap;
     r.cplx += s0 * o.scan_cap * 2;
+    r.ptroot += s0 * o.scan_cap;
     return r;   // frozen, base_sums, newroot, spec: shared by all slots
 }
 extern "C" {
@@ -3248,7 +3253,10 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
     // root pass: the fast path (lk_ov_root_fast_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
     // (LEGKILO_OV_FAST=0: the generic pass over every touched root, round 4's path; A/B)
-    static const bool ov_fast = getenv("LEGKILO_OV_FAST") == nullptr || atoi(getenv("LEGKILO_OV_FAST")) != 0;
+    // LEGKILO_OV_FAST: 2 (default) = the fast path as one thread per point (geometry) + one lane per root (lk_ov_point_geom_kernel,
+    // lk_ov_root_lane_kernel); 1 = the fast path one wave per root (lk_ov_root_fast_kernel); 0 = the generic pass only
+    static const int ov_fast_mode = getenv("LEGKILO_OV_FAST") ? atoi(getenv("LEGKILO_OV_FAST")) : 2;
+    static const bool ov_fast = ov_fast_mode != 0;
     static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // generic pass without the fit: 184 VGPRs at 2 waves, 168 at 3
     const auto root_kernel = ov_fast ? (root_waves >= 4 ? lk_ov_insert_root_kernel<4, true> : root_waves == 3 ? lk_ov_insert_root_kernel<3, true> : lk_ov_insert_root_kernel<2, true>)
                                      : (root_waves >= 4 ? lk_ov_insert_root_kernel<4, false> : root_waves == 3 ? lk_ov_insert_root_kernel<3, false> : lk_ov_insert_root_kernel<2, false>);
@@ -3306,15 +3314,23 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
         LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        if (ov_fast) {
+        if (ov_fast_mode >= 2) {
+            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, Sg), dim3(256), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+            static const int lane_blocks = getenv("LEGKILO_OV_LANE_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_LANE_BLOCKS"))) : 0;
+            LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(lane_blocks ? lane_blocks : std::max(4, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        } else if (ov_fast) {
             LAUNCH(h, "ov_root_fast", hipLaunchKernelGGL(fast_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl));
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         } else {
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         }
-        LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
-        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
-        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
+        LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+        static const int ov_apply_wg = getenv("LEGKILO_OV_APPLY_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_APPLY_WG"))) : 0;
+        static const int ov_fb_wg = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
+        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(ov_apply_wg ? ov_apply_wg : per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(ov_fb_wg ? ov_fb_wg : std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
         if (k + 1 < live.size())
             LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
                                                     t_begin + bucket_dt[live[k + 1]], 2));

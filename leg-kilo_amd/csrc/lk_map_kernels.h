@@ -720,7 +720,7 @@ static_assert(sizeof(LkGroup) == 64, "group descriptor must be 64 B");
 struct LkFitJob {   // 96 B: a plane fit the overlay replay's root pass leaves to lk_ov_fit_lane_kernel (apply_leaf<DEFER>)
     int leaf, block, cnt, decided;   // cnt = points of the leaf's last refit event (0: no fit), block = where they are, decided = is_plane of that event
     double s9[9];                    // its moment sums (sum p, sum p p^T)
-    double pad_;
+    int base_block, n_base;          // a SPLIT leaf (lk_ov_root_fast_kernel): its first n_base points are in the base map's block base_block; else n_base = 0
 };
 static_assert(sizeof(LkFitJob) == 96, "fit job must be 96 B");
 struct LeafInfo {
@@ -930,7 +930,7 @@ __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr,
             if (fitted) {
                 if (DEFER) {
                     if (lane == 0) {
-                        job->leaf = leaf, job->block = r.block, job->decided = fit.is_plane ? 1 : 0;
+                        job->leaf = leaf, job->block = r.block, job->decided = fit.is_plane ? 1 : 0, job->base_block = -1, job->n_base = 0;
 #pragma unroll
                         for (int q = 0; q < 9; ++q) job->s9[q] = fit.s9[q];
                         job->cnt = fit_count;
@@ -1028,7 +1028,10 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 // pad_[LK_PAD_COWBLK] = 1 + that block).  This pass reads those points where they are and stores old + new points to the private
 // block in one go (light roots and roots that are one in-place leaf group: nearly all); any other path copies them first.
 #define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 0 not in the slot's map yet, 1 complete, 2 thin
-#define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin private root: 1 + id of the BASE map's point block that holds its old points
+#define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin / split private root: 1 + id of the BASE map's point block that holds its old points
+#define LK_PAD_SPLIT 6    // lk_node_rec::pad_[6] of a private root leaf the FAST root pass (lk_ov_root_fast_kernel) has appended to without copying its old
+                          // points: the first pad_[6] points of the leaf still are the base block's (COWBLK - 1), points pad_[6] .. npts-1 sit at their own
+                          // index in the private block.  0 = the private block is complete.  The generic passes merge such a root before they touch it
 // CPLX (overlay replay): the work list is not the touched list but what the fast root pass (lk_ov_root_fast_kernel) has left over -
 // map.heavy = {root, index in the touched list} pairs, counter LK_CTR_HEAVY; the fit jobs stay indexed by the touched-list position.
 template <bool FROM_PV, bool OV = false, bool CPLX = false>
@@ -1077,7 +1080,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         if (any_) ROOT_HIST(4, tw_);   // a wave with a second root: its time so far
         any_ = true;
 #endif
-        int root, m, rnpts, rnewp, rblock, rlayer, cur_list, slot_idx, ov_live = 0, ov_cowblk = 0;
+        int root, m, rnpts, rnewp, rblock, rlayer, cur_list, slot_idx, ov_live = 0, ov_cowblk = 0, ov_split = 0;
         unsigned int rst, rpf;
         const float cpx = pf_px, cpy = pf_py, cpz = pf_pz;   // OV: this root's queued points (lane k: the k-th queued), before the next root's are requested
         if (OV) {
@@ -1088,6 +1091,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
             cur_list = __builtin_amdgcn_readlane(pf_rec.w, 5);
             m = __builtin_amdgcn_readlane(pf_rec.x, 6), ov_live = __builtin_amdgcn_readlane(pf_rec.w, 6);   // pad_[0], pad_[LK_PAD_LIVE]
             ov_cowblk = __builtin_amdgcn_readlane(pf_rec.y, 7);                                              // pad_[LK_PAD_COWBLK]
+            ov_split = __builtin_amdgcn_readlane(pf_rec.z, 7);                                               // pad_[LK_PAD_SPLIT]
             rpf = (unsigned int)bcast0(pf_flags);
             slot_idx = pf_slot;
             pf_root1 = pf_root2;
@@ -1111,16 +1115,18 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         // plane 0 is dense for lk_ov_fit_lane_kernel's lanes (job_stride = entries per plane)
         if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + tix].cnt = 0;
         int job_i = 0;
+        int cow_n = 0;   // old points that still sit in the base block
         if (OV) {
             const unsigned int live = (unsigned int)ov_live;
             const int cow_blk = ov_cowblk - 1;
-            if (live == 2u && cow_blk >= 0) cow_src = cow_base->blocks[cow_blk].pts;
+            if (live == 2u && cow_blk >= 0) cow_src = cow_base->blocks[cow_blk].pts, cow_n = rnpts;
+            else if (ov_split > 0 && cow_blk >= 0) cow_src = cow_base->blocks[cow_blk].pts, cow_n = min(ov_split, rnpts);
             if (live == 2u && lane == 0) nd->pad_[LK_PAD_LIVE] = 1;   // complete when this wave is done with it (nothing reads the word before the next bucket)
         }
-        // thin root leaving the fused paths: its old points go to the private block first, then it is a root like any other
+        // thin / split root leaving the fused paths: its old points go to the private block first, then it is a root like any other
         auto cow_finalise = [&]() {
             if (OV && cow_src) {
-                if (lane < rnpts) {
+                if (lane < cow_n && rblock >= 0) {
                     double qw[3], qv[6];
                     load_pt(cow_src, nullptr, lane, qw, qv);
                     lk_pt_rec* dst = &map.blocks[rblock].pts[lane];
@@ -1129,10 +1135,12 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
 #pragma unroll
                     for (int c = 0; c < 6; ++c) dst->var[c] = qv[c];
                 }
+                if (lane == 0) nd->pad_[LK_PAD_SPLIT] = 0;
                 wave_fence();
                 cow_src = nullptr;
             }
         };
+        if (OV && ov_split > 0 && ov_live != 2) cow_finalise();   // a leaf the fast pass left split: merged before anything else looks at its block
         if (lane == 0) nd->pad_[0] = 0, nd->list_head = -1;   // the root's bucket-local queue is consumed
         // ---- light root: append only (one lane per point, input order = ascending index)
         const bool light = !FROM_PV && root_is_light(pr, m, rst, rpf, rnpts, rnewp);

@@ -33,6 +33,7 @@
 // have been claimed in this bucket but the root does not exist in the slot's map yet; 1 it exists; 2 "thin": it exists, only its old points are still
 // the base map's (block COWBLK - 1) - a state that lasts from the copy-on-write pass to the root pass of the same bucket.
 #define LK_PAD_BASE 4     // lk_node_rec::pad_[4] of a private root record that does not exist yet: 1 + id of the base map's voxel of that key (0: none)
+#define LK_PLANE_LAZY (-2)   // lk_plane_rec::points_size of a private root whose plane record (but for d, radius, flags) has not been made private: the base map's holds
 #define LK_OV_EMPTY 0x8000000000000000ull   // empty entry of a slot's key table (a packed key never has bit 63 set)
 
 // Moment sums of the FIRST n points of a leaf's block (sum p, sum p p^T: what every refit event's plane test is made from,
@@ -74,6 +75,7 @@ struct LkOverlay {
     struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_fast_kernel)
     struct LkLeafSum* base_sums; // [base max_nodes], shared: the same for the BASE map's root leaves, once per replay (lk_ov_base_sums_kernel)
     int* cplx;                   // [S][2 * scan_cap]: {root, index in the touched list} of the roots the fast root pass leaves to the generic one
+    int* ptroot;                 // [S][scan_cap]: per bucket point, the private root it was queued on in a slot line (-1: dropped, or queued in the overflow list)
     unsigned int hash_cap, nodes_cap, blocks_cap, scan_cap, bit_words;
 };
 
@@ -212,6 +214,9 @@ __global__ void __launch_bounds__(LK_WAVE) lk_ov_begin_kernel(LkOverlay ov) {
 // Would UpdateOctoTree ignore this point (voxel_map.cc:185-241)?  The walk of dev_reproject_point: down through initialised
 // non-planar nodes below max_layer (they never change again) to the node the point would be pushed into; ignored iff that node
 // is frozen.
+// (Round 5, measured and not kept: the node's fields requested together, one round trip per node instead of one per field - 3.4 -> 3.9 ms per
+// batch.  At eight waves per SIMD this pass is bound by the NUMBER of memory requests, not by their latency: the compiler's habit of fetching
+// a field only behind the test that needs it is the cheaper one here.)
 __device__ __forceinline__ bool ov_walk_ignored(const LkMap& m, int root, const V3& pw, int max_layer) {
     int node = root;
     for (int depth = 0; depth <= LK_MAX_LAYER; ++depth) {
@@ -259,12 +264,9 @@ __global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsi
 // voxel of the key, if any, is still the truth - the insert's first phase is read-only on every tree.  A point that is not ignored
 // claims its key in the slot's table (if nobody has) and is queued on that entry = root record; lk_ov_materialise_kernel then
 // creates the roots that do not exist yet.
-__global__ void __launch_bounds__(LK_WAVE)
-    lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                           size_t pts_slot_stride, int n) {
-    const int i = blockIdx.x * LK_WAVE + threadIdx.x;
-    if (i >= n) return;
-    const unsigned int slot = blockIdx.y;
+// returns the private root the point was queued on in a slot line, or -1 (ignored, or queued in a long root's overflow list)
+__device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const LkFilter* __restrict__ filters,
+                                                  const lk_point* __restrict__ pts, size_t pts_slot_stride, const int i, const unsigned int slot) {
     const LkMap pm = ov_slot_map(ov, slot);
     unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
     BucketConst bc;
@@ -276,25 +278,31 @@ __global__ void __launch_bounds__(LK_WAVE)
     unsigned long long pk;
     if (!ov_pack_key(key[0], key[1], key[2], &pk)) {
         atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
-        return;
+        return -1;
     }
-    {   // the base voxel of this key is a frozen leaf: the point is ignored, and no private voxel of that key can exist
-        unsigned int cell;
-        if (ov_cell_of(base, key, &cell) && ((ov.frozen[cell >> 5] >> (cell & 31u)) & 1u)) return;
-    }
+    unsigned int cell = 0;
+    const bool in_grid = ov_cell_of(base, key, &cell);
+    // the base voxel of this key is a frozen leaf: the point is ignored, and no private voxel of that key can exist
+    if (in_grid && ((ov.frozen[cell >> 5] >> (cell & 31u)) & 1u)) return -1;
     const unsigned int hk = ov_slot_hash(key[0], key[1], key[2]);
     int root = ov_key_find(keys, pm.hash_mask, pk, hk);
     if (root >= 0 && pm.nodes[root].pad_[LK_PAD_LIVE] != 0) {
-        if (ov_walk_ignored(pm, root, pw, pr.max_layer)) return;
+        if (ov_walk_ignored(pm, root, pw, pr.max_layer)) return -1;
     } else {
-        const int broot = hash_find(base, key[0], key[1], key[2]);
-        if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return;
+        // the base map's voxel of this key: its node id sits in the frozen-map grid cell (arithmetic index, 4 bytes; a key outside the grid's
+        // box has no base voxel) - no probe of the base table
+        int broot = -1;
+        if (in_grid) {
+            const unsigned int bnode = base.match[(size_t)base.grid_base + cell].pad_;
+            if (bnode != LK_GRID_EMPTY) broot = (int)bnode;
+        }
+        if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return -1;
         if (root < 0) {
             bool claimed;
             root = ov_key_claim(keys, pm.hash_mask, pk, hk, &claimed);
             if (root < 0) {
                 atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
-                return;
+                return -1;
             }
             // what the materialise pass copies into this root (no lookup there): stored by the ONE lane that claimed the key - a store
             // per point cost 2.8 ms per 1024-scan batch
@@ -313,6 +321,15 @@ __global__ void __launch_bounds__(LK_WAVE)
         const unsigned int t = atomicAdd(&pm.counters[LK_CTR_TOUCHED], 1u);
         pm.touched[t] = root;
     }
+    return k < (unsigned int)LK_SLOTS ? root : -1;
+}
+__global__ void __launch_bounds__(LK_WAVE)
+    lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                           size_t pts_slot_stride, int n) {
+    const int i = blockIdx.x * LK_WAVE + threadIdx.x;
+    if (i >= n) return;
+    const int r = ov_reproject_point(base, ov, pr, filters, pts, pts_slot_stride, i, blockIdx.y);
+    ov.ptroot[(size_t)blockIdx.y * ov.scan_cap + i] = r;   // for lk_ov_point_geom_kernel
 }
 
 // ---------------------------------------------------------------- copy-on-write of a base voxel's octree
@@ -470,12 +487,16 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
         }
         // the root's moment-sum prefix (lk_ov_root_fast_kernel): the base leaf's (made once per replay) for a childless base voxel, none otherwise
         if (need) {
+            pm.nodes[my_root].pad_[LK_PAD_SPLIT] = 0;   // (a word of the previous replay may still be there)
             LkLeafSum* sr = &ov.sums[(size_t)slot * ov.hash_cap + my_root];
             if (has_base && childless) {
                 const int4* bs = reinterpret_cast<const int4*>(&ov.base_sums[my_base - 1]);
                 int4* ds = reinterpret_cast<int4*>(sr);
+                int4 tmp[5];   // all five loads first: a store between them would hold the next load back (the two records may alias, for all the compiler knows)
 #pragma unroll
-                for (int c = 0; c < 5; ++c) ds[c] = bs[c];
+                for (int c = 0; c < 5; ++c) tmp[c] = bs[c];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) ds[c] = tmp[c];
             } else {
                 sr->n = 0;
             }
@@ -489,13 +510,16 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             pm.nodes[my_root].key[0] = rec[5].x, pm.nodes[my_root].key[1] = rec[5].y, pm.nodes[my_root].key[2] = rec[5].z;
             pm.nodes[my_root].pad_[LK_PAD_COWBLK] = pending ? (unsigned int)(s_block + 1) : 0u;
         }
-        // ... and their plane (16 pieces) + match (9 pieces) records as one flat list over the chunk's thin voxels, five loads in flight per lane
+        // ... and their match records (9 pieces of 16 B) as one flat list over the chunk's thin voxels, five loads in flight per lane.  The 256-B
+        // PLANE record is not copied (round 5): every reader on the replay's path wants its flags word only, which the match record carries -
+        // the lane that copies match piece 3 {d, radius, flags, .} also writes plane piece 3 {d, radius, flags, points_size = LK_PLANE_LAZY}.
+        // A fit rewrites the whole record; lk_ov_merge_split_kernel fetches the base map's record for an export of a voxel that was never refitted
         {
             const unsigned long long thin_mask = __ballot(thin);
             const int n_thin = __popcll(thin_mask);
             const int pos = thin ? __popcll(thin_mask & ((1ull << lane) - 1ull)) : 63;   // n_thin == 64: every lane is a member
             const int c_src = __builtin_amdgcn_ds_permute(pos << 2, my_base - 1), c_dst = __builtin_amdgcn_ds_permute(pos << 2, my_root);
-            constexpr int PIECES = 25, U = 5;
+            constexpr int PIECES = 9, U = 5;
             const int total = n_thin * PIECES;
             for (int j0 = 0; j0 < total; j0 += 64 * U) {
                 uint4 v[U];
@@ -508,15 +532,14 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
                     const int src = __shfl(c_src, r & 63, LK_WAVE);
                     dsts[u] = __shfl(c_dst, r & 63, LK_WAVE);
                     v[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (idx < total)
-                        v[u] = cs[u] < 16 ? reinterpret_cast<const uint4*>(&base.planes[src])[cs[u]] : reinterpret_cast<const uint4*>(&base.match[src])[cs[u] - 16];
+                    if (idx < total) v[u] = reinterpret_cast<const uint4*>(&base.match[src])[cs[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int idx = j0 + 64 * u + lane;
                     if (idx < total) {
-                        if (cs[u] < 16) reinterpret_cast<uint4*>(&pm.planes[dsts[u]])[cs[u]] = v[u];
-                        else reinterpret_cast<uint4*>(&pm.match[dsts[u]])[cs[u] - 16] = v[u];
+                        reinterpret_cast<uint4*>(&pm.match[dsts[u]])[cs[u]] = v[u];
+                        if (cs[u] == 3) reinterpret_cast<uint4*>(&pm.planes[dsts[u]])[3] = make_uint4(v[u].x, v[u].y, v[u].z, (unsigned int)LK_PLANE_LAZY);
                     }
                 }
             }
@@ -550,11 +573,46 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 // (Measured and not kept: the whole root pass one lane per root - queue, sums, state machine - is bound by memory TRANSACTIONS, every
 // lane's 8-B access its own: 9.4 + 2.2 ms against 10.8 ms for the wave-per-root pass, 512 scans; profiles/EXPERIMENTS.md.)
 #ifndef LK_FIT_WAVES
-#define LK_FIT_WAVES 2
+#define LK_FIT_WAVES 4
 #endif
+
 // (Sorting a workgroup's jobs by point count, so that a wave's lanes run similar loop lengths, changes nothing: 4.04 vs 3.99 ms per 1024
 // scans - the pass moves 1.7 KB per fit in 16-B pieces, 2 TB/s.)
-__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(LkOverlay ov, LkParams pr) {
+// First half of a fit, one lane per job: init_plane's centroid, scatter matrix and eigen-decomposition (voxel_map.cc:46-66) from the event's moment
+// sums.  A "not a plane" event ends here (flag cleared); for a plane the centre, the three eigenvectors and eigenvalues are left in the leaf's
+// private plane record (centre, normal = v_min; v_mid, v_max and the eigenvalues in the first nine plane_var words) for lk_ov_fit_lane_kernel,
+// which overwrites them with the finished plane.  Two kernels because the closed-form eigen-solver (acos, two cos) and the loop over the leaf's
+// points each fit 128 registers and together do not: the single kernel ran at two waves per SIMD.
+__global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkOverlay ov, LkParams pr) {
+    const unsigned int slot = blockIdx.y;
+    const LkMap pm = ov_slot_map(ov, slot);
+    if (pm.counters[LK_CTR_ERR]) return;
+    const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
+    const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
+    for (int i = blockIdx.x * LK_WAVE + threadIdx.x; i < n_touched * LK_INLINE_GROUPS; i += gridDim.x * LK_WAVE) {
+        const int g = i / n_touched, t = i - g * n_touched;
+        const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
+        const int4 hd = *reinterpret_cast<const int4*>(job);
+        const int root = hd.x, cnt = hd.z;
+        if (cnt <= 0) continue;
+        lk_plane_rec* pl = &pm.planes[root];
+        if (hd.w == 0) {   // plane_commit's "not a plane" branch
+            pl->points_size = cnt;
+            const unsigned int fl = pl->flags & ~LK_PLANE_IS_PLANE;
+            pl->flags = fl;
+            pm.match[root].flags = fl;
+            continue;
+        }
+        PlaneFit ev;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ev.s9[q] = job->s9[q];
+        const PlaneFit fit = plane_test_regs<false, true>(nullptr, false, cnt, pr.planer_threshold, &ev);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl->center[k] = fit.c[k], pl->normal[k] = fit.vmin[k], pl->plane_var[k] = fit.vmid[k], pl->plane_var[3 + k] = fit.vmax[k];
+        pl->plane_var[6] = fit.emin, pl->plane_var[7] = fit.emid, pl->plane_var[8] = fit.emax;
+    }
+}
+__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
@@ -566,77 +624,77 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
         const int4 hd = *reinterpret_cast<const int4*>(job);
         const int root = hd.x /* the leaf's node id */, block = hd.y, cnt = hd.z;
         if (cnt <= 0) continue;
-        PlaneFit ev;
+        if (hd.w == 0) continue;   // the event said "not a plane": lk_ov_fit_eig_kernel has cleared the flag, there is no plane_var to make
+        // centre, eigenvectors and eigenvalues of the fit: left in the leaf's private plane record by lk_ov_fit_eig_kernel
+        PlaneFit fit;
+        {
+            const lk_plane_rec* pl = &pm.planes[root];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) ev.s9[q] = job->s9[q];
-        PlaneFit fit = plane_test_regs<false, true>(nullptr, false, cnt, pr.planer_threshold, &ev);
-        fit.is_plane = hd.w != 0;   // the lane pass already followed the event's decision
+            for (int k = 0; k < 3; ++k) fit.c[k] = pl->center[k], fit.vmin[k] = pl->normal[k], fit.vmid[k] = pl->plane_var[k], fit.vmax[k] = pl->plane_var[3 + k];
+            fit.emin = pl->plane_var[6], fit.emid = pl->plane_var[7], fit.emax = pl->plane_var[8];
+        }
+        fit.is_plane = true;
         double acc21[21];
 #pragma unroll
         for (int q = 0; q < 21; ++q) acc21[q] = 0.0;
         if (fit.is_plane) {
-            double rhsA[9], rhsB[9];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    rhsA[3 * r + cc] = fit.vmid[r] * fit.vmin[cc] + fit.vmin[r] * fit.vmid[cc];
-                    rhsB[3 * r + cc] = fit.vmax[r] * fit.vmin[cc] + fit.vmin[r] * fit.vmax[cc];
-                }
-            const double denA = cnt * (fit.emin - fit.emid), denB = cnt * (fit.emin - fit.emax);
+            // plane_var = sum_i J_i var_i J_i^T (voxel_map.cc:76-95) with J_i = [A_i ; I / n], A_i = v_mid FA_i^T + v_max FB_i^T (rank 2; the row of
+            // v_min is zero), FA_i = ((q.v_mid) v_min + (q.v_min) v_mid) / den_A, FB_i likewise with v_max, q = p_i - centre.  With a = var FA, b = var FB:
+            //   A var A^T = v_mid v_mid^T (FA.a) + (v_mid v_max^T + v_max v_mid^T) (FA.b) + v_max v_max^T (FB.b),   A var = v_mid a^T + v_max b^T
+            // so the 21 sums of 3 x 3 products per point become 15 running sums of a few dot products - the same value (a different, equally
+            // valid rounding), a quarter of the arithmetic and half the registers: four waves per SIMD instead of two
+            const double invA = 1.0 / (cnt * (fit.emin - fit.emid)), invB = 1.0 / (cnt * (fit.emin - fit.emax));
             const double invn = 1.0 / cnt;
             const lk_pt_rec* __restrict__ bp = pm.blocks[block].pts;
-            double nw[3], nv[6];   // the next point is requested while this one is worked on
-#pragma unroll
-            for (int c = 0; c < 3; ++c) nw[c] = bp[0].pw[c];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) nv[c] = bp[0].var[c];
+            // a split leaf (lk_ov_root_fast_kernel): its first n_base points are still the base map's
+            const int n_base = job->n_base;
+            const lk_pt_rec* __restrict__ bb = n_base > 0 ? base.blocks[job->base_block].pts : bp;
+            double sa[3] = {0.0, 0.0, 0.0}, sb[3] = {0.0, 0.0, 0.0}, saa = 0.0, sab = 0.0, sbb = 0.0, sV[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
             for (int j = 0; j < cnt; ++j) {
                 double pw[3], var[6];
+                const lk_pt_rec* __restrict__ pj = (j < n_base ? bb : bp) + j;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) pw[c] = nw[c];
+                for (int c = 0; c < 3; ++c) pw[c] = pj->pw[c];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) var[c] = nv[c];
-                if (j + 1 < cnt) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) nw[c] = bp[j + 1].pw[c];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) nv[c] = bp[j + 1].var[c];
-                }
-                double q[3] = {pw[0] - fit.c[0], pw[1] - fit.c[1], pw[2] - fit.c[2]};
-                double la[3] = {q[0] / denA, q[1] / denA, q[2] / denA};
-                double lb[3] = {q[0] / denB, q[1] / denB, q[2] / denB};
+                for (int c = 0; c < 6; ++c) var[c] = pj->var[c];
+                const double q0 = pw[0] - fit.c[0], q1 = pw[1] - fit.c[1], q2 = pw[2] - fit.c[2];
+                const double dmin = q0 * fit.vmin[0] + q1 * fit.vmin[1] + q2 * fit.vmin[2];
+                const double dmid = (q0 * fit.vmid[0] + q1 * fit.vmid[1] + q2 * fit.vmid[2]) * invA;
+                const double dmax = (q0 * fit.vmax[0] + q1 * fit.vmax[1] + q2 * fit.vmax[2]) * invB;
+                const double dmA = dmin * invA, dmB = dmin * invB;
                 double FA[3], FB[3];
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    FA[cc] = la[0] * rhsA[cc] + la[1] * rhsA[3 + cc] + la[2] * rhsA[6 + cc];
-                    FB[cc] = lb[0] * rhsB[cc] + lb[1] * rhsB[3 + cc] + lb[2] * rhsB[6 + cc];
-                }
-                double J[6][3];
+                for (int c = 0; c < 3; ++c) FA[c] = dmid * fit.vmin[c] + dmA * fit.vmid[c], FB[c] = dmax * fit.vmin[c] + dmB * fit.vmax[c];
+                const double a0 = var[0] * FA[0] + var[1] * FA[1] + var[2] * FA[2], a1 = var[1] * FA[0] + var[3] * FA[1] + var[4] * FA[2],
+                             a2 = var[2] * FA[0] + var[4] * FA[1] + var[5] * FA[2];
+                const double b0 = var[0] * FB[0] + var[1] * FB[1] + var[2] * FB[2], b1 = var[1] * FB[0] + var[3] * FB[1] + var[4] * FB[2],
+                             b2 = var[2] * FB[0] + var[4] * FB[1] + var[5] * FB[2];
+                saa += FA[0] * a0 + FA[1] * a1 + FA[2] * a2;
+                sab += FA[0] * b0 + FA[1] * b1 + FA[2] * b2;
+                sbb += FB[0] * b0 + FB[1] * b1 + FB[2] * b2;
+                sa[0] += a0, sa[1] += a1, sa[2] += a2, sb[0] += b0, sb[1] += b1, sb[2] += b2;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        J[r][cc] = fit.vmid[r] * FA[cc] + fit.vmax[r] * FB[cc];
-                        J[3 + r][cc] = (r == cc) ? invn : 0.0;
-                    }
-                double Sv[3][3] = {{var[0], var[1], var[2]}, {var[1], var[3], var[4]}, {var[2], var[4], var[5]}};
-                double JV[6][3];
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) JV[r][cc] = J[r][0] * Sv[0][cc] + J[r][1] * Sv[1][cc] + J[r][2] * Sv[2][cc];
-                int kk = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int cc = r; cc < 6; ++cc) acc21[kk++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
+                for (int c = 0; c < 6; ++c) sV[c] += var[c];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // the 21 unique entries, upper triangle row by row: rows 0..2 = [A var A^T | A var / n], rows 3..5 = [. | sum var / n^2]
+            int kk = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = r; cc < 3; ++cc)
+                    acc21[kk++] = fit.vmid[r] * fit.vmid[cc] * saa + (fit.vmid[r] * fit.vmax[cc] + fit.vmax[r] * fit.vmid[cc]) * sab + fit.vmax[r] * fit.vmax[cc] * sbb;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) acc21[kk++] = (fit.vmid[r] * sa[cc] + fit.vmax[r] * sb[cc]) * invn;
+            }
+            const double invn2 = invn * invn;
+            acc21[15] = sV[0] * invn2, acc21[16] = sV[1] * invn2, acc21[17] = sV[2] * invn2, acc21[18] = sV[3] * invn2, acc21[19] = sV[4] * invn2, acc21[20] = sV[5] * invn2;
         }
         plane_commit<true>(&pm.planes[root], &pm.match[root], fit, acc21, cnt);
     }
 }
-
 
 // ---------------------------------------------------------------- the root pass of the batch replay, FAST PATH (round 5)
 // Nearly every touched root of a batch bucket is a leaf that takes its few new points (in input order), maybe passes a refit event or
@@ -664,6 +722,9 @@ __device__ __forceinline__ bool ov_plane_decide(const double* s, int count, floa
     const double m3 = b11 * (b22 * b33 - byz * byz) - bxy * (bxy * b33 - byz * bxz) + bxz * (bxy * byz - b22 * bxz);
     return !(b11 > 0.0 && m2 > 0.0 && m3 > 0.0);
 }
+#ifndef LK_FAST_SLOTS
+#define LK_FAST_SLOTS 8   // slot-line entries (16 B each) requested with a root's record: one 128-B line (a power of two)
+#endif
 #ifndef LK_FAST_X
 #define LK_FAST_X 0   // attribution builds only (results wrong): 1 no point covariance, 2 no wave sums
 #endif
@@ -681,42 +742,47 @@ __global__ void __launch_bounds__(LK_MB, W)
     LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
     BucketConst bc;
     load_bucket_const(&filters[slot], pr, bc);
-    // requested ahead (lane k: 16-B piece k of the node record / of the sums record, point k of the slot line)
-    int pf_root1 = -1, pf_root2 = -1, pf_flags = 0, pf_slot = 0x7fffffff;
+    // Requested one root ahead: the node record (lane k: 16-B piece k & 7), the sums record (lane k: double k, lane >= 9: its point count), the
+    // plane flags, the first line of the slot points (lane k: point k & 7).  EVERY lane loads, from clamped addresses, and nothing looks at
+    // the registers before the next iteration: a load behind a lane test (or a default value merged in) makes the compiler wait for it on the
+    // spot - the first version of this loop had four memory round trips in a row per root where it was meant to have none.
+    // The touched list is read 64 entries at a time (lane k: the id k + 1 roots ahead) instead of one dependent load per root.
+    int pf_flags = 0, pf_slot = 0x7fffffff;
     float pf_px = 0.f, pf_py = 0.f, pf_pz = 0.f;
-    int4 pf_rec = make_int4(0, 0, 0, 0), pf_sum = make_int4(0, 0, 0, 0);
+    int4 pf_rec = make_int4(0, 0, 0, 0);
+    int2 pf_sum = make_int2(0, 0);   // lane k: double k of the root's sums record (k < 9), lane 9: its point count
     auto prefetch_record = [&](int r) {
-        if (r >= 0) {
-            if (lane < 8) pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane];
-            if (lane < 5) pf_sum = reinterpret_cast<const int4*>(&sums[r])[lane];
-            pf_flags = (int)map.planes[r].flags;
-            pf_slot = 0x7fffffff;
-            if (lane < LK_SLOTS) {
-                const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)r * LK_SLOTS + lane];
-                pf_px = q.x, pf_py = q.y, pf_pz = q.z, pf_slot = __float_as_int(q.w);
-            }
-        }
+        pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane & 7];
+        pf_sum = reinterpret_cast<const int2*>(&sums[r])[min(lane, 9)];
+        pf_flags = (int)map.planes[r].flags;
+        const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)r * LK_SLOTS + (lane & (LK_FAST_SLOTS - 1))];
+        pf_px = q.x, pf_py = q.y, pf_pz = q.z, pf_slot = __float_as_int(q.w);
     };
-    pf_root1 = wave < n_touched ? bcast0(map.touched[wave]) : -1;
-    pf_root2 = wave + nwaves < n_touched ? bcast0(map.touched[wave + nwaves]) : -1;
-    prefetch_record(pf_root1);
-    for (int t = wave; t < n_touched; t += nwaves) {
-        const float cpx = pf_px, cpy = pf_py, cpz = pf_pz;
-        const int slot_idx = pf_slot;
-        const int4 rec = pf_rec, sumv = pf_sum;
-        const int root = pf_root1;
+    if (wave >= n_touched) return;
+    int next_root = bcast0(map.touched[wave]);
+    int ahead = map.touched[min(wave + (lane + 1) * nwaves, n_touched - 1)];   // ids of the roots 1 .. 64 iterations ahead
+    prefetch_record(next_root);
+    int it = 0;
+    for (int t = wave; t < n_touched; t += nwaves, ++it) {
+        float cpx = pf_px, cpy = pf_py, cpz = pf_pz;
+        int slot_idx = pf_slot;
+        const int4 rec = pf_rec;
+        const int2 sumv = pf_sum;
+        const int root = next_root;
         const unsigned int rpf = (unsigned int)bcast0(pf_flags);
-        pf_root1 = pf_root2;
-        prefetch_record(pf_root1);
-        pf_root2 = t + 2 * nwaves < n_touched ? bcast0(map.touched[t + 2 * nwaves]) : -1;
         const int rlayer = __builtin_amdgcn_readlane(rec.w, 3);
         const int n0 = __builtin_amdgcn_readlane(rec.x, 4), rnewp = __builtin_amdgcn_readlane(rec.y, 4);
         const unsigned int rst = (unsigned int)__builtin_amdgcn_readlane(rec.z, 4);
         int rblock = __builtin_amdgcn_readlane(rec.w, 4);
         const int m = __builtin_amdgcn_readlane(rec.x, 6);                      // pad_[0]: points queued in this bucket
+        if (m > LK_FAST_SLOTS && lane >= LK_FAST_SLOTS && lane < LK_SLOTS) {    // more points than the line requested ahead holds
+            const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)root * LK_SLOTS + lane];
+            cpx = q.x, cpy = q.y, cpz = q.z, slot_idx = __float_as_int(q.w);
+        }
         const int ov_live = __builtin_amdgcn_readlane(rec.w, 6);               // pad_[LK_PAD_LIVE]
         const int cow_blk = __builtin_amdgcn_readlane(rec.y, 7) - 1;           // pad_[LK_PAD_COWBLK] - 1
-        int sum_n = __builtin_amdgcn_readlane(sumv.z, 4);
+        const int split0 = __builtin_amdgcn_readlane(rec.z, 7);                // pad_[LK_PAD_SPLIT]
+        int sum_n = __builtin_amdgcn_readlane(sumv.x, 9);
         const bool thin = ov_live == 2 && cow_blk >= 0;
         const bool uninit = !(rst & LK_NODE_INIT_OCTO), lplane = (rpf & LK_PLANE_IS_PLANE) != 0, live = (rst & LK_NODE_UPDATE_ENABLE) != 0;
         // ---- is this the common case?  (everything here is uniform over the wave)
@@ -727,9 +793,20 @@ __global__ void __launch_bounds__(LK_MB, W)
         const bool may_refit = uninit ? (n0 + m > thr) : (rnewp + m > 5);
         const int U = may_refit ? n0 - sum_n : 0;     // old points behind the sums' prefix: read (pw only) when a refit event may need them
         if (U + m > LK_WAVE) complex_root = true;
+        // the old points behind the sums' prefix, lanes m .. m+U-1 (normally none).  These loads - like the slot points of a long queue above -
+        // are issued BEFORE the next root's request: memory operations complete in order, so whoever waits for the youngest one waits for all,
+        // and a wait the compiler places at a join is paid on the path that did not load, too
+        double ppw[3] = {0.0, 0.0, 0.0};
+        if (!complex_root && lane >= m && lane < m + U) {
+            const int oj = sum_n + (lane - m);   // (a split leaf's sums cover at least its base part, so these normally are private points)
+            const lk_pt_rec* q = ((thin || oj < split0) ? base.blocks[cow_blk].pts : map.blocks[rblock].pts) + oj;
+            ppw[0] = q->pw[0], ppw[1] = q->pw[1], ppw[2] = q->pw[2];
+        }
+        next_root = __builtin_amdgcn_readlane(ahead, it & 63);
+        prefetch_record(t + nwaves < n_touched ? next_root : root);
+        if ((it & 63) == 63) ahead = map.touched[min(t + (lane + 2) * nwaves, n_touched - 1)];
         int cur = n0, newp = rnewp, consumed = 0, fit_count = 0;
         bool frozen = false, fitted = false;
-        double ppw[3] = {0.0, 0.0, 0.0};
         double sev[9];    // moment sums of the last refit event (uniform)
 #pragma unroll
         for (int q = 0; q < 9; ++q) sev[q] = 0.0;
@@ -747,21 +824,12 @@ __global__ void __launch_bounds__(LK_MB, W)
             // ---- stores that do no harm if the root turns out to need the generic pass after all (it writes the same bytes again):
             // the old points of a voxel seen for the first time, as a FLAT copy of 72 n0 bytes in 16-B pieces (+ one 8-B tail when n0 is
             // odd); the new points behind them, each by its lane (a freeze ignores the ones past it: they lie beyond npts)
+            // a voxel seen for the first time keeps its old points WHERE THEY ARE, in the base map's block: the leaf becomes "split"
+            // (LK_PAD_SPLIT = n0 old points in the base block, everything appended from now on at its own index in the private block).
+            // This pass never needs them (sums), the plane fits read them from the base block - which all scans of the batch share, so
+            // they come out of the L2 / Infinity Cache - and whoever else wants the block whole merges it first (dev_insert_root's
+            // cow_finalise, lk_ov_merge_split_kernel before an export).  Copying them was 17 GB of the batch's 57.
             lk_pt_rec* dstp = map.blocks[rblock].pts;
-            if (thin && n0 > 0) {
-                const int n16 = (n0 * 72) >> 4;
-                const uint4* sp = reinterpret_cast<const uint4*>(base.blocks[cow_blk].pts);
-                uint4* dp = reinterpret_cast<uint4*>(dstp);
-                for (int j0 = 0; j0 < n16; j0 += 2 * LK_WAVE) {
-                    const int ja = j0 + lane, jb = j0 + LK_WAVE + lane;
-                    uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
-                    if (ja < n16) va = sp[ja];
-                    if (jb < n16) vb = sp[jb];
-                    if (ja < n16) dp[ja] = va;
-                    if (jb < n16) dp[jb] = vb;
-                }
-                if ((n0 & 1) && lane == 0) reinterpret_cast<double*>(dstp)[n0 * 9 - 1] = reinterpret_cast<const double*>(base.blocks[cow_blk].pts)[n0 * 9 - 1];
-            }
             if (lane < m && n0 + lane < LK_BLOCK_PTS) {
                 // point_geom's expressions (KILO.cc:126-140), evaluated in three phases with the results stored as they come - the
                 // full inline form keeps ~80 registers alive at once and cost this pass its fourth wave per SIMD
@@ -787,9 +855,6 @@ __global__ void __launch_bounds__(LK_MB, W)
                 }
                 d->var[0] = va.xx, d->var[1] = va.xy, d->var[2] = va.xz, d->var[3] = va.yy, d->var[4] = va.yz, d->var[5] = va.zz;
                 __builtin_amdgcn_sched_barrier(0);
-            } else if (lane >= m && lane < m + U) {
-                const lk_pt_rec* q = (thin ? base.blocks[cow_blk].pts : map.blocks[rblock].pts) + (sum_n + (lane - m));
-                ppw[0] = q->pw[0], ppw[1] = q->pw[1], ppw[2] = q->pw[2];
             }
             // ---- the register simulation of voxel_map.cc:186-204 for a root leaf (apply_leaf's loop, modes 0 and 1 only): every refit event
             // must say "plane", anything else belongs to the generic pass
@@ -810,10 +875,11 @@ __global__ void __launch_bounds__(LK_MB, W)
                         sq[3] = ppw[0] * ppw[0], sq[4] = ppw[0] * ppw[1], sq[5] = ppw[0] * ppw[2];
                         sq[6] = ppw[1] * ppw[1], sq[7] = ppw[1] * ppw[2], sq[8] = ppw[2] * ppw[2];
                     }
-                    if (sum_n > 0) {   // the prefix: lane k of the request holds doubles 2k, 2k+1 of the record and adds them to its own partial sums
+                    if (sum_n > 0) {   // the prefix: lane q of the request holds double q of the record and adds it to its own partial sum
+                        const double mine = __hiloint2double(sumv.y, sumv.x);
 #pragma unroll
                         for (int q = 0; q < 9; ++q)
-                            if (lane == (q >> 1)) sq[q] += (q & 1) ? __hiloint2double(sumv.w, sumv.z) : __hiloint2double(sumv.y, sumv.x);
+                            if (lane == q) sq[q] += mine;
                     }
 #if !(LK_FAST_X & 2)
                     wave_sum_n<9>(sq);
@@ -850,13 +916,14 @@ __global__ void __launch_bounds__(LK_MB, W)
             nnpts = 0, newp = 0, nblock = -1;
             if (lane == 0) retire_block(map, rblock);   // not handed out again before the next bucket: the fit below still reads it
         }
-        // the record: lanes 4, 5, 6 store their own 16-B piece (counters | key + list head | queue words)
+        // the record: the counters as one 16-B piece (lane 4), the queue words one lane each (the request's registers are long dead)
         {
-            int4 o = rec;
-            if (lane == 4) o = make_int4(nnpts, newp, (int)nst, nblock);
-            else if (lane == 5) o.w = -1;                 // list_head
-            else if (lane == 6) o.x = 0, o.w = 1;         // pad_[0] = 0: queue consumed; pad_[LK_PAD_LIVE] = 1: complete
-            if (lane >= 4 && lane <= 6) reinterpret_cast<int4*>(&map.nodes[root])[lane] = o;
+            lk_node_rec* nd = &map.nodes[root];
+            if (lane == 4) reinterpret_cast<int4*>(nd)[4] = make_int4(nnpts, newp, (int)nst, nblock);
+            if (lane >= 5 && lane <= (thin ? 8 : 7)) {
+                int* wp = lane == 5 ? &nd->list_head : reinterpret_cast<int*>(&nd->pad_[lane == 6 ? 0 : lane == 7 ? LK_PAD_LIVE : LK_PAD_SPLIT]);
+                *wp = lane == 5 ? -1 : lane == 6 ? 0 : lane == 7 ? 1 : n0;   // list head | queue consumed | complete | n0 old points stay in the base block
+            }
         }
         // fit jobs of this root's row: [0] = this leaf's fit (if an event happened), [1 ..] none
         if (lane < LK_INLINE_GROUPS) {
@@ -865,6 +932,8 @@ __global__ void __launch_bounds__(LK_MB, W)
                 jb->leaf = root, jb->block = rblock, jb->decided = 1, jb->cnt = fit_count;
 #pragma unroll
                 for (int q = 0; q < 9; ++q) jb->s9[q] = sev[q];
+                const int nb = thin ? n0 : split0;   // the leaf's first nb points are the base block's
+                jb->base_block = nb > 0 ? cow_blk : -1, jb->n_base = nb > 0 ? nb : 0;
             } else {
                 jb->cnt = 0;
             }
@@ -875,6 +944,38 @@ __global__ void __launch_bounds__(LK_MB, W)
             for (int q = 0; q < 9; ++q) sr->s9[q] = sev[q];
             sr->n = fit_count;
         }
+    }
+}
+
+// Before anything reads a slot's private blocks as whole blocks (lk_overlay_export): the leaves the fast root pass left split get their base part.
+__global__ void __launch_bounds__(LK_MB) lk_ov_merge_split_kernel(LkMap base, LkOverlay ov, unsigned int slot) {
+    const LkMap pm = ov_slot_map(ov, slot);
+    const unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6, nwaves = (gridDim.x * LK_MB) >> 6;
+    for (unsigned int r = wave; r < ov.hash_cap; r += nwaves) {
+        if (keys[r] == LK_OV_EMPTY) continue;
+        lk_node_rec* nd = &pm.nodes[r];
+        const int nb = (int)nd->pad_[LK_PAD_SPLIT], cb = (int)nd->pad_[LK_PAD_COWBLK] - 1, blk = nd->block;
+        if (nd->pad_[LK_PAD_LIVE] == 0) continue;
+        const int bnode = (int)nd->pad_[LK_PAD_BASE] - 1;
+        if (bnode >= 0 && pm.planes[r].points_size == LK_PLANE_LAZY) {   // never refitted in this replay: everything but d / radius / flags is the base record's
+            if (lane < 16) {
+                uint4 v = reinterpret_cast<const uint4*>(&base.planes[bnode])[lane];
+                if (lane == 3) {
+                    const uint4 mine = reinterpret_cast<const uint4*>(&pm.planes[r])[3];
+                    v.x = mine.x, v.y = mine.y, v.z = mine.z;   // w = the base record's points_size
+                }
+                reinterpret_cast<uint4*>(&pm.planes[r])[lane] = v;
+            }
+        }
+        if (nb <= 0) continue;
+        if (blk >= 0 && cb >= 0) {
+            const double* sp = reinterpret_cast<const double*>(base.blocks[cb].pts);
+            double* dp = reinterpret_cast<double*>(pm.blocks[blk].pts);
+            for (int j = lane; j < min(nb, nd->npts) * 9; j += LK_WAVE) dp[j] = sp[j];
+        }
+        if (lane == 0) nd->pad_[LK_PAD_SPLIT] = 0;
     }
 }
 
@@ -900,6 +1001,153 @@ __global__ void __launch_bounds__(256) lk_ov_base_sums_kernel(LkMap base, unsign
         r.n = npts;
     }
     out[e.w] = r;
+}
+
+
+// ---------------------------------------------------------------- root pass of the batch replay, one LANE per point / per root (round 5)
+// The wave-per-root fast pass above is bound by VALU ISSUE: ~600 wave instructions per root - a third of them the fp64 covariance of the
+// new points - executed for the ~8 points a root queues, one eighth of the lanes.  This form splits the root pass by what it parallelises over:
+//   lk_ov_point_geom_kernel  one THREAD per bucket point (every lane busy): the point's world position and covariance (KILO.cc:216-230,
+//                            point_geom: the very expressions of every other pass), stored straight to its final place in the root's private
+//                            block - n0 + its rank among the root's queued points (input order = ascending index; the slot line is read for
+//                            the rank, its neighbours in the wave mostly read the same line).  Stores past the end of what the leaf finally
+//                            takes (a freeze) or into a leaf the generic pass re-does are the same bytes written again, or beyond npts.
+//   lk_ov_root_lane_kernel   one LANE per touched root: voxel_map.cc:186-204 literally, point after point, on the positions the first
+//                            kernel has just stored (read back, 24 B per point; the old points are covered by the leaf's moment sums) -
+//                            counters, refit events decided from prefix sums, freeze, the fit job, the sums.  Whatever is not a root leaf
+//                            that appends / refits / freezes goes to the generic wave-per-root pass as it was found (map.heavy).
+// Per root the second kernel issues ~40 small memory requests and a few hundred lane-instructions: 64 roots per wave instead of one.
+__global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                                                               size_t pts_slot_stride, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int slot = blockIdx.y;
+    const int root = ov.ptroot[(size_t)slot * ov.scan_cap + i];
+    if (root < 0) return;
+    const LkMap pm = ov_slot_map(ov, slot);
+    const lk_node_rec* nd = &pm.nodes[root];
+    const int4 cnt = reinterpret_cast<const int4*>(nd)[4];   // npts, new_points, state, block
+    const int m = (int)nd->pad_[0];
+    if (cnt.w < 0 || m > LK_SLOTS) return;                    // no block: not a leaf that takes points; a long queue: the generic pass
+    const float4* line = reinterpret_cast<const float4*>(pm.slots) + (size_t)root * LK_SLOTS;
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += (__float_as_int(line[j].w) < i) ? 1 : 0;
+    const int pos = cnt.x + rank;
+    if (pos >= LK_BLOCK_PTS) return;
+    BucketConst bc;
+    load_bucket_const(&filters[slot], pr, bc);
+    const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
+    const PointGeom gm = point_geom(p.x, p.y, p.z, bc, pr);
+    lk_pt_rec* d = &pm.blocks[cnt.w].pts[pos];
+    d->pw[0] = gm.p_w.x, d->pw[1] = gm.p_w.y, d->pw[2] = gm.p_w.z;
+    d->var[0] = gm.var.xx, d->var[1] = gm.var.xy, d->var[2] = gm.var.xz;
+    d->var[3] = gm.var.yy, d->var[4] = gm.var.yz, d->var[5] = gm.var.zz;
+}
+__global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    const unsigned int slot = blockIdx.y;
+    const LkMap map = ov_slot_map(ov, slot);
+    if (map.counters[LK_CTR_ERR]) return;
+    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
+    LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
+    const size_t job_stride = ov.hash_cap;
+    LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
+    const int thr = pr.layer_init_num[0];
+    for (int t = blockIdx.x * LK_WAVE + threadIdx.x; t < n_touched; t += gridDim.x * LK_WAVE) {
+        const int root = map.touched[t];
+        lk_node_rec* nd = &map.nodes[root];
+        const int4 cnt = reinterpret_cast<const int4*>(nd)[4];   // npts, new_points, state, block
+        const int4 qw = reinterpret_cast<const int4*>(nd)[6];    // pad_[0..3]: queued, ., ., LIVE
+        const int4 cw = reinterpret_cast<const int4*>(nd)[7];    // pad_[4..7]: BASE, COWBLK, SPLIT, .
+        const unsigned int rpf = map.planes[root].flags;
+        const int rlayer = nd->layer;
+        const int n0 = cnt.x, rnewp = cnt.y, rblock = cnt.w, m = qw.x, ov_live = qw.w, cow_blk = cw.y - 1, split0 = cw.z;
+        const unsigned int rst = (unsigned int)cnt.z;
+        const bool thin = ov_live == 2 && cow_blk >= 0;
+        const bool uninit = !(rst & LK_NODE_INIT_OCTO), lplane = (rpf & LK_PLANE_IS_PLANE) != 0, live = (rst & LK_NODE_UPDATE_ENABLE) != 0;
+        bool complex_root = m > LK_SLOTS || m <= 0 || !(uninit || (lplane && live)) || (rst & LK_NODE_PTS_DROPPED) != 0 || n0 + 1 >= LK_BLOCK_PTS || rlayer != 0 ||
+                            (ov_live == 2 && cow_blk < 0 && n0 > 0) || rblock < 0;
+        const bool may_refit = uninit ? (n0 + m > thr) : (rnewp + m > 5);
+        int cur = n0, newp = rnewp, fit_count = 0;
+        bool frozen = false, fitted = false;
+        double sq[9], sev[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sq[q] = 0.0, sev[q] = 0.0;
+        if (!complex_root) {
+            const lk_pt_rec* bpts = map.blocks[rblock].pts;
+            const int split_n = thin ? n0 : split0;   // points [0, split_n) of the leaf are the base block's
+            const lk_pt_rec* cpts = (split_n > 0 && cow_blk >= 0) ? base.blocks[cow_blk].pts : bpts;
+            auto add_point = [&](int j) {
+                const lk_pt_rec* q = (j < split_n ? cpts : bpts) + j;
+                const double x = q->pw[0], y = q->pw[1], z = q->pw[2];
+                sq[0] += x, sq[1] += y, sq[2] += z;
+                sq[3] += x * x, sq[4] += x * y, sq[5] += x * z, sq[6] += y * y, sq[7] += y * z, sq[8] += z * z;
+            };
+            if (may_refit) {   // the sums of the leaf's first sum_n points, then the old points behind them (normally none)
+                const LkLeafSum* sr = &sums[root];
+                int sum_n = sr->n;
+                if (sum_n < 0 || sum_n > n0) sum_n = 0;
+                if (sum_n > 0) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sq[q] = sr->s9[q];
+                }
+                for (int j = sum_n; j < n0; ++j) add_point(j);
+            }
+            int mode = uninit ? 0 : 1;
+            for (int j = 0; j < m && !frozen; ++j) {   // voxel_map.cc:186-204, one pushed point per step
+                if (may_refit) add_point(n0 + j);
+                const int m0 = mode;
+                cur += 1, newp += 1;
+                if (m0 == 0 ? cur > thr : newp > 5) {
+                    if (!ov_plane_decide(sq, cur, pr.planer_threshold)) {
+                        complex_root = true;   // a cut, or a plane that stops being one: the generic pass
+                        break;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sev[q] = sq[q];
+                    fit_count = cur, fitted = true, newp = 0;
+                    if (m0 == 0) {
+                        mode = 1;
+                        if (cur > pr.max_points_num) frozen = true;
+                    }
+                }
+                if (m0 == 1 && cur >= pr.max_points_num) frozen = true;
+            }
+        }
+        if (complex_root) {   // record, queue and sums untouched: the generic pass finds the root as the earlier passes left it
+            const unsigned int c = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
+            if (c < map.max_scan) map.heavy[2 * c] = root, map.heavy[2 * c + 1] = t;
+            else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
+            continue;
+        }
+        unsigned int nst = rst;
+        int nnpts = cur, nblock = rblock;
+        if (fitted) nst = (nst | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
+        if (frozen) {   // node_freeze (voxel_map.cc:199-203); the block is not handed out again before the next bucket: the fit still reads it
+            nst &= ~LK_NODE_UPDATE_ENABLE;
+            nnpts = 0, newp = 0, nblock = -1;
+            retire_block(map, rblock);
+        }
+        reinterpret_cast<int4*>(nd)[4] = make_int4(nnpts, newp, (int)nst, nblock);
+        nd->list_head = -1;
+        reinterpret_cast<int4*>(nd)[6] = make_int4(0, qw.y, qw.z, 1);          // queue consumed; complete
+        if (thin) nd->pad_[LK_PAD_SPLIT] = (unsigned int)n0;                    // the n0 old points stay in the base block
+#pragma unroll
+        for (int g = 1; g < LK_INLINE_GROUPS; ++g) jobs[(size_t)g * job_stride + t].cnt = 0;
+        LkFitJob* jb = &jobs[t];
+        if (fitted) {
+            const int nb = thin ? n0 : split0;
+            *reinterpret_cast<int4*>(jb) = make_int4(root, rblock, fit_count, 1);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) jb->s9[q] = sev[q];
+            jb->base_block = nb > 0 ? cow_blk : -1, jb->n_base = nb > 0 ? nb : 0;
+            LkLeafSum* sr = &sums[root];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) sr->s9[q] = sev[q];
+            sr->n = fit_count;
+        } else {
+            jb->cnt = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- the ordered insert, slot = blockIdx.y
