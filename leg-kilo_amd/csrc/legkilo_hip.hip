@@ -3251,17 +3251,14 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
-    // root pass: the fast path (lk_ov_root_fast_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
+    // root pass: the fast path (lk_ov_point_geom_kernel + lk_ov_root_lane_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
     // (LEGKILO_OV_FAST=0: the generic pass over every touched root, round 4's path; A/B)
-    // LEGKILO_OV_FAST: 2 (default) = the fast path as one thread per point (geometry) + one lane per root (lk_ov_point_geom_kernel,
-    // lk_ov_root_lane_kernel); 1 = the fast path one wave per root (lk_ov_root_fast_kernel); 0 = the generic pass only
-    static const int ov_fast_mode = getenv("LEGKILO_OV_FAST") ? atoi(getenv("LEGKILO_OV_FAST")) : 2;
-    static const bool ov_fast = ov_fast_mode != 0;
+    // LEGKILO_OV_FAST: 1 (default) = the fast path - one thread per point (geometry) + one lane per root (lk_ov_point_geom_kernel,
+    // lk_ov_root_lane_kernel), the generic pass for what they leave; 0 = the generic pass over every touched root (round 4's path; A/B)
+    static const bool ov_fast = getenv("LEGKILO_OV_FAST") == nullptr || atoi(getenv("LEGKILO_OV_FAST")) != 0;
     static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // generic pass without the fit: 184 VGPRs at 2 waves, 168 at 3
     const auto root_kernel = ov_fast ? (root_waves >= 4 ? lk_ov_insert_root_kernel<4, true> : root_waves == 3 ? lk_ov_insert_root_kernel<3, true> : lk_ov_insert_root_kernel<2, true>)
                                      : (root_waves >= 4 ? lk_ov_insert_root_kernel<4, false> : root_waves == 3 ? lk_ov_insert_root_kernel<3, false> : lk_ov_insert_root_kernel<2, false>);
-    static const int fast_waves = getenv("LEGKILO_OV_FAST_WAVES") ? atoi(getenv("LEGKILO_OV_FAST_WAVES")) : 4;
-    const auto fast_kernel = fast_waves >= 5 ? lk_ov_root_fast_kernel<5> : fast_waves == 4 ? lk_ov_root_fast_kernel<4> : lk_ov_root_fast_kernel<3>;
     if (ov_fast) LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
     static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
@@ -3312,15 +3309,12 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         // (measured at 1024 slots x 20 000-point buckets, workgroups per slot: copy-on-write 2.8 / 6.6 / 12.2 ms per batch at 4 / 16 / 32 - a wave takes 64
         // roots, more waves only find nothing to do; root pass 12.8 / 11.0 / 11.7 - a wave works through its roots one after the other)
         const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
-        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(ov_fast ? lk_ov_materialise_kernel<true> : lk_ov_materialise_kernel<false>, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        if (ov_fast_mode >= 2) {
+        if (ov_fast) {
             LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, Sg), dim3(256), 0, st, ov, h->pr, fl, pts, n_pts, nb));
             static const int lane_blocks = getenv("LEGKILO_OV_LANE_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_LANE_BLOCKS"))) : 0;
             LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(lane_blocks ? lane_blocks : std::max(4, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
-        } else if (ov_fast) {
-            LAUNCH(h, "ov_root_fast", hipLaunchKernelGGL(fast_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl));
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
         } else {
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));

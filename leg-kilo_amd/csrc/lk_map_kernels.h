@@ -720,7 +720,7 @@ static_assert(sizeof(LkGroup) == 64, "group descriptor must be 64 B");
 struct LkFitJob {   // 96 B: a plane fit the overlay replay's root pass leaves to lk_ov_fit_lane_kernel (apply_leaf<DEFER>)
     int leaf, block, cnt, decided;   // cnt = points of the leaf's last refit event (0: no fit), block = where they are, decided = is_plane of that event
     double s9[9];                    // its moment sums (sum p, sum p p^T)
-    int base_block, n_base;          // a SPLIT leaf (lk_ov_root_fast_kernel): its first n_base points are in the base map's block base_block; else n_base = 0
+    int base_block, n_base;          // a SPLIT leaf (lk_ov_root_lane_kernel): its first n_base points are in the base map's block base_block; else n_base = 0
 };
 static_assert(sizeof(LkFitJob) == 96, "fit job must be 96 B");
 struct LeafInfo {
@@ -1029,10 +1029,11 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 // block in one go (light roots and roots that are one in-place leaf group: nearly all); any other path copies them first.
 #define LK_PAD_LIVE 3     // lk_node_rec::pad_[3] of a PRIVATE root record: 0 not in the slot's map yet, 1 complete, 2 thin
 #define LK_PAD_COWBLK 5   // lk_node_rec::pad_[5] of a thin / split private root: 1 + id of the BASE map's point block that holds its old points
-#define LK_PAD_SPLIT 6    // lk_node_rec::pad_[6] of a private root leaf the FAST root pass (lk_ov_root_fast_kernel) has appended to without copying its old
+#define LK_PAD_SUMSRC 7   // lk_node_rec::pad_[7] of a private root: where its moment sums (LkLeafSum) are - 0 its own record, 1 the base leaf's, 2 none yet
+#define LK_PAD_SPLIT 6    // lk_node_rec::pad_[6] of a private root leaf the FAST root pass (lk_ov_root_lane_kernel) has appended to without copying its old
                           // points: the first pad_[6] points of the leaf still are the base block's (COWBLK - 1), points pad_[6] .. npts-1 sit at their own
                           // index in the private block.  0 = the private block is complete.  The generic passes merge such a root before they touch it
-// CPLX (overlay replay): the work list is not the touched list but what the fast root pass (lk_ov_root_fast_kernel) has left over -
+// CPLX (overlay replay): the work list is not the touched list but what the fast root pass (lk_ov_root_lane_kernel) has left over -
 // map.heavy = {root, index in the touched list} pairs, counter LK_CTR_HEAVY; the fit jobs stay indexed by the touched-list position.
 template <bool FROM_PV, bool OV = false, bool CPLX = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,

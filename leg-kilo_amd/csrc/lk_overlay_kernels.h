@@ -72,7 +72,7 @@ struct LkOverlay {
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
     unsigned int* frozen;        // [bit_words], shared by all slots: bit c = the BASE map's voxel at grid cell c is a frozen leaf (lk_ov_frozen_bits_kernel)
     struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
-    struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_fast_kernel)
+    struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_lane_kernel)
     struct LkLeafSum* base_sums; // [base max_nodes], shared: the same for the BASE map's root leaves, once per replay (lk_ov_base_sums_kernel)
     int* cplx;                   // [S][2 * scan_cap]: {root, index in the touched list} of the roots the fast root pass leaves to the generic one
     int* ptroot;                 // [S][scan_cap]: per bucket point, the private root it was queued on in a slot line (-1: dropped, or queued in the overflow list)
@@ -417,6 +417,12 @@ __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base,
 //     points in this pass (one voxel after the other, two dependent round trips each) took 7.1 ms of a 33 ms batch;
 //   * a base voxel WITH children (a cut voxel): its octree is copied node by node (ov_copy_node), all lanes on one voxel.
 // Point blocks are allocated with ONE bump of the block counter per chunk.  Then the key's bit is set for the residual pass.
+// LEAN (the fast root path, lk_ov_root_lane_kernel): a childless base voxel's private copy is its NODE record and one 16-B piece of its plane
+// record (d, radius, flags; points_size = LK_PLANE_LAZY) - nothing else.  Its match record, its moment sums and its "has a private root" bit
+// for the residual pass are not made here: until the leaf's plane is fitted again the base map's plane IS the scan's plane, so the residual
+// pass keeps matching the base grid cell (the bit is set by the root pass when it refits the leaf or hands the root to the generic pass, which
+// also gets the match record made first); the sums are read from the base map's (LK_PAD_SUMSRC).  35 -> 15 memory requests per new root.
+template <bool LEAN>
 __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
@@ -485,21 +491,10 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             pm.planes[my_root].flags = 0;
             pm.match[my_root].flags = 0;
         }
-        // the root's moment-sum prefix (lk_ov_root_fast_kernel): the base leaf's (made once per replay) for a childless base voxel, none otherwise
         if (need) {
             pm.nodes[my_root].pad_[LK_PAD_SPLIT] = 0;   // (a word of the previous replay may still be there)
-            LkLeafSum* sr = &ov.sums[(size_t)slot * ov.hash_cap + my_root];
-            if (has_base && childless) {
-                const int4* bs = reinterpret_cast<const int4*>(&ov.base_sums[my_base - 1]);
-                int4* ds = reinterpret_cast<int4*>(sr);
-                int4 tmp[5];   // all five loads first: a store between them would hold the next load back (the two records may alias, for all the compiler knows)
-#pragma unroll
-                for (int c = 0; c < 5; ++c) tmp[c] = bs[c];
-#pragma unroll
-                for (int c = 0; c < 5; ++c) ds[c] = tmp[c];
-            } else {
-                sr->n = 0;
-            }
+            // where the root's moment sums are (lk_ov_root_lane_kernel): the base leaf's, made once per replay, for a childless base voxel; none otherwise
+            pm.nodes[my_root].pad_[LK_PAD_SUMSRC] = (has_base && childless) ? 1u : 2u;
         }
         // childless base voxels: the node record by the root's own lane (the queue fields list_head / pad_[] are the re-projection pass's) ...
         const bool pending = thin && s_block >= 0 && s_npts > 0;
@@ -510,11 +505,17 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
             pm.nodes[my_root].key[0] = rec[5].x, pm.nodes[my_root].key[1] = rec[5].y, pm.nodes[my_root].key[2] = rec[5].z;
             pm.nodes[my_root].pad_[LK_PAD_COWBLK] = pending ? (unsigned int)(s_block + 1) : 0u;
         }
-        // ... and their match records (9 pieces of 16 B) as one flat list over the chunk's thin voxels, five loads in flight per lane.  The 256-B
-        // PLANE record is not copied (round 5): every reader on the replay's path wants its flags word only, which the match record carries -
-        // the lane that copies match piece 3 {d, radius, flags, .} also writes plane piece 3 {d, radius, flags, points_size = LK_PLANE_LAZY}.
-        // A fit rewrites the whole record; lk_ov_merge_split_kernel fetches the base map's record for an export of a voxel that was never refitted
-        {
+        // ... and (not LEAN) their match records (9 pieces of 16 B) as one flat list over the chunk's thin voxels, five loads in flight per lane.
+        // The 256-B PLANE record is never copied (round 5): every reader on the replay's path wants its flags word only - plane piece 3
+        // {d, radius, flags, points_size = LK_PLANE_LAZY} is written, a fit rewrites the whole record, lk_ov_merge_split_kernel fetches the base
+        // map's record for an export of a voxel that was never refitted
+        if (LEAN) {
+            if (thin) {
+                uint4 v = reinterpret_cast<const uint4*>(&base.planes[my_base - 1])[3];
+                v.w = (unsigned int)LK_PLANE_LAZY;
+                reinterpret_cast<uint4*>(&pm.planes[my_root])[3] = v;
+            }
+        } else {
             const unsigned long long thin_mask = __ballot(thin);
             const int n_thin = __popcll(thin_mask);
             const int pos = thin ? __popcll(thin_mask & ((1ull << lane) - 1ull)) : 63;   // n_thin == 64: every lane is a member
@@ -555,7 +556,10 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
         if (need) {
             pm.nodes[my_root].pad_[LK_PAD_LIVE] = pending ? 2u : 1u;
             unsigned int cell;
-            if (ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
+            // LEAN: only a voxel the base map does not have at all gets its bit here - its mere EXISTENCE changes what the residual pass does
+            // (a point whose home voxel exists but gives no match tries one neighbour voxel, KILO.cc:152-178; without a home voxel it
+            // does not), plane or no plane.  A copied voxel exists in the base map, too: its bit waits for its first change
+            if ((!LEAN || my_base == 0) && ov_cell_of(base, key, &cell)) atomicOr(&bits[cell >> 5], 1u << (cell & 31u));
         }
         const int n_new = __popcll(__ballot(need));
         if (lane == 0 && n_new) atomicAdd(&pm.counters[LK_CTR_ROOTS], (unsigned int)n_new);
@@ -646,7 +650,7 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
             const double invA = 1.0 / (cnt * (fit.emin - fit.emid)), invB = 1.0 / (cnt * (fit.emin - fit.emax));
             const double invn = 1.0 / cnt;
             const lk_pt_rec* __restrict__ bp = pm.blocks[block].pts;
-            // a split leaf (lk_ov_root_fast_kernel): its first n_base points are still the base map's
+            // a split leaf (lk_ov_root_lane_kernel): its first n_base points are still the base map's
             const int n_base = job->n_base;
             const lk_pt_rec* __restrict__ bb = n_base > 0 ? base.blocks[job->base_block].pts : bp;
             double sa[3] = {0.0, 0.0, 0.0}, sb[3] = {0.0, 0.0, 0.0}, saa = 0.0, sab = 0.0, sbb = 0.0, sV[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -701,17 +705,19 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
 // two, maybe freezes.  The generic pass (dev_insert_root<.., OV>) spends its time - 168 VGPRs, three waves per SIMD, 5.5 GB per launch -
 // on what that case does not need: every old point of the leaf re-read (9 doubles at a 72-B stride per lane: 36 cache lines per load
 // instruction for 512 B) and, for a voxel seen for the first time, written back the same way; the per-lane walk, the grouping, the
-// hand-over lists.  This pass does the common case only and leaves everything else UNTOUCHED on a list for the generic pass
-// (map.heavy / LK_CTR_HEAVY -> lk_ov_insert_root_kernel<.., CPLX>):
+// hand-over lists.  The fast path (lk_ov_point_geom_kernel + lk_ov_root_lane_kernel below) does the common case only and leaves
+// everything else UNTOUCHED on a list for the generic pass (map.heavy / LK_CTR_HEAVY -> lk_ov_insert_root_kernel<.., CPLX>):
 //   * the leaf's moment sums are kept per root (LkLeafSum: sums of its first n points, updated at every refit event; for a base voxel
-//     computed once per replay, lk_ov_base_sums_kernel, and copied with the record).  A refit event's plane test needs
-//     prefix + the points behind it - a handful, usually only the new ones.  The old points are not read at all;
-//   * a voxel seen for the first time ("thin": its old points still in the base map's block) gets them as a FLAT copy of n0 x 72 bytes in
-//     16-B pieces, coalesced, independent of everything else the wave does;
-//   * per root: record + plane flags + slot line + sums requested one root ahead (the same pipeline as the generic pass); the simulation
-//     of voxel_map.cc:186-204 is side-effect free, so a root that turns out to need the generic code (a cut: init_octo_tree says "not a
-//     plane"; a plane that stops being one; more than a slot line of points; a tree below the root) is handed over as it was found.
-// The fit that ends a leaf's bucket is left to lk_ov_fit_lane_kernel as before (96-B job).
+//     computed once per replay, lk_ov_base_sums_kernel).  A refit event's plane test needs prefix + the points behind it - a handful,
+//     usually only the new ones.  The old points are not read at all;
+//   * a voxel seen for the first time ("thin") keeps its old points in the base map's block: the leaf becomes SPLIT (LK_PAD_SPLIT);
+//   * the simulation of voxel_map.cc:186-204 is side-effect free, so a root that turns out to need the generic code (a cut:
+//     init_octo_tree says "not a plane"; a plane that stops being one; more than a slot line of points; a tree below the root) is
+//     handed over as it was found.
+// The fit that ends a leaf's bucket is left to lk_ov_fit_eig_kernel / lk_ov_fit_lane_kernel (96-B job).
+// (First version of the round, measured and replaced: the same fast path one WAVE per root - 128 VGPRs, four waves per SIMD, real
+// one-root-ahead requests - 5.6 ms per batch against the generic pass's 10.8: bound by VALU issue, ~600 wave instructions per root for
+// the ~8 lanes a root's points occupy.  profiles/EXPERIMENTS.md.)
 __device__ __forceinline__ bool ov_plane_decide(const double* s, int count, float planer_threshold) {   // plane_test_regs<decide_only>: lambda_min < t
     const double n = (double)count;
     const double c0 = s[0] / n, c1 = s[1] / n, c2 = s[2] / n;
@@ -722,231 +728,6 @@ __device__ __forceinline__ bool ov_plane_decide(const double* s, int count, floa
     const double m3 = b11 * (b22 * b33 - byz * byz) - bxy * (bxy * b33 - byz * bxz) + bxz * (bxy * byz - b22 * bxz);
     return !(b11 > 0.0 && m2 > 0.0 && m3 > 0.0);
 }
-#ifndef LK_FAST_SLOTS
-#define LK_FAST_SLOTS 8   // slot-line entries (16 B each) requested with a root's record: one 128-B line (a power of two)
-#endif
-#ifndef LK_FAST_X
-#define LK_FAST_X 0   // attribution builds only (results wrong): 1 no point covariance, 2 no wave sums
-#endif
-template <int W>
-__global__ void __launch_bounds__(LK_MB, W)
-    lk_ov_root_fast_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters) {
-    const unsigned int slot = blockIdx.y;
-    const LkMap map = ov_slot_map(ov, slot);
-    if (map.counters[LK_CTR_ERR]) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * LK_MB) >> 6);
-    const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
-    LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
-    const size_t job_stride = ov.hash_cap;
-    LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
-    BucketConst bc;
-    load_bucket_const(&filters[slot], pr, bc);
-    // Requested one root ahead: the node record (lane k: 16-B piece k & 7), the sums record (lane k: double k, lane >= 9: its point count), the
-    // plane flags, the first line of the slot points (lane k: point k & 7).  EVERY lane loads, from clamped addresses, and nothing looks at
-    // the registers before the next iteration: a load behind a lane test (or a default value merged in) makes the compiler wait for it on the
-    // spot - the first version of this loop had four memory round trips in a row per root where it was meant to have none.
-    // The touched list is read 64 entries at a time (lane k: the id k + 1 roots ahead) instead of one dependent load per root.
-    int pf_flags = 0, pf_slot = 0x7fffffff;
-    float pf_px = 0.f, pf_py = 0.f, pf_pz = 0.f;
-    int4 pf_rec = make_int4(0, 0, 0, 0);
-    int2 pf_sum = make_int2(0, 0);   // lane k: double k of the root's sums record (k < 9), lane 9: its point count
-    auto prefetch_record = [&](int r) {
-        pf_rec = reinterpret_cast<const int4*>(&map.nodes[r])[lane & 7];
-        pf_sum = reinterpret_cast<const int2*>(&sums[r])[min(lane, 9)];
-        pf_flags = (int)map.planes[r].flags;
-        const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)r * LK_SLOTS + (lane & (LK_FAST_SLOTS - 1))];
-        pf_px = q.x, pf_py = q.y, pf_pz = q.z, pf_slot = __float_as_int(q.w);
-    };
-    if (wave >= n_touched) return;
-    int next_root = bcast0(map.touched[wave]);
-    int ahead = map.touched[min(wave + (lane + 1) * nwaves, n_touched - 1)];   // ids of the roots 1 .. 64 iterations ahead
-    prefetch_record(next_root);
-    int it = 0;
-    for (int t = wave; t < n_touched; t += nwaves, ++it) {
-        float cpx = pf_px, cpy = pf_py, cpz = pf_pz;
-        int slot_idx = pf_slot;
-        const int4 rec = pf_rec;
-        const int2 sumv = pf_sum;
-        const int root = next_root;
-        const unsigned int rpf = (unsigned int)bcast0(pf_flags);
-        const int rlayer = __builtin_amdgcn_readlane(rec.w, 3);
-        const int n0 = __builtin_amdgcn_readlane(rec.x, 4), rnewp = __builtin_amdgcn_readlane(rec.y, 4);
-        const unsigned int rst = (unsigned int)__builtin_amdgcn_readlane(rec.z, 4);
-        int rblock = __builtin_amdgcn_readlane(rec.w, 4);
-        const int m = __builtin_amdgcn_readlane(rec.x, 6);                      // pad_[0]: points queued in this bucket
-        if (m > LK_FAST_SLOTS && lane >= LK_FAST_SLOTS && lane < LK_SLOTS) {    // more points than the line requested ahead holds
-            const float4 q = reinterpret_cast<const float4*>(map.slots)[(size_t)root * LK_SLOTS + lane];
-            cpx = q.x, cpy = q.y, cpz = q.z, slot_idx = __float_as_int(q.w);
-        }
-        const int ov_live = __builtin_amdgcn_readlane(rec.w, 6);               // pad_[LK_PAD_LIVE]
-        const int cow_blk = __builtin_amdgcn_readlane(rec.y, 7) - 1;           // pad_[LK_PAD_COWBLK] - 1
-        const int split0 = __builtin_amdgcn_readlane(rec.z, 7);                // pad_[LK_PAD_SPLIT]
-        int sum_n = __builtin_amdgcn_readlane(sumv.x, 9);
-        const bool thin = ov_live == 2 && cow_blk >= 0;
-        const bool uninit = !(rst & LK_NODE_INIT_OCTO), lplane = (rpf & LK_PLANE_IS_PLANE) != 0, live = (rst & LK_NODE_UPDATE_ENABLE) != 0;
-        // ---- is this the common case?  (everything here is uniform over the wave)
-        bool complex_root = m > LK_SLOTS || m <= 0 || !(uninit || (lplane && live)) || (rst & LK_NODE_PTS_DROPPED) != 0 || n0 + 1 >= LK_BLOCK_PTS || rlayer != 0 ||
-                            (ov_live == 2 && cow_blk < 0 && n0 > 0) || rblock < 0;   // (the copy-on-write pass gives every root it creates a block)
-        if (sum_n < 0 || sum_n > n0) sum_n = 0;
-        const int thr = pr.layer_init_num[0];
-        const bool may_refit = uninit ? (n0 + m > thr) : (rnewp + m > 5);
-        const int U = may_refit ? n0 - sum_n : 0;     // old points behind the sums' prefix: read (pw only) when a refit event may need them
-        if (U + m > LK_WAVE) complex_root = true;
-        // the old points behind the sums' prefix, lanes m .. m+U-1 (normally none).  These loads - like the slot points of a long queue above -
-        // are issued BEFORE the next root's request: memory operations complete in order, so whoever waits for the youngest one waits for all,
-        // and a wait the compiler places at a join is paid on the path that did not load, too
-        double ppw[3] = {0.0, 0.0, 0.0};
-        if (!complex_root && lane >= m && lane < m + U) {
-            const int oj = sum_n + (lane - m);   // (a split leaf's sums cover at least its base part, so these normally are private points)
-            const lk_pt_rec* q = ((thin || oj < split0) ? base.blocks[cow_blk].pts : map.blocks[rblock].pts) + oj;
-            ppw[0] = q->pw[0], ppw[1] = q->pw[1], ppw[2] = q->pw[2];
-        }
-        next_root = __builtin_amdgcn_readlane(ahead, it & 63);
-        prefetch_record(t + nwaves < n_touched ? next_root : root);
-        if ((it & 63) == 63) ahead = map.touched[min(t + (lane + 2) * nwaves, n_touched - 1)];
-        int cur = n0, newp = rnewp, consumed = 0, fit_count = 0;
-        bool frozen = false, fitted = false;
-        double sev[9];    // moment sums of the last refit event (uniform)
-#pragma unroll
-        for (int q = 0; q < 9; ++q) sev[q] = 0.0;
-        if (!complex_root) {
-            // the queued points in input order (= ascending index): rank among the m, then a forward permute - lanes 0 .. m-1 hold the new
-            // points in order, lanes m .. m+U-1 the old points behind the prefix
-            const int myidx = (lane < m) ? slot_idx : 0x7fffffff;
-            int rank = 0;
-            for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(myidx, j) < myidx) ? 1 : 0;
-            const int dstl = ((lane < m) ? rank : lane) << 2;
-            float4 p4;
-            p4.x = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpx)));
-            p4.y = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpy)));
-            p4.z = __int_as_float(__builtin_amdgcn_ds_permute(dstl, __float_as_int(cpz)));
-            // ---- stores that do no harm if the root turns out to need the generic pass after all (it writes the same bytes again):
-            // the old points of a voxel seen for the first time, as a FLAT copy of 72 n0 bytes in 16-B pieces (+ one 8-B tail when n0 is
-            // odd); the new points behind them, each by its lane (a freeze ignores the ones past it: they lie beyond npts)
-            // a voxel seen for the first time keeps its old points WHERE THEY ARE, in the base map's block: the leaf becomes "split"
-            // (LK_PAD_SPLIT = n0 old points in the base block, everything appended from now on at its own index in the private block).
-            // This pass never needs them (sums), the plane fits read them from the base block - which all scans of the batch share, so
-            // they come out of the L2 / Infinity Cache - and whoever else wants the block whole merges it first (dev_insert_root's
-            // cow_finalise, lk_ov_merge_split_kernel before an export).  Copying them was 17 GB of the batch's 57.
-            lk_pt_rec* dstp = map.blocks[rblock].pts;
-            if (lane < m && n0 + lane < LK_BLOCK_PTS) {
-                // point_geom's expressions (KILO.cc:126-140), evaluated in three phases with the results stored as they come - the
-                // full inline form keeps ~80 registers alive at once and cost this pass its fourth wave per SIMD
-                lk_pt_rec* d = &dstp[n0 + lane];
-                const V3 pb = V3{(double)p4.x, (double)p4.y, (double)p4.z};
-                const V3 e = mat3_mul_v(pr.ext_R, pb);
-                const V3 p_i = V3{e.x + pr.ext_T[0], e.y + pr.ext_T[1], e.z + pr.ext_T[2]};
-                {
-                    const V3 w = mat3_mul_v(bc.R, p_i);
-                    ppw[0] = w.x + bc.p[0], ppw[1] = w.y + bc.p[1], ppw[2] = w.z + bc.p[2];
-                    d->pw[0] = ppw[0], d->pw[1] = ppw[1], d->pw[2] = ppw[2];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                S3 va = congruence(bc.RE, calc_body_cov(pb, pr));
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    double K[9], RK[9];
-                    skew3(p_i, K);
-                    mat3_mul(bc.R, K, RK);
-                    const S3 vb = congruence(RK, bc.Prr);
-                    va = S3{va.xx + vb.xx + bc.Ppp.xx, va.xy + vb.xy + bc.Ppp.xy, va.xz + vb.xz + bc.Ppp.xz,
-                            va.yy + vb.yy + bc.Ppp.yy, va.yz + vb.yz + bc.Ppp.yz, va.zz + vb.zz + bc.Ppp.zz};
-                }
-                d->var[0] = va.xx, d->var[1] = va.xy, d->var[2] = va.xz, d->var[3] = va.yy, d->var[4] = va.yz, d->var[5] = va.zz;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- the register simulation of voxel_map.cc:186-204 for a root leaf (apply_leaf's loop, modes 0 and 1 only): every refit event
-            // must say "plane", anything else belongs to the generic pass
-            int mode = uninit ? 0 : 1;
-            while (consumed < m && !frozen && !complex_root) {
-                const int rem = m - consumed;
-                const int m0 = mode;
-                const int lim = m0 == 0 ? thr + 1 - cur : min(6 - newp, pr.max_points_num - cur);
-                const int k = max(min(rem, lim), 1);
-                cur += k, newp += k, consumed += k;
-                if (m0 == 0 ? cur > thr : newp > 5) {
-                    const bool act = lane < cur - n0 || (lane >= m && lane < m + U);
-                    double sq[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) sq[q] = 0.0;
-                    if (act) {
-                        sq[0] = ppw[0], sq[1] = ppw[1], sq[2] = ppw[2];
-                        sq[3] = ppw[0] * ppw[0], sq[4] = ppw[0] * ppw[1], sq[5] = ppw[0] * ppw[2];
-                        sq[6] = ppw[1] * ppw[1], sq[7] = ppw[1] * ppw[2], sq[8] = ppw[2] * ppw[2];
-                    }
-                    if (sum_n > 0) {   // the prefix: lane q of the request holds double q of the record and adds it to its own partial sum
-                        const double mine = __hiloint2double(sumv.y, sumv.x);
-#pragma unroll
-                        for (int q = 0; q < 9; ++q)
-                            if (lane == q) sq[q] += mine;
-                    }
-#if !(LK_FAST_X & 2)
-                    wave_sum_n<9>(sq);
-#endif
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) sev[q] = sq[q];
-                    if (!ov_plane_decide(sev, cur, pr.planer_threshold)) {
-                        complex_root = true;   // a cut (init_octo_tree on a non-plane) or a plane that stops being one: generic code
-                        break;
-                    }
-                    fit_count = cur, fitted = true, newp = 0;
-                    if (m0 == 0) {
-                        mode = 1;
-                        if (cur > pr.max_points_num) frozen = true;
-                    }
-                }
-                if (m0 == 1 && cur >= pr.max_points_num) frozen = true;
-            }
-        }
-        if (complex_root) {   // its record, queue and sums untouched: the generic pass finds the root as the re-projection and copy-on-write passes left it
-            if (lane == 0) {
-                const unsigned int c = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
-                if (c < map.max_scan) map.heavy[2 * c] = root, map.heavy[2 * c + 1] = t;
-                else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
-            }
-            continue;
-        }
-        // ---- commit: counters, state, queue words, the fit job, the sums
-        unsigned int nst = rst;
-        int nnpts = cur, nblock = rblock;
-        if (fitted) nst = (nst | LK_NODE_INIT_OCTO) & ~LK_NODE_OCTO_STATE;
-        if (frozen) {   // node_freeze: update_enable_ = false, temp_points_ swapped away, new_points_ = 0 (voxel_map.cc:199-203)
-            nst &= ~LK_NODE_UPDATE_ENABLE;
-            nnpts = 0, newp = 0, nblock = -1;
-            if (lane == 0) retire_block(map, rblock);   // not handed out again before the next bucket: the fit below still reads it
-        }
-        // the record: the counters as one 16-B piece (lane 4), the queue words one lane each (the request's registers are long dead)
-        {
-            lk_node_rec* nd = &map.nodes[root];
-            if (lane == 4) reinterpret_cast<int4*>(nd)[4] = make_int4(nnpts, newp, (int)nst, nblock);
-            if (lane >= 5 && lane <= (thin ? 8 : 7)) {
-                int* wp = lane == 5 ? &nd->list_head : reinterpret_cast<int*>(&nd->pad_[lane == 6 ? 0 : lane == 7 ? LK_PAD_LIVE : LK_PAD_SPLIT]);
-                *wp = lane == 5 ? -1 : lane == 6 ? 0 : lane == 7 ? 1 : n0;   // list head | queue consumed | complete | n0 old points stay in the base block
-            }
-        }
-        // fit jobs of this root's row: [0] = this leaf's fit (if an event happened), [1 ..] none
-        if (lane < LK_INLINE_GROUPS) {
-            LkFitJob* jb = &jobs[(size_t)lane * job_stride + t];
-            if (lane == 0 && fitted) {
-                jb->leaf = root, jb->block = rblock, jb->decided = 1, jb->cnt = fit_count;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) jb->s9[q] = sev[q];
-                const int nb = thin ? n0 : split0;   // the leaf's first nb points are the base block's
-                jb->base_block = nb > 0 ? cow_blk : -1, jb->n_base = nb > 0 ? nb : 0;
-            } else {
-                jb->cnt = 0;
-            }
-        }
-        if (fitted && lane == 0) {   // the sums now cover the first fit_count points
-            LkLeafSum* sr = &sums[root];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) sr->s9[q] = sev[q];
-            sr->n = fit_count;
-        }
-    }
-}
-
 // Before anything reads a slot's private blocks as whole blocks (lk_overlay_export): the leaves the fast root pass left split get their base part.
 __global__ void __launch_bounds__(LK_MB) lk_ov_merge_split_kernel(LkMap base, LkOverlay ov, unsigned int slot) {
     const LkMap pm = ov_slot_map(ov, slot);
@@ -1058,7 +839,9 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
         const int4 cnt = reinterpret_cast<const int4*>(nd)[4];   // npts, new_points, state, block
         const int4 qw = reinterpret_cast<const int4*>(nd)[6];    // pad_[0..3]: queued, ., ., LIVE
         const int4 cw = reinterpret_cast<const int4*>(nd)[7];    // pad_[4..7]: BASE, COWBLK, SPLIT, .
-        const unsigned int rpf = map.planes[root].flags;
+        const uint4 pl3 = reinterpret_cast<const uint4*>(&map.planes[root])[3];   // d, radius, flags, points_size
+        const unsigned int rpf = pl3.z;
+        const bool lazy_plane = (int)pl3.w == LK_PLANE_LAZY;   // plane AND match record are still the base map's (lk_ov_materialise_kernel<LEAN>)
         const int rlayer = nd->layer;
         const int n0 = cnt.x, rnewp = cnt.y, rblock = cnt.w, m = qw.x, ov_live = qw.w, cow_blk = cw.y - 1, split0 = cw.z;
         const unsigned int rst = (unsigned int)cnt.z;
@@ -1083,8 +866,8 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
                 sq[3] += x * x, sq[4] += x * y, sq[5] += x * z, sq[6] += y * y, sq[7] += y * z, sq[8] += z * z;
             };
             if (may_refit) {   // the sums of the leaf's first sum_n points, then the old points behind them (normally none)
-                const LkLeafSum* sr = &sums[root];
-                int sum_n = sr->n;
+                const LkLeafSum* sr = cw.w == 1 ? &ov.base_sums[cw.x - 1] : &sums[root];   // LK_PAD_SUMSRC: 1 the base leaf's, 0 the root's own, 2 none
+                int sum_n = cw.w == 2 ? 0 : sr->n;
                 if (sum_n < 0 || sum_n > n0) sum_n = 0;
                 if (sum_n > 0) {
 #pragma unroll
@@ -1113,7 +896,20 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
                 if (m0 == 1 && cur >= pr.max_points_num) frozen = true;
             }
         }
+        // the residual pass of the next bucket has to look at this scan's own voxel from now on: the generic pass may change its planes, a fit will
+        if (complex_root || fitted) {
+            int key[3];
+            ov_unpack_key(ov.keys[(size_t)slot * ov.hash_cap + root], key);   // (the table entry IS the key; a copied node record's key words are whatever the base record held)
+            unsigned int cell;
+            if (ov_cell_of(base, key, &cell)) atomicOr(&ov.bits[(size_t)slot * ov.bit_words + (cell >> 5)], 1u << (cell & 31u));
+        }
         if (complex_root) {   // record, queue and sums untouched: the generic pass finds the root as the earlier passes left it
+            if (lazy_plane && cw.x > 0) {   // ... with the match record its residual-side twin reads made private first (lk_ov_materialise_kernel<LEAN> left it out)
+                const uint4* sp = reinterpret_cast<const uint4*>(&base.match[cw.x - 1]);
+                uint4* dp = reinterpret_cast<uint4*>(&map.match[root]);
+#pragma unroll 1
+                for (int c = 0; c < 9; ++c) dp[c] = sp[c];   // (a rare path: piece after piece, no registers held for it)
+            }
             const unsigned int c = atomicAdd(&map.counters[LK_CTR_HEAVY], 1u);
             if (c < map.max_scan) map.heavy[2 * c] = root, map.heavy[2 * c + 1] = t;
             else atomicOr(&map.counters[LK_CTR_ERR], LK_E_SCRATCH_FULL);
@@ -1144,6 +940,7 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
 #pragma unroll
             for (int q = 0; q < 9; ++q) sr->s9[q] = sev[q];
             sr->n = fit_count;
+            if (cw.w != 0) nd->pad_[LK_PAD_SUMSRC] = 0;   // the root has its own sums record now
         } else {
             jb->cnt = 0;
         }
