@@ -57,7 +57,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X datasheet: peak fp64 vector = fp64 matrix = 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 row; 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6)
 COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
 OV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_overlay_pmc.json")
-OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_root_fast", "ov_point_geom", "ov_root_lane", "ov_fit_eig", "ov_fit_lane",
+OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_point_geom", "ov_root_lane", "ov_insert_root", "ov_fit_eig", "ov_fit_lane",
               "ov_insert_apply", "ov_insert_fallback")
 OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
@@ -98,11 +98,11 @@ def overlay_roofline(kernel_ms, launches, n_scans, warnings):
         c = (pmc.get("kernels") or {}).get(k)
         e = {"ms_per_batch": ms, "launches": launches[k], "ms_per_launch": round(ms / launches[k], 4)}
         if c:
-            scale = n_scans / float(pmc.get("slots") or n_scans)   # counters are per launch of the profiled batch
-            gb = c["hbm_bytes_per_launch"] * scale / 1e9
+            scale = n_scans / float(pmc.get("slots") or n_scans)   # counters are per REPLAY of the profiled batch (its launches differ: three slot groups there)
+            gb = c["hbm_bytes_per_replay"] * scale / launches[k] / 1e9
             e.update({"hbm_GB_per_launch": round(gb, 3), "achieved_GBs": round(gb / (ms / launches[k] * 1e-3), 1),
                       "frac": round(gb / (ms / launches[k] * 1e-3) / HBM_PEAK_GBS, 4),
-                      "valu_issue_frac": None if not c.get("valu_insts_per_launch") else round(c["valu_insts_per_launch"] * scale * 4.0 / (SIMDS * CLK_GHZ * 1e9 * ms / launches[k] * 1e-3), 3),
+                      "valu_issue_frac": None if not c.get("valu_insts_per_replay") else round(c["valu_insts_per_replay"] * scale * 4.0 / (SIMDS * CLK_GHZ * 1e9 * ms * 1e-3), 3),
                       "vgprs": c.get("vgprs"), "scratch_bytes": c.get("scratch"), "waves_per_simd": c.get("waves_per_simd")})
             tot_bytes += gb * launches[k]
             tot_ms += ms

@@ -79,7 +79,7 @@ def main():
         g.profile_enable(1)
         run()
         g.profile_enable(0)
-        out["kernel_ms"] = {k: round(g.profile_get(k)[1], 3) for k in ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_insert_root", "ov_root_fast", "ov_point_geom", "ov_root_lane", "ov_base_sums", "ov_fit_eig", "ov_fit_lane",
+        out["kernel_ms"] = {k: round(g.profile_get(k)[1], 3) for k in ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_point_geom", "ov_root_lane", "ov_insert_root", "ov_base_sums", "ov_fit_eig", "ov_fit_lane",
                                                                           "ov_insert_apply", "ov_insert_fallback")}
     if args.stats:
         g.stream_stats()
