@@ -332,8 +332,17 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
  * (the message names the slot and the sizes in use). */
 int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                                 const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
+/* The same for a RECORDED run's scans (config 1 / config 4 shape): every scan its own size, its own time buckets (runs of equal curvature,
+ * KILO.cc:375-378), its own start time and - msg_kind 1: lk_imu, 2: lk_kin_imu, 0: none - its own messages, applied between the buckets
+ * as the loop at KILO.cc:379-390 does (n_msg[s] records of scan s, concatenated in msgs, time-sorted per scan).  Table arguments as for
+ * lk_batch_replay_ragged_dev.  Bucket index after bucket index over all scans: messages + predict, residual against base map + the scan's
+ * overlay, update, re-projection + UpdateVoxelMap into the overlay (KILO.cc:108-233) - what KILO::process computes for each scan alone on a
+ * private copy of the map.  Any bucket size; synchronous; out may be NULL. */
+int lk_batch_replay_overlay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const uint32_t* n_buckets,
+                                       const uint32_t* bucket_off, const double* bucket_dt, const double* t_begin, const uint32_t* n_msg,
+                                       const void* msgs, int msg_kind, lk_pose* out);
 /* Per-scan overlay capacities: root voxels a scan's inserts may touch or create, octree nodes and live point blocks of those voxels.
- * 0 (default) = sized by the library: a first guess from the scan size (n_pts / 16 roots), afterwards the previous replay's high-water
+ * 0 (default) = sized by the library: a first guess from the scan size (n_pts / 18 roots), afterwards the previous replay's high-water
  * marks + 25 %, and a scan that outgrows such pools makes them grow and the batch run again (no error).  Capacities set HERE are the
  * caller's word: overflowing them fails the replay with LK_ERR_CAPACITY.  Releases pools of another shape. */
 int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per_scan, uint32_t blocks_per_scan);

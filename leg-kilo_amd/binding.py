@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats",
 ]
 
@@ -366,6 +366,37 @@ class LegKiloHip:
         try:
             self.h2d(d, allpts)
             return self.batch_replay_overlay_dev(d, len(scans), n_pts, t_begin, bucket_off, bucket_dt)
+        finally:
+            self.device_free(d)
+
+    def batch_replay_overlay_ragged_dev(self, d_pts, tables, want_poses=True):
+        """Ragged batch WITH the map insert on slots [0, n_scans): `tables` from ragged_tables() (with imus= or kins= for the messages between
+        the buckets); every scan on its own copy-on-write overlay of the handle's map (lk_batch_replay_overlay_ragged_dev)."""
+        t = tables
+        n_scans = t["n_scans"]
+        poses = (abi.lk_pose * n_scans)() if want_poses else None
+        kind, n_msg, msgs = (2, t["n_kin"], t["kins"]) if "n_kin" in t else (1, t["n_imu"], t["imus"]) if "n_imu" in t else (0, None, None)
+        self._chk(self.L.lk_batch_replay_overlay_ragged_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), _p(t["scan_off"]), _p(t["n_buckets"]),
+                                                            _p(t["bucket_off"]), _p(t["bucket_dt"]), _p(t["t_begin"]),
+                                                            _p(n_msg) if n_msg is not None else None, _p(msgs) if msgs is not None else None,
+                                                            C.c_int(kind), poses))
+        return poses
+
+    def batch_replay_overlay_ragged(self, scans, t_begins, xs=None, Ps=None, imus=None, kins=None):
+        """Convenience: host scans (lk_point arrays, time-sorted, any sizes) -> HBM, buckets = runs of equal curvature (KILO.cc:375-378),
+        optional priors and per-scan messages, ragged replay WITH insert.  Returns the poses."""
+        from . import synth
+
+        if xs is not None:
+            self.batch_set_priors(np.asarray(xs), np.asarray(Ps))
+        allpts = np.ascontiguousarray(np.concatenate(scans))
+        scan_off = np.r_[0, np.cumsum([len(sc) for sc in scans])]
+        tabs = [synth.buckets_of(sc) for sc in scans]
+        tables = self.ragged_tables(scan_off, [t[0] for t in tabs], [t[1] for t in tabs], t_begins, imus, kins)
+        d = self.device_malloc(allpts.nbytes)
+        try:
+            self.h2d(d, allpts)
+            return self.batch_replay_overlay_ragged_dev(d, tables)
         finally:
             self.device_free(d)
 

@@ -780,6 +780,45 @@ __device__ __forceinline__ void dev_scan_wave(const LkMap& map, const LkParams& 
         f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
     }
 }
+// Ragged batch WITH insert, the way to bucket b of every scan that has one: the scan's messages stamped before the bucket's time that no
+// earlier bucket has consumed (KILO.cc:379-390: predictUpdateImu / predictUpdateKinImu one after the other), then the predict to the bucket's
+// time (KILO.cc:111-115) - dev_scan_wave's event loop between two buckets, as a launch of its own (one wave per scan).
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_rag_advance_kernel(LkFilter* filters, const double* __restrict__ Q, LkRagged rg, int b, int msg_kind) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (b >= rag_nb(rg, slot)) return;
+    LkFilter* f = &filters[slot];
+    const double* T = rag_t(rg, slot);
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+    if (lane < 36) sm.x[lane] = f->x[lane];
+    double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    __syncthreads();
+    const double tb = T[b];
+    if (msg_kind) {
+        const size_t mstride = msg_kind == 2 ? 33 : 7;
+        const unsigned int q0 = rg.imu_off[slot], q1 = rg.imu_off[slot + 1];
+        for (unsigned int q = q0; q < q1; ++q) {
+            const double* m = rg.imu + mstride * (size_t)q;
+            const double tm = m[0];
+            if (!(tm < tb)) break;                  // time-sorted: the rest belongs to later buckets
+            if (b > 0 && tm < T[b - 1]) continue;   // consumed on the way to an earlier bucket
+            wave_predict_core(sm, Q, tm - t_upd, tm - t_pred, lane, rg.q_diag != 0);
+            t_pred = tm;
+            if (msg_kind == 2) wave_kin_update_core(sm, rows, m, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
+            else wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
+            t_upd = tm;   // KILO.cc:256 / :312
+        }
+    }
+    wave_predict_core(sm, Q, tb - t_upd, tb - t_pred, lane, rg.q_diag != 0);
+    t_pred = tb;
+    __syncthreads();
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+    if (lane < 36) f->x[lane] = sm.x[lane];
+    if (lane == 0) f->last_update_t = t_upd, f->last_predict_t = t_pred;
+}
+
 __global__ void __launch_bounds__(LK_WAVE, 2)
     lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
                         const double* __restrict__ Q) {
@@ -2746,9 +2785,11 @@ static int ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const Lk
 // launch per bucket INDEX over all scans (grid sized by the largest bucket of that index; scans that have run out of
 // buckets leave at once), every scan reading its own tables (LkRagged).  Same kernels' arithmetic as the uniform entry:
 // a ragged batch of equally shaped scans gives the same bits.  Synchronous; priors as for lk_batch_replay_dev.
+static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,
+                                 const int* max_n, size_t max_scan_pts, int msg_kind, lk_pose* out);
 static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
                          const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
-                         const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out) {
+                         const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out, bool with_insert = false) {
     CHECK_H(h);
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
@@ -2778,7 +2819,7 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
         row_o += nbs + 1, row_t += nbs;
     }
     // every check comes before the first memset / upload / launch: a refused call leaves the filter slots untouched
-    if (n_imu && biggest_bucket > (uint32_t)LK_SCAN_WAVE_MAX)
+    if (n_imu && biggest_bucket > (uint32_t)LK_SCAN_WAVE_MAX && !with_insert)   // (the batch with insert runs bucket by bucket: lk_rag_advance_kernel takes the messages at any bucket size)
         return fail(h, LK_ERR_INVALID, "IMU / kinematic messages between buckets are only replayed for scans whose buckets hold <= 512 points");
     // tables: pt_off [S][ldb+1] u64 | t [S][ldb] f64 | t_begin [S] f64 | nb [S] u32, staged in pinned host memory
     size_t n_imu_total = 0;
@@ -2847,6 +2888,12 @@ static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, co
     rg.acc_scale = h->cfg.gravity / h->acc_norm;
     imu_noise(h->cfg, rg.Rn);
     rg.bstart = nullptr;
+    if (with_insert) {
+        size_t max_scan_pts = 0;
+        for (size_t s = 0; s < S; ++s) max_scan_pts = std::max(max_scan_pts, (size_t)(scan_off[s + 1] - scan_off[s]));
+        return overlay_ragged_launch(h, d_pts, S, rg, reinterpret_cast<const double*>(dr + o_tb), (int)biggest_bucket, ldb, max_n.data(), max_scan_pts,
+                                     n_imu ? (msg_bytes == sizeof(lk_kin_imu) ? 2 : 1) : 0, out);
+    }
     return ragged_launch(h, d_pts, S, rg, reinterpret_cast<const double*>(dr + o_tb), (int)biggest_bucket, ldb, max_n.data(),
                          n_imu ? (msg_bytes == sizeof(lk_kin_imu) ? 2 : 1) : 0, out);
 }
@@ -3076,7 +3123,7 @@ static void ov_free(lk_handle* h) {
 }
 // Per-scan capacities.  lk_overlay_reserve's numbers if given; else, when an earlier replay of scans of this size has left its
 // high-water marks, those + 25 % (pools more than twice that are released and re-made: round 4 reserved n_pts / 6 roots = 110 MB per scan,
-// 113 GB for 1 024 scans, where the bench's scans use 4 700 roots); else a first guess of n_pts / 16 roots.  `grow` (bits of the slots' error
+// 113 GB for 1 024 scans, where the bench's scans use 4 700 roots); else a first guess of n_pts / 18 roots.  `grow` (bits of the slots' error
 // word: 1 private root table, 2 nodes, 4 point blocks) doubles what overflowed - the replay is then run again (lk_batch_replay_overlay_dev).
 static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap, unsigned int grow = 0) {
     const bool hist = h->ov_hw_roots > 0 && h->ov_hw_npts == n_pts_scan;
@@ -3091,7 +3138,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
         nodes_extra = child + child / 4 + 256;
         blocks = h->ov_hw_blocks + h->ov_hw_blocks / 4 + 64;
     } else {
-        roots = (uint32_t)std::min<size_t>(std::max<size_t>(2048, n_pts_scan / 16), std::max<size_t>(1024, n_pts_scan));
+        roots = (uint32_t)std::min<size_t>(std::max<size_t>(2048, n_pts_scan / 18), std::max<size_t>(1024, n_pts_scan));
         nodes_extra = roots / 2;
         blocks = roots;
     }
@@ -3298,12 +3345,13 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         const double t = t_begin + bucket_dt[b];
         const int nblk = (nb + LK_RB - 1) / LK_RB;
         const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
+        const LkPtSrc src = {pts, n_pts, nb, nullptr, nullptr, 0, 0};
         if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
-        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, Sg), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb, parts, h->part_stride));
+        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, Sg), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, parts, h->part_stride));
         LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
         // the bucket's insert into every slot's overlay, from the posterior (KILO.cc:216-233)
         LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, ov));
-        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
         // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
         const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
         // (measured at 1024 slots x 20 000-point buckets, workgroups per slot: copy-on-write 2.8 / 6.6 / 12.2 ms per batch at 4 / 16 / 32 - a wave takes 64
@@ -3312,19 +3360,19 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(ov_fast ? lk_ov_materialise_kernel<true> : lk_ov_materialise_kernel<false>, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
         // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
         if (ov_fast) {
-            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, Sg), dim3(256), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, Sg), dim3(256), 0, st, ov, h->pr, fl, src));
             static const int lane_blocks = getenv("LEGKILO_OV_LANE_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_LANE_BLOCKS"))) : 0;
             LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(lane_blocks ? lane_blocks : std::max(4, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
         } else {
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, pts, n_pts, nb));
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
         }
         LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
         LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
         static const int ov_apply_wg = getenv("LEGKILO_OV_APPLY_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_APPLY_WG"))) : 0;
         static const int ov_fb_wg = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
-        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(ov_apply_wg ? ov_apply_wg : per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
-        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(ov_fb_wg ? ov_fb_wg : std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, pts, n_pts, nb));
+        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(ov_apply_wg ? ov_apply_wg : per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
+        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(ov_fb_wg ? ov_fb_wg : std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
         if (k + 1 < live.size())
             LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
                                                     t_begin + bucket_dt[live[k + 1]], 2));
@@ -3377,6 +3425,105 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     }
     return LK_OK;
 }
+
+int lk_batch_replay_overlay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const uint32_t* n_buckets,
+                                       const uint32_t* bucket_off, const double* bucket_dt, const double* t_begin, const uint32_t* n_msg, const void* msgs,
+                                       int msg_kind, lk_pose* out) {
+    CHECK_H(h);
+    if (msg_kind < 0 || msg_kind > 2) return fail(h, LK_ERR_INVALID, "msg_kind must be 0 (no messages), 1 (lk_imu) or 2 (lk_kin_imu)");
+    if (msg_kind && !n_msg) return fail(h, LK_ERR_INVALID, "null argument");
+    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, msg_kind ? n_msg : nullptr, msgs,
+                         msg_kind == 2 ? sizeof(lk_kin_imu) : sizeof(lk_imu), out, true);
+}
+}  // extern "C"
+// The ragged batch WITH insert, bucket INDEX after bucket index over all scans (one launch of every pass per index, grids sized by that
+// index's longest bucket; a scan that has run out of buckets leaves every launch at once): per index b - the scan's messages up to the
+// bucket's time + predict (lk_rag_advance_kernel), residual with the overlay lookup, update, then the insert passes of
+// lk_batch_replay_overlay_dev on each scan's own bucket (LkPtSrc).  One stream: a recorded run's buckets are small, the launches are what it costs.
+static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,
+                                 const int* max_n, size_t max_scan_pts, int msg_kind, lk_pose* out) {
+    const int S = (int)S_;
+    int rc = join_side_streams(h);
+    if (rc) return rc;
+    LkMap fmap;
+    rc = frozen_map(h, &fmap);
+    if (rc) return rc;
+    if (!fmap.grid_on) return fail(h, LK_ERR_STATE, "overlay replay needs the frozen-map grid (root keys' bounding box too large, LEGKILO_GRID=0, or out of device memory)");
+    rc = ov_reserve(h, (uint32_t)S, max_scan_pts, (size_t)biggest, fmap);
+    if (rc) return rc;
+    if (h->ov_priors_cap < (size_t)S) {
+        if (h->d_ov_priors) hipFree(h->d_ov_priors), h->d_ov_priors = nullptr, h->ov_priors_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ov_priors, sizeof(LkFilter) * (size_t)S));
+        h->ov_priors_cap = (size_t)S;
+    }
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_ov_priors, h->d_filters, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
+    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
+    unsigned int stt[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int attempt = 0;; ++attempt) {
+        const LkOverlay ov = h->ov;
+        LkFilter* fl = h->d_filters;
+        rc = zero_scan_counters(h, 0, (uint32_t)S);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, S, d_tbegin);
+        HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
+        LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
+        LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
+        {
+            const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);
+            LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
+        }
+        for (size_t b = 0; b < ldb; ++b) {
+            const int nb = std::max(1, max_n ? max_n[b] : biggest);
+            const int nblk = (nb + LK_RB - 1) / LK_RB;
+            const LkPtSrc src = {d_pts, 0, 0, rg.pt_off, rg.nb, rg.ldb, (int)b};
+            LAUNCH(h, "rag_advance", hipLaunchKernelGGL(lk_rag_advance_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_Q, rg, (int)b, msg_kind));
+            LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, h->d_partials, h->part_stride));
+            LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, (int)b, 1));
+            LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
+            LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
+            const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
+            LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel<true>, dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, S), dim3(256), 0, st, ov, h->pr, fl, src));
+            LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(std::max(1, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL((lk_ov_insert_root_kernel<3, true>), dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
+            LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, ov, h->pr));
+            LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+            LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
+            LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
+        }
+        HIPCHK(h, hipGetLastError());
+        h->ov_last_slots = (uint32_t)S;
+        const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
+        HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        const bool growable = !h->ov_want_roots && !(stt[0] & ~(LK_E_HASH_FULL | LK_E_NODES_FULL | LK_E_BLOCKS_FULL)) && attempt < 4;
+        if (!stt[0] || !growable) break;
+        HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_ov_priors, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
+        rc = ov_reserve(h, (uint32_t)S, max_scan_pts, (size_t)biggest, fmap, stt[0]);
+        if (rc) return rc;
+    }
+    if (!stt[0]) h->ov_hw_roots = stt[3], h->ov_hw_nodes = stt[1], h->ov_hw_blocks = stt[2], h->ov_hw_npts = max_scan_pts;
+    if (out) {
+        std::vector<lk_pose> tmp((size_t)S);
+        rc = fetch_poses(h, tmp.data(), S);
+        if (rc) return rc;
+        memcpy(out, tmp.data(), sizeof(lk_pose) * (size_t)S);
+    }
+    if (stt[0]) {
+        const LkOverlay& ov = h->ov;
+        char buf[256];
+        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots; per-scan pools: %u root entries, %u child nodes, %u blocks (lk_overlay_reserve)",
+                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.hash_cap, ov.nodes_cap - ov.hash_cap, ov.blocks_cap);
+        return fail(h, LK_ERR_CAPACITY, buf);
+    }
+    return LK_OK;
+}
+extern "C" {
 
 int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks) {
     CHECK_H(h);

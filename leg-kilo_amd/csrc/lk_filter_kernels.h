@@ -1132,11 +1132,16 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
 // sizes and "is there a next bucket" come from the scan's own tables.
 __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
     lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
-                                 const double* __restrict__ Q, LkRagged rg, int b) {
+                                 const double* __restrict__ Q, LkRagged rg, int b, int update_only = 0) {
     __shared__ WaveSmem sm;
     const int slot = blockIdx.x;
     const int nbk = rag_nb(rg, slot);
     if (b >= nbk) return;
+    if (update_only) {   // the batch WITH insert: the posterior of bucket b first (the insert reads it), the way to bucket b + 1 is lk_rag_advance_kernel's
+        const unsigned long long* po1 = rag_pt_off(rg, slot);
+        dev_update_wave(&filters[slot], sm, partials + (size_t)slot * slot_stride, ((int)(po1[b + 1] - po1[b]) + LK_WAVE - 1) / LK_WAVE, rag_t(rg, slot)[b], Q, 0.0, 1);
+        return;
+    }
     const double* T = rag_t(rg, slot);
     const double* part = partials + (size_t)slot * slot_stride;
     if (b < 0) {

@@ -45,6 +45,29 @@ struct LkLeafSum {   // 80 B = 5 x 16 B
 };
 static_assert(sizeof(LkLeafSum) == 80, "leaf sums record must be 80 B");
 
+// Where the points of the CURRENT bucket of slot s are.  Uniform batch (lk_batch_replay_overlay_dev: every scan the same shape): pts + s * stride,
+// n points.  Ragged batch (lk_batch_replay_overlay_ragged_dev: every scan its own size and bucket table, LkRagged's padded form): bucket b of
+// slot s = pts[pt_off[s][b] .. pt_off[s][b + 1]), none when the scan has fewer than b + 1 buckets.
+struct LkPtSrc {
+    const lk_point* pts;
+    size_t stride;
+    int n;
+    const unsigned long long* pt_off;   // null: uniform
+    const unsigned int* nb;
+    int ldb, b;
+};
+__device__ __forceinline__ int ov_pt_src(const LkPtSrc& s, unsigned int slot, const lk_point** p) {
+    if (!s.pt_off) {
+        *p = s.pts + (size_t)slot * s.stride;
+        return s.n;
+    }
+    *p = s.pts;
+    if (s.b >= (int)s.nb[slot]) return 0;
+    const unsigned long long* po = s.pt_off + (size_t)slot * (size_t)(s.ldb + 1);
+    *p = s.pts + po[s.b];
+    return (int)(po[s.b + 1] - po[s.b]);
+}
+
 // The overlay pools of all slots, passed by value.  Slot s owns element range [s * cap, (s + 1) * cap) of every array.
 // Private root table of a slot: open addressing over PACKED 64-bit keys (3 x 21 bits), and the root's node id IS its table index -
 // node records [0, hash_cap) of the slot are its roots, children are allocated from hash_cap upwards.  A key is claimed with ONE
@@ -266,12 +289,12 @@ __global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsi
 // creates the roots that do not exist yet.
 // returns the private root the point was queued on in a slot line, or -1 (ignored, or queued in a long root's overflow list)
 __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const LkFilter* __restrict__ filters,
-                                                  const lk_point* __restrict__ pts, size_t pts_slot_stride, const int i, const unsigned int slot) {
+                                                  const lk_point* __restrict__ pts, const int i, const unsigned int slot) {
     const LkMap pm = ov_slot_map(ov, slot);
     unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
-    const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
+    const float4 p = reinterpret_cast<const float4*>(pts)[i];
     const V3 pw = point_world(p.x, p.y, p.z, bc, pr);
     int key[3];
     key_floor(pw, pr.voxel_size_f, key);
@@ -324,11 +347,12 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
     return k < (unsigned int)LK_SLOTS ? root : -1;
 }
 __global__ void __launch_bounds__(LK_WAVE)
-    lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                           size_t pts_slot_stride, int n) {
+    lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
     const int i = blockIdx.x * LK_WAVE + threadIdx.x;
+    const lk_point* pts;
+    const int n = ov_pt_src(src, blockIdx.y, &pts);
     if (i >= n) return;
-    const int r = ov_reproject_point(base, ov, pr, filters, pts, pts_slot_stride, i, blockIdx.y);
+    const int r = ov_reproject_point(base, ov, pr, filters, pts, i, blockIdx.y);
     ov.ptroot[(size_t)blockIdx.y * ov.scan_cap + i] = r;   // for lk_ov_point_geom_kernel
 }
 
@@ -798,11 +822,12 @@ __global__ void __launch_bounds__(256) lk_ov_base_sums_kernel(LkMap base, unsign
 //                            counters, refit events decided from prefix sums, freeze, the fit job, the sums.  Whatever is not a root leaf
 //                            that appends / refits / freezes goes to the generic wave-per-root pass as it was found (map.heavy).
 // Per root the second kernel issues ~40 small memory requests and a few hundred lane-instructions: 64 roots per wave instead of one.
-__global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                                                               size_t pts_slot_stride, int n) {
+__global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const unsigned int slot = blockIdx.y;
+    const lk_point* pts;
+    const int n = ov_pt_src(src, slot, &pts);
+    if (i >= n) return;
     const int root = ov.ptroot[(size_t)slot * ov.scan_cap + i];
     if (root < 0) return;
     const LkMap pm = ov_slot_map(ov, slot);
@@ -817,7 +842,7 @@ __global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkP
     if (pos >= LK_BLOCK_PTS) return;
     BucketConst bc;
     load_bucket_const(&filters[slot], pr, bc);
-    const float4 p = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride)[i];
+    const float4 p = reinterpret_cast<const float4*>(pts)[i];
     const PointGeom gm = point_geom(p.x, p.y, p.z, bc, pr);
     lk_pt_rec* d = &pm.blocks[cnt.w].pts[pos];
     d->pw[0] = gm.p_w.x, d->pw[1] = gm.p_w.y, d->pw[2] = gm.p_w.z;
@@ -952,25 +977,34 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
 // ~10^6 roots, each a chain of dependent round trips - concurrency, not the single wave's speed, sets its duration
 template <int W, bool CPLX>
 __global__ void __launch_bounds__(LK_MB, W)
-    lk_ov_insert_root_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
+    lk_ov_insert_root_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    dev_insert_root<false, true, CPLX>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
+    const lk_point* pts;
+    const int n = ov_pt_src(src, blockIdx.y, &pts);
+    if (n == 0) return;
+    dev_insert_root<false, true, CPLX>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                                  (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base,
                                  ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
 }
 __global__ void __launch_bounds__(LK_MB)
-    lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
+    lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    dev_insert_apply<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
+    const lk_point* pts;
+    const int n = ov_pt_src(src, blockIdx.y, &pts);
+    if (n == 0) return;
+    dev_insert_apply<false>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                             (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
 __global__ void __launch_bounds__(LK_MB)
-    lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n) {
+    lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
     if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    dev_insert_fallback<false>(pm, pr, filters + blockIdx.y, pts + (size_t)blockIdx.y * pts_slot_stride, (const lk_pt_rec*)nullptr, n,
+    const lk_point* pts;
+    const int n = ov_pt_src(src, blockIdx.y, &pts);
+    if (n == 0) return;
+    dev_insert_fallback<false>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                                (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
 
@@ -978,11 +1012,14 @@ __global__ void __launch_bounds__(LK_MB)
 // lk_residual_kernel's body with the overlay root lookup (residual_tile<..., GRID = 3>).
 template <bool XID>
 __global__ void LK_RES_BOUNDS
-    lk_ov_residual_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
-                          size_t pts_slot_stride, int n, double* __restrict__ partials, size_t part_slot_stride) {
+    lk_ov_residual_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src, double* __restrict__ partials,
+                          size_t part_slot_stride) {
     __shared__ double stage[64 * LK_ROW2];
     const unsigned int slot = blockIdx.y;
     const int lane = threadIdx.x;
+    const lk_point* pts;
+    const int n = ov_pt_src(src, slot, &pts);
+    if ((int)(blockIdx.x * LK_RB) >= n) return;   // (ragged batch: this scan's bucket is shorter than the launch's longest, or it has none)
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
     LkOvView ovv;
@@ -993,8 +1030,8 @@ __global__ void LK_RES_BOUNDS
     ovv.bits = ov.bits + (size_t)slot * ov.bit_words;
     ResidualOut out;
     out.h6 = nullptr, out.z = nullptr, out.R = nullptr, out.valid = nullptr, out.world = nullptr, out.ids = nullptr;
-    const double acc = residual_tile<false, 3, XID, false, false>(base, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
-                                                                  blockIdx.x * LK_RB + lane, n, stage, lane, out, (size_t)0, &ovv);
+    const double acc = residual_tile<false, 3, XID, false, false>(base, pr, bc, reinterpret_cast<const float4*>(pts), blockIdx.x * LK_RB + lane, n, stage, lane, out,
+                                                                  (size_t)0, &ovv);
     if (lane < LK_NPART) partials[(size_t)slot * part_slot_stride + (size_t)blockIdx.x * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
 }
 

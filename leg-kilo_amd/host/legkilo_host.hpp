@@ -426,6 +426,60 @@ class KiloPath {
         return out;
     }
 
+    // A recorded run's scans WITH the map insert (lk_batch_replay_overlay_ragged_dev): every scan its own size, its own time buckets (runs of
+    // equal curvature, KILO.cc:375-378), its own start time and - optionally - its own IMU (only_imu_use, KILO.cc:379-383) or kinematic + IMU
+    // (leg fusion, KILO.cc:384-390) messages between the buckets; each scan inserts into its own copy-on-write overlay of the current map,
+    // the map itself is not changed.  Per scan the result equals processSorted() on a private copy of the map.
+    std::vector<lk_pose> replayRecordedRunWithInsert(const std::vector<PointCloudType>& sorted_scans, const std::vector<double>& t_begin,
+                                                     const std::vector<State>& prior_states, const std::vector<StateCov>& prior_covs,
+                                                     const std::vector<std::vector<lk_imu>>* imus = nullptr,
+                                                     const std::vector<std::vector<lk_kin_imu>>* kins = nullptr) {
+        const size_t S = sorted_scans.size();
+        if (S == 0 || t_begin.size() != S || prior_states.size() != S || prior_covs.size() != S || (imus && imus->size() != S) || (kins && kins->size() != S))
+            throw std::runtime_error("replayRecordedRunWithInsert: one start time, prior state and prior covariance per scan");
+        if (imus && kins) throw std::runtime_error("replayRecordedRunWithInsert: IMU messages or kinematic + IMU messages, not both");
+        std::vector<lk_point> pts;
+        std::vector<uint64_t> scan_off(1, 0);
+        std::vector<uint32_t> n_buckets, bucket_off, n_msg;
+        std::vector<double> bucket_dt, x36(S * LK_STATE_DOUBLES), P900(S * DIM_STATE * DIM_STATE);
+        std::vector<lk_imu> imu_flat;
+        std::vector<lk_kin_imu> kin_flat;
+        for (size_t s = 0; s < S; ++s) {
+            const PointCloudType& sc = sorted_scans[s];
+            if (sc.size() == 0) throw std::runtime_error("replayRecordedRunWithInsert: empty scan");
+            uint32_t nb = 0;
+            bucket_off.push_back(0);
+            for (size_t i = 0; i < sc.size();) {   // KILO.cc:375-378
+                size_t j = i + 1;
+                while (j < sc.size() && sc[i].curvature == sc[j].curvature) ++j;
+                bucket_dt.push_back((double)sc[i].curvature);
+                bucket_off.push_back((uint32_t)j);
+                ++nb;
+                i = j;
+            }
+            n_buckets.push_back(nb);
+            for (size_t i = 0; i < sc.size(); ++i) pts.push_back(lk_point{sc[i].x, sc[i].y, sc[i].z, sc[i].curvature});
+            scan_off.push_back(pts.size());
+            prior_states[s].to_x36(&x36[s * LK_STATE_DOUBLES]);
+            std::memcpy(&P900[s * DIM_STATE * DIM_STATE], prior_covs[s].d.data(), sizeof(double) * DIM_STATE * DIM_STATE);
+            if (imus) n_msg.push_back((uint32_t)(*imus)[s].size()), imu_flat.insert(imu_flat.end(), (*imus)[s].begin(), (*imus)[s].end());
+            if (kins) n_msg.push_back((uint32_t)(*kins)[s].size()), kin_flat.insert(kin_flat.end(), (*kins)[s].begin(), (*kins)[s].end());
+        }
+        void* d_pts = nullptr;
+        dev_->check(lk_device_malloc(dev_->h(), &d_pts, sizeof(lk_point) * std::max<size_t>(pts.size(), 1)));
+        std::vector<lk_pose> out(S);
+        int rc = lk_memcpy_h2d(dev_->h(), d_pts, pts.data(), sizeof(lk_point) * pts.size());
+        if (!rc) rc = lk_batch_set_priors(dev_->h(), x36.data(), P900.data(), S);
+        if (!rc)
+            rc = lk_batch_replay_overlay_ragged_dev(dev_->h(), static_cast<const lk_point*>(d_pts), S, scan_off.data(), n_buckets.data(), bucket_off.data(), bucket_dt.data(),
+                                                    t_begin.data(), (imus || kins) ? n_msg.data() : nullptr,
+                                                    kins ? static_cast<const void*>(kin_flat.data()) : static_cast<const void*>(imu_flat.data()), kins ? 2 : (imus ? 1 : 0),
+                                                    out.data());
+        lk_device_free(dev_->h(), d_pts);
+        dev_->check(rc);
+        return out;
+    }
+
    private:
     std::shared_ptr<Device> dev_;
     std::unique_ptr<ESKF> eskf_;

@@ -1094,6 +1094,88 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
     o.close()
 
 
+@pytest.mark.parametrize("mode", ["plain", "imu", "kin"])
+def test_batch_replay_overlay_ragged(scene, oracle_lib, hip_lib, mode):
+    """lk_batch_replay_overlay_ragged_dev: a recorded run's scans - every scan its own size, time buckets and start time, optionally its IMU
+    (only_imu_use) or kinematic + IMU (leg fusion, KILO.cc:379-390) messages between the buckets - replayed WITH the map insert, each scan on
+    its own copy-on-write overlay.  Per slot the oracle runs KILO::process on that scan alone on a private copy of the map (blob re-imported,
+    insert ON): identical bucket / update / match counts, state to 1e-6, every private voxel equal to the oracle's and every voxel the
+    oracle changed private on the device.  The shapes cover config-1 scans (hundreds of two-ms buckets of a dozen points), dense scans with
+    few large buckets, one-point and one-bucket scans; the insert really matters (the frozen-map replay of the same batch matches less)."""
+    if mode == "kin":
+        sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3), **CAPS)
+        o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=False)
+    else:
+        sc = scene
+        o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=True)
+    t0 = 2.0
+    x0 = scenes.init_filter(o, sc, t0)
+    scenes.first_frame(o, sc, t0, x0)
+    scenes.replay_vlp(o, sc, t0, 3, use_kin=(mode == "kin"))
+    o.map_import(o.map_export())   # the form a blob round trip leaves the map in (see test_batch_replay_overlay)
+    blob = o.map_export()
+    base = scenes.canon_map(blob)
+    rng = np.random.default_rng(606060)
+    shapes = [None, (6000, 4), None, (1, 1), (2500, 1), None] if mode == "plain" else [None, None, (3000, 3), None]
+    scans, tbs, xs, Ps, msgs = [], [], [], [], []
+    for s, shp in enumerate(shapes):
+        tb = t0 + 0.6 + 0.17 * s
+        if shp is None:
+            pts = scenes.vlp_scan_input(sc, tb, 80 + s)
+        else:
+            pts = synth.dense_scan(sc.world, sc.traj, tb, sc.P, n=shp[0], n_buckets=shp[1], seed_scan=8600 + s, seed_noise=8700 + s)
+        scans.append(pts)
+        tbs.append(tb)
+        xs.append(synth.initial_state(sc.traj, tb, sc.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+        if mode == "imu":
+            msgs.append(synth.imu_stream(sc.traj, tb, tb + 0.1, seed=9300 + s))
+        elif mode == "kin":
+            msgs.append(synth.kin_stream(sc.traj, tb, tb + 0.1, sc.P, seed=9400 + s))
+    S = len(scans)
+    g = hip_lib.LegKiloHip(sc.cfg(n_slots=S))
+    g.map_import(blob)
+    g.init_process_cov_q()
+    g.set_acc_norm(9.81)
+    o.set_acc_norm(9.81)
+    kw = {"imus": msgs} if mode == "imu" else {"kins": msgs} if mode == "kin" else {}
+    frozen = g.batch_replay_ragged(scans, tbs, xs, Ps, host_tables=True, **kw) if all(np.diff(synth.buckets_of(p_)[0].astype(np.int64)).max() <= 512 for p_ in scans) or mode == "plain" else None
+    poses = g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
+    Xall, Pall = g.batch_get_states(0, S)
+    assert np.array_equal(g.map_export(), np.frombuffer(blob, dtype=np.uint8)) or scenes.maps_identical(g.map_export(), blob)   # the shared map is untouched
+    poses2 = g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)   # the overlays start empty every time: the same bits again
+    X2, P2 = g.batch_get_states(0, S)
+    assert np.array_equal(Xall, X2) and np.array_equal(Pall, P2)
+    differs = 0
+    for s in range(S):
+        o.map_import(blob)
+        o.set_map_insert(True)
+        o.set_state(xs[s], Ps[s])
+        o.set_times(tbs[s], tbs[s])
+        okw = {"imus": msgs[s]} if mode == "imu" else {"kins": msgs[s]} if mode == "kin" else {}
+        po, _ = o.process_scan(scans[s], tbs[s], **okw)
+        xo, Po = o.get_state()
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (poses[s].n_buckets, poses[s].n_updates, int(poses[s].n_effect)), \
+            (mode, s, po.n_buckets, po.n_updates, po.n_effect, poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect)
+        assert (poses2[s].n_buckets, poses2[s].n_updates, int(poses2[s].n_effect)) == (poses[s].n_buckets, poses[s].n_updates, int(poses[s].n_effect))
+        assert np.abs(xo - Xall[s]).max() < 1e-6, (mode, s, np.abs(xo - Xall[s]).max())
+        assert np.abs(Pall[s] - Po).max() <= 1e-6 * np.abs(Po).max(), (mode, s)
+        st = scenes.compare_overlay(g.overlay_export(s), base, scenes.canon_map(o.map_export()), (mode, s), rtol=1e-5, ptol=1e-7)
+        if len(scans[s]) > 100:
+            assert st["private_roots"] > 0 and st["changed_roots"] > 0, (mode, s, st)
+        if frozen is not None:
+            differs += int(int(po.n_effect) != int(frozen[s].n_effect))
+        print(f"overlay ragged {mode} slot {s}: {len(scans[s])} points, {po.n_buckets} buckets, n_effect {int(po.n_effect)}"
+              + (f" (frozen map: {int(frozen[s].n_effect)})" if frozen is not None else "") + f", private roots {st['private_roots']}, max |dx| {np.abs(xo - Xall[s]).max():.2e}")
+    if frozen is not None:
+        assert differs >= 1, "the insert changed nothing any later bucket matched"
+    if mode != "plain":   # without the messages the outcome differs (they are really applied)
+        g.batch_replay_overlay_ragged(scans[:1], tbs[:1], xs[:1], Ps[:1])
+        assert not np.array_equal(g.get_state(slot=0)[0], Xall[0])
+    g.close()
+    o.close()
+
+
 def test_frozen_grid_equals_hash_and_follows_the_map(scene, oracle_lib, hip_lib, monkeypatch):
     """Batch replay looks root voxels up through the frozen-map grid (dense array of root records + flattened subtree lists,
     rebuilt when the map changes) and runs the kernel specialised for ext_R == I; LEGKILO_GRID=0 / LEGKILO_XID=0 keep the hash
