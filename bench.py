@@ -749,7 +749,31 @@ def main():
         extra["config1_points_per_scan"] = round(float(len(allp)) / S1, 1)
         extra["config1_buckets_per_scan"] = round(float(p1["n_buckets"].mean()), 1)
         extra["config1_mean_n_effect"] = round(float(p1["n_effect"].astype(np.float64).mean()), 1)
-        c1 = (c1_scans, c1_tb, xs1, Ps1, tile1, p1.copy())
+        # the same recorded-run batch WITH the map insert, every scan on its own overlay (lk_batch_replay_overlay_ragged_dev: bucket index after
+        # bucket index over all scans - the launches are what it costs)
+        p1ov = None
+        try:
+            S1o = min(S1, S_max)
+            tables1o = g.ragged_tables(scan_off[:S1o + 1], offs[:S1o], dts[:S1o], tbs1[:S1o])
+
+            def run_c1_ov():
+                g.batch_set_priors_dev(d_x1.data_ptr(), d_P1.data_ptr(), S1o)
+                return g.batch_replay_overlay_ragged_dev(d_c1.data_ptr(), tables1o)
+
+            run_c1_ov()
+            run_c1_ov()
+            tc = time.perf_counter()
+            poses1o = run_c1_ov()
+            el1o = time.perf_counter() - tc
+            p1ov = np.frombuffer(poses1o, dtype=_abi.pose_dtype()).copy()
+            extra["config1_overlay_ragged_ms_per_batch"] = round(el1o * 1e3, 2)
+            extra["config1_overlay_ragged_scans_per_s"] = round(S1o / el1o, 1)
+            extra["config1_overlay_ragged_batch"] = int(S1o)
+            extra["config1_overlay_ragged_mean_n_effect"] = round(float(p1ov["n_effect"].astype(np.float64).mean()), 1)
+        except Exception as e:  # noqa: BLE001
+            extra["config1_overlay_ragged_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+            warnings.append("config-1 overlay replay failed: " + extra["config1_overlay_ragged_error"])
+        c1 = (c1_scans, c1_tb, xs1, Ps1, tile1, p1.copy(), p1ov)
         # live stream of ONE config-1 scan sequence (what a robot runs: bucket after bucket, with insert)
         g.set_state(synth.initial_state(traj, c1_tb[0], P), 1e-6 * np.eye(30), slot=0)
         g.set_times(c1_tb[0], c1_tb[0])
@@ -836,7 +860,7 @@ def main():
                   "counts_equal": cnt_eq, "max_pos_delta_m": d_pos, "max_rot_delta": d_rot, "tolerance_m": 1e-7,
                   "ok": bool(d_pos <= 1e-7 and d_rot <= 1e-7 and cnt_eq >= n_chk - max(1, n_chk // 50)), "worst_slot": worst}
         if c1 is not None:   # the same config-1 scans on the CPU port, one at a time (frozen map), and the same comparison
-            c1_scans_, c1_tb_, xs1, Ps1, tile1, p1 = c1
+            c1_scans_, c1_tb_, xs1, Ps1, tile1, p1, p1ov = c1
             t1s, c1_dpos, c1_eq = [], 0.0, 0
             for s in range(min(16, len(tile1))):
                 u = tile1[s]
@@ -851,6 +875,25 @@ def main():
             extra["config1_speedup_vs_cpu_port"] = round(extra["config1_ragged_scans_per_s"] / extra["config1_cpu_port_scans_per_s"], 1)
             parity["config1_ragged"] = {"n": len(t1s), "counts_equal": c1_eq, "max_pos_delta_m": c1_dpos}
             parity["ok"] = bool(parity["ok"] and c1_dpos <= 1e-7)
+            if p1ov is not None:   # the recorded-run batch WITH insert: the oracle with insert ON on a private copy of the map, scan by scan
+                o_eq, o_dpos, t1o = 0, 0.0, []
+                n_o = min(8, len(p1ov))
+                for s in range(n_o):
+                    u = tile1[s]
+                    o.map_import(map_blob_for_oracle)
+                    o.set_map_insert(True)
+                    o.set_state(xs1[s], Ps1[s].reshape(30, 30))
+                    o.set_times(c1_tb_[u], c1_tb_[u])
+                    tc = time.perf_counter()
+                    pose, _ = o.process_scan(c1_scans_[u], c1_tb_[u], with_sort=True)
+                    t1o.append(time.perf_counter() - tc)
+                    o_dpos = max(o_dpos, float(np.abs(np.array(pose.pos) - p1ov[s]["pos"]).max()))
+                    o_eq += int((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect)) == (int(p1ov[s]["n_buckets"]), int(p1ov[s]["n_updates"]), int(p1ov[s]["n_effect"])))
+                o.map_import(map_blob_for_oracle)
+                o.set_map_insert(False)
+                parity["config1_overlay_ragged"] = {"n": n_o, "counts_equal": o_eq, "max_pos_delta_m": o_dpos, "tolerance_m": 1e-7}
+                parity["ok"] = bool(parity["ok"] and o_dpos <= 1e-7 and o_eq >= n_o - 1)
+                extra["config1_overlay_cpu_port_scans_per_s"] = round(1.0 / float(np.median(t1o)), 1)
         if shuf is not None:   # the shuffled batch's own parity sample: same oracle, same map, the scans as the device got them (the sort is stable)
             sh_host, sh_last = shuf
             sh_eq, sh_dpos = 0, 0.0
