@@ -233,6 +233,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
     ap.add_argument("--shuffle-check", type=int, default=24, help="extra.shuffled_in_bucket_*: the same batch with a random permutation inside every time bucket (curvature kept) - "
                     "the headline's scans come in voxel-grid cell order inside a bucket; this many of its scans are replayed by the oracle (0 = skip the extra)")
+    ap.add_argument("--shuffle-main", action="store_true", help="profiling aid: the MAIN timed loop runs on the batch with a random permutation inside every bucket "
+                    "(tools/gpu_prof_shuffled.sh collects the residual kernel's counters for that order -> profiles/latest_shuffled_pmc.json); the line says so")
     ap.add_argument("--overlay-scans", type=int, default=1024, help="scans of the batch replayed WITH the map insert (per-scan overlay, extra.overlay_*; 0 = skip)")
     ap.add_argument("--overlay-check", type=int, default=24, help="of those, scans the oracle replays (insert on, private copy of the map) for extra.overlay_parity")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
@@ -376,6 +378,25 @@ def main():
     d_unique = torch.from_numpy(host_batch).to(dev)
     d_batch = d_unique if U == S else d_unique[torch.from_numpy(tile).to(dev)].contiguous()
     assert d_batch.numel() == S * N_PTS * 16
+
+    def shuffled_in_bucket(batch, seed):
+        """The same scans with a random permutation inside every time bucket (curvature kept): [S, N_PTS, 4] int32 view, on the device."""
+        pts_i = batch.view(torch.int32).view(S, N_PTS, 4)
+        out_ = torch.empty_like(pts_i)
+        gen_t = torch.Generator(device=dev)
+        gen_t.manual_seed(seed)
+        for b in range(len(dt)):
+            a_, e_ = int(off[b]), int(off[b + 1])
+            if e_ <= a_:
+                continue
+            perm = torch.rand((S, e_ - a_), device=dev, generator=gen_t).argsort(dim=1)
+            out_[:, a_:e_] = torch.gather(pts_i[:, a_:e_], 1, perm[..., None].expand(-1, -1, 4))
+            del perm
+        return out_
+
+    if args.shuffle_main:
+        d_batch = shuffled_in_bucket(d_batch, 4242).view(torch.uint8).reshape(S, -1)
+        warnings.append("--shuffle-main: the timed loop ran on the batch with a RANDOM order inside every bucket (profiling aid), not on the headline's cell order")
     d_x = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
     d_P = torch.from_numpy(np.ascontiguousarray(Ps)).to(dev)
     torch.cuda.synchronize()
@@ -497,18 +518,8 @@ def main():
     # bucket, in voxel-grid cell order (synth.dense_scan(layout="cell"): the order pcl::VoxelGrid leaves its output in, KILO.cc:356-360), which
     # puts neighbouring lanes into neighbouring voxels; a recorded scan that was not voxel-filtered has no such order.
     shuf = None
-    if rank == 0 and world_size == 1 and args.shuffle_check > 0:
-        pts_i = d_batch.view(torch.int32).view(S, N_PTS, 4)
-        d_shuf = torch.empty_like(pts_i)
-        gen_t = torch.Generator(device=dev)
-        gen_t.manual_seed(4242)
-        for b in range(len(dt)):
-            a_, e_ = int(off[b]), int(off[b + 1])
-            if e_ <= a_:
-                continue
-            perm = torch.rand((S, e_ - a_), device=dev, generator=gen_t).argsort(dim=1)
-            d_shuf[:, a_:e_] = torch.gather(pts_i[:, a_:e_], 1, perm[..., None].expand(-1, -1, 4))
-            del perm
+    if rank == 0 and world_size == 1 and args.shuffle_check > 0 and not args.shuffle_main:
+        d_shuf = shuffled_in_bucket(d_batch, 4242)
         torch.cuda.synchronize()
         for k in range(max(args.warmup, 3)):
             step(k, d_shuf.data_ptr())
@@ -538,7 +549,46 @@ def main():
             except Exception as e:  # noqa: BLE001
                 warnings.append(f"profiles/latest_shuffled_pmc.json unreadable: {e}")
         shuf = (sh_host, sh_last)
-        del d_shuf, pts_i
+        # ... and what it costs to put such a batch back into voxel order on the device: per scan, world position from the scan's PRIOR pose ->
+        # voxel key -> stable sort of every bucket by key (torch = rocPRIM radix sort; once per loaded batch, not per replay), and the step on it
+        try:
+            vs = float(P["voxel_size"])
+            R_ = d_x[:, :9].reshape(S, 3, 3)
+            E_ = torch.tensor(np.array(P["extrinsic_R"], float).reshape(3, 3), device=dev)
+            T_ = torch.tensor(np.array(P["extrinsic_T"], float), device=dev)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            d_res = torch.empty_like(d_shuf)
+            for b in range(len(dt)):
+                a_, e_ = int(off[b]), int(off[b + 1])
+                if e_ <= a_:
+                    continue
+                xyz = d_shuf[:, a_:e_, :3].contiguous().view(torch.float32).to(torch.float64)
+                pw = torch.matmul(torch.matmul(xyz, E_.T) + T_, R_.transpose(1, 2)) + d_x[:, None, 9:12]
+                kk = torch.floor(pw / vs).to(torch.int64) + 2048
+                key = (kk[..., 2] * 4096 + kk[..., 1]) * 4096 + kk[..., 0]
+                order = torch.argsort(key, dim=1, stable=True)
+                d_res[:, a_:e_] = torch.gather(d_shuf[:, a_:e_], 1, order[..., None].expand(-1, -1, 4))
+                del xyz, pw, kk, key, order
+            torch.cuda.synchronize()
+            t_sort = time.perf_counter() - ts
+            for k in range(max(args.warmup, 3)):
+                step(k, d_res.data_ptr())
+            finish(min(max(args.warmup, 3), ring_rows))
+            sync_all()
+            ts = time.perf_counter()
+            for k in range(args.steps):
+                step(k, d_res.data_ptr())
+            finish(args.steps)
+            sync_all()
+            el_rs = time.perf_counter() - ts
+            extra["shuffled_resort_by_voxel_ms_per_batch_once"] = round(t_sort * 1e3, 2)
+            extra["shuffled_resorted_ms_per_step"] = round(el_rs / args.steps * 1e3, 3)
+            extra["shuffled_resort_breaks_even_after_steps"] = None if el_sh <= el_rs else int(math.ceil(t_sort / ((el_sh - el_rs) / args.steps)))
+            del d_res
+        except Exception as e:  # noqa: BLE001
+            extra["shuffled_resort_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+        del d_shuf
 
     # ---- kernel-level timing pass (HIP events on the handle's stream, whole-batch launches on ONE stream), outside the timed region
     g.profile_reset()

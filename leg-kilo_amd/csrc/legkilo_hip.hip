@@ -1404,7 +1404,8 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         // one wave per touched root (append / group / apply of single-group roots), then one wave per emitted leaf group (2 resident
         // waves per SIMD at ~200 VGPRs: 512 blocks x 4 waves is one resident round on 256 CUs), then the generic fallback for the few
         // groups that need it; all loops are grid-stride and read their work counts on the device
-        int grid = std::min(std::max((n + 3) / 4, 1), 512);
+        static const int root_grid_cap = getenv("LEGKILO_ROOT_GRID") ? std::max(1, atoi(getenv("LEGKILO_ROOT_GRID"))) : 512;
+        int grid = std::min(std::max((n + 3) / 4, 1), root_grid_cap);
         static const bool small_insert = getenv("LEGKILO_SMALL_INSERT") == nullptr || atoi(getenv("LEGKILO_SMALL_INSERT")) != 0;
         if (n <= LK_SMALL_MAX && small_insert) {   // small bucket: root pass + (in the last workgroup) apply + fallback as one launch
             LAUNCH(h, "insert_root", hipLaunchKernelGGL(lk_insert_small_kernel, dim3(std::min(grid, 128)), dim3(LK_MB), 0, h->stream, h->map, h->pr,

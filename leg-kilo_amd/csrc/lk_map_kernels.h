@@ -361,52 +361,53 @@ __device__ __forceinline__ PlaneFit plane_test_regs(const double* pw, bool activ
     f.is_plane = f.emin < (double)planer_threshold;
     return f;
 }
-// plane_var = sum_i J_i var_i J_i^T over the active lanes (voxel_map.cc:76-95), 21 unique terms, wave-reduced
+// plane_var = sum_i J_i var_i J_i^T over the active lanes (voxel_map.cc:76-95), 21 unique terms.
+// Round 5: J_i = [A_i ; I / n] with A_i = v_mid FA_i^T + v_max FB_i^T (rank 2: the row of v_min is zero),
+//   FA_i = ((q.v_mid) v_min + (q.v_min) v_mid) / den_A,  FB_i likewise with v_max,  q = p_i - centre.
+// With a = var FA, b = var FB:  A var A^T = v_mid v_mid^T (FA.a) + (v_mid v_max^T + v_max v_mid^T) (FA.b) + v_max v_max^T (FB.b)  and  A var = v_mid a^T + v_max b^T,
+// so a lane contributes 15 numbers (a, b, the three dot products, var) instead of the 21 entries of a 6 x 3 x 3 x 6 product, the wave reduces
+// 15 sums instead of 21, and the 21 entries are composed once from the sums.  The same value (a different, equally valid rounding of the
+// same sum); a third of the arithmetic and ~50 registers fewer at the root pass's peak.
 __device__ __forceinline__ void plane_var_regs(const PlaneFit& f, const double* pw, const double* var, bool active, int count,
                                                double* acc) {
-#pragma unroll
-    for (int q = 0; q < 21; ++q) acc[q] = 0.0;
-    double rhsA[9], rhsB[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            rhsA[3 * r + cc] = f.vmid[r] * f.vmin[cc] + f.vmin[r] * f.vmid[cc];
-            rhsB[3 * r + cc] = f.vmax[r] * f.vmin[cc] + f.vmin[r] * f.vmax[cc];
-        }
-    const double denA = count * (f.emin - f.emid), denB = count * (f.emin - f.emax);
+    const double invA = 1.0 / (count * (f.emin - f.emid)), invB = 1.0 / (count * (f.emin - f.emax));
     const double invn = 1.0 / count;
+    double s15[15];   // a (3), b (3), FA.a, FA.b, FB.b, var (6)
+#pragma unroll
+    for (int q = 0; q < 15; ++q) s15[q] = 0.0;
     if (active) {
-        double q[3] = {pw[0] - f.c[0], pw[1] - f.c[1], pw[2] - f.c[2]};
-        double la[3] = {q[0] / denA, q[1] / denA, q[2] / denA};
-        double lb[3] = {q[0] / denB, q[1] / denB, q[2] / denB};
+        const double q0 = pw[0] - f.c[0], q1 = pw[1] - f.c[1], q2 = pw[2] - f.c[2];
+        const double dmin = q0 * f.vmin[0] + q1 * f.vmin[1] + q2 * f.vmin[2];
+        const double dmid = (q0 * f.vmid[0] + q1 * f.vmid[1] + q2 * f.vmid[2]) * invA;
+        const double dmax = (q0 * f.vmax[0] + q1 * f.vmax[1] + q2 * f.vmax[2]) * invB;
+        const double dmA = dmin * invA, dmB = dmin * invB;
         double FA[3], FB[3];
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            FA[cc] = la[0] * rhsA[cc] + la[1] * rhsA[3 + cc] + la[2] * rhsA[6 + cc];
-            FB[cc] = lb[0] * rhsB[cc] + lb[1] * rhsB[3 + cc] + lb[2] * rhsB[6 + cc];
-        }
-        double J[6][3];
+        for (int c = 0; c < 3; ++c) FA[c] = dmid * f.vmin[c] + dmA * f.vmid[c], FB[c] = dmax * f.vmin[c] + dmB * f.vmax[c];
+        s15[0] = var[0] * FA[0] + var[1] * FA[1] + var[2] * FA[2], s15[1] = var[1] * FA[0] + var[3] * FA[1] + var[4] * FA[2],
+        s15[2] = var[2] * FA[0] + var[4] * FA[1] + var[5] * FA[2];
+        s15[3] = var[0] * FB[0] + var[1] * FB[1] + var[2] * FB[2], s15[4] = var[1] * FB[0] + var[3] * FB[1] + var[4] * FB[2],
+        s15[5] = var[2] * FB[0] + var[4] * FB[1] + var[5] * FB[2];
+        s15[6] = FA[0] * s15[0] + FA[1] * s15[1] + FA[2] * s15[2];
+        s15[7] = FA[0] * s15[3] + FA[1] * s15[4] + FA[2] * s15[5];
+        s15[8] = FB[0] * s15[3] + FB[1] * s15[4] + FB[2] * s15[5];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                J[r][cc] = f.vmid[r] * FA[cc] + f.vmax[r] * FB[cc];
-                J[3 + r][cc] = (r == cc) ? invn : 0.0;
-            }
-        double Sv[3][3] = {{var[0], var[1], var[2]}, {var[1], var[3], var[4]}, {var[2], var[4], var[5]}};
-        double JV[6][3];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) JV[r][cc] = J[r][0] * Sv[0][cc] + J[r][1] * Sv[1][cc] + J[r][2] * Sv[2][cc];
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = r; cc < 6; ++cc) acc[k++] += JV[r][0] * J[cc][0] + JV[r][1] * J[cc][1] + JV[r][2] * J[cc][2];
+        for (int c = 0; c < 6; ++c) s15[9 + c] = var[c];
     }
-    wave_sum_n<21>(acc);
+    wave_sum_n<15>(s15);
+    const double saa = s15[6], sab = s15[7], sbb = s15[8];
+    int kk = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = r; cc < 3; ++cc)
+            acc[kk++] = f.vmid[r] * f.vmid[cc] * saa + (f.vmid[r] * f.vmax[cc] + f.vmax[r] * f.vmid[cc]) * sab + f.vmax[r] * f.vmax[cc] * sbb;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) acc[kk++] = (f.vmid[r] * s15[cc] + f.vmax[r] * s15[3 + cc]) * invn;
+    }
+    const double invn2 = invn * invn;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[15 + c] = s15[9 + c] * invn2;
 }
 // lane 0 writes the plane and its compact match copy, both from registers (the match record is derived from the values, not read
 // back from the plane record just stored).  No fence: nothing in the apply pass reads a plane it has committed.
@@ -1457,8 +1458,11 @@ __device__ __forceinline__ void dev_insert_fallback(const LkMap& map, const LkPa
     }
 }
 
+#ifndef LK_ROOT_WAVES
+#define LK_ROOT_WAVES 2   // waves per SIMD the stream path's root pass is compiled for
+#endif
 template <bool FROM_PV>
-__global__ void __launch_bounds__(LK_MB)
+__global__ void __launch_bounds__(LK_MB, LK_ROOT_WAVES)
     lk_insert_root_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                           const lk_pt_rec* __restrict__ pv, int n) {
     dev_insert_root<FROM_PV>(map, pr, filters, pts, pv, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
