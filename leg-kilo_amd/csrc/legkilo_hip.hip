@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -73,6 +75,14 @@ struct lk_handle {
     bool resident_enable = true;  // scans of small buckets as one resident launch (lk_scan_stream_kernel); LEGKILO_RESIDENT=0 / lk_stream_resident(h, 0): per-bucket launches
     bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
     LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
+    struct ScanResult {            // what a stream-path scan hands back: written by ONE kernel into host-mapped pinned memory (no copies, one sync)
+        lk_pose pose;
+        unsigned int ctr[LK_CTR_COUNT];
+        unsigned int seq, pad_;      // written last: the host may poll it instead of blocking in hipStreamSynchronize
+    };
+    unsigned int result_seq = 0;
+    ScanResult* h_result = nullptr;   // hipHostMalloc(mapped)
+    ScanResult* d_result = nullptr;   // its device-side address
     LkFilter* d_fbackup = nullptr;   // filters[0] as it was when the running scan started: what an LK_ERR_TIMEOUT puts back (grid-resident and pipelined paths)
     bool fbackup_valid = false;
     int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
@@ -170,10 +180,14 @@ static unsigned int next_pow2(unsigned int v) {
     return p;
 }
 
-static int check_map_errors(lk_handle* h) {
+static int check_map_errors(lk_handle* h, const unsigned int* fetched = nullptr) {
     unsigned int ctr[LK_CTR_COUNT];
-    HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (fetched) {
+        memcpy(ctr, fetched, sizeof(ctr));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     if (ctr[LK_CTR_ERR] & LK_E_SPEC_TIMEOUT) {
         // not sticky: the word is cleared, so the handle stays usable once its map has been restored
         const unsigned int rest = ctr[LK_CTR_ERR] & ~LK_E_SPEC_TIMEOUT;
@@ -364,6 +378,7 @@ void lk_destroy(lk_handle* h) {
     for (void* p : pre)
         if (p) hipFree(p);
     if (h->h_rag) hipHostFree(h->h_rag);
+    if (h->h_result) hipHostFree(h->h_result);
     ov_free(h);
     if (h->d_ov_status) hipFree(h->d_ov_status);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1506,9 +1521,16 @@ static ResidualKernelFn batch_residual_kernel(const lk_handle* h, const LkMap& f
     return (h->pr.ext_identity && xid_enable) ? lk_residual_kernel<false, 1, true> : lk_residual_kernel<false, 1, false>;
 }
 
+__global__ void lk_zero_scan_counters_kernel(LkFilter* filters, unsigned int n_slots) {
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    LkFilter* f = &filters[s];
+    f->n_effect = 0ull, f->n_updates = 0u, f->n_buckets = 0u, f->updated = 0, f->last_N = 0;
+}
 static int zero_scan_counters(lk_handle* h, uint32_t first_slot, uint32_t n_slots) {
-    // n_effect, n_updates, n_buckets, updated, last_N are contiguous (24 bytes)
-    HIPCHK(h, hipMemset2DAsync(&h->d_filters[first_slot].n_effect, sizeof(LkFilter), 0, 24, n_slots, h->stream));
+    // n_effect, n_updates, n_buckets, updated, last_N of every slot: ONE launch (a 24-byte-wide 2-D memset is two fill kernels)
+    hipLaunchKernelGGL(lk_zero_scan_counters_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, h->stream, h->d_filters + first_slot, n_slots);
+    HIPCHK(h, hipGetLastError());
     return LK_OK;
 }
 
@@ -1530,6 +1552,58 @@ static int fetch_poses(lk_handle* h, lk_pose* out, int n) {
     HIPCHK(h, hipMemcpyAsync(out, h->d_poses, sizeof(lk_pose) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return LK_OK;
+}
+
+// End of a stream-path scan: the pose of filter slot 0 and the map's counter words (pool overflow / timeout bits) written by ONE kernel
+// straight into host-mapped pinned memory, ONE stream synchronisation - instead of a gather kernel, two pageable device-to-host copies
+// and two synchronisations (round 5: ~100 us of every scan's 430 were spent between its last kernel and the next scan's first).
+__global__ void lk_scan_finish_kernel(const LkFilter* filters, const unsigned int* counters, lk_handle::ScanResult* out, unsigned int seq) {
+    const int i = threadIdx.x;
+    if (i == 0) {
+        const LkFilter* f = &filters[0];
+        lk_pose p;
+        for (int k = 0; k < 9; ++k) p.rot[k] = f->x[k];
+        for (int k = 0; k < 3; ++k) p.pos[k] = f->x[9 + k], p.vel[k] = f->x[12 + k];
+        p.n_effect = f->n_effect, p.n_buckets = f->n_buckets, p.n_updates = f->n_updates;
+        out->pose = p;
+    }
+    if (i < LK_CTR_COUNT) out->ctr[i] = counters[i];
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) {
+        __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+static int finish_scan(lk_handle* h, lk_pose* pose) {
+    if (!h->h_result) {
+        HIPCHK(h, hipHostMalloc((void**)&h->h_result, sizeof(lk_handle::ScanResult), hipHostMallocMapped));
+        memset(h->h_result, 0, sizeof(lk_handle::ScanResult));
+        HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
+    }
+    const unsigned int seq = ++h->result_seq ? h->result_seq : ++h->result_seq;   // never 0 (the buffer's initial value)
+    hipLaunchKernelGGL(lk_scan_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->d_filters, h->map.counters, h->d_result, seq);
+    HIPCHK(h, hipGetLastError());
+    // a scan is a fraction of a millisecond to a few: the caller's thread POLLS the sequence word the kernel writes last (a blocking
+    // synchronisation wakes through an interrupt, 10-20 us later) - for at most 20 ms, then it blocks (which also surfaces device errors).
+    // LEGKILO_SPIN_WAIT=0: always block
+    static const bool spin = getenv("LEGKILO_SPIN_WAIT") == nullptr || atoi(getenv("LEGKILO_SPIN_WAIT")) != 0;
+    bool seen = false;
+    if (spin) {
+        volatile unsigned int* sq = &h->h_result->seq;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+        for (unsigned int it = 0;; ++it) {
+            if (*sq == seq) {
+                seen = true;
+                break;
+            }
+            if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
+    *pose = h->h_result->pose;
+    return check_map_errors(h, h->h_result->ctr);
 }
 
 // ------------------------------------------------------------------ VoxelMapManager surface
@@ -2265,8 +2339,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
                 HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
             }
             lk_pose pose;
-            if ((rc = fetch_poses(h, &pose, 1))) return rc;
-            if ((rc = check_map_errors(h))) return rc;
+            if ((rc = finish_scan(h, &pose))) return rc;
             if (xyz_world_out)
                 for (size_t i = 0; i < n; ++i)
                     for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
@@ -2283,8 +2356,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
                 HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
             }
             lk_pose pose;
-            if ((rc = fetch_poses(h, &pose, 1))) return rc;
-            if ((rc = check_map_errors(h))) return rc;
+            if ((rc = finish_scan(h, &pose))) return rc;
             if (xyz_world_out)
                 for (size_t i = 0; i < n; ++i)
                     for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
@@ -2329,9 +2401,7 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
         HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
     }
     lk_pose pose;
-    rc = fetch_poses(h, &pose, 1);
-    if (rc) return rc;
-    rc = check_map_errors(h);
+    rc = finish_scan(h, &pose);
     if (rc) return rc;
     if (xyz_world_out)
         for (size_t i = 0; i < n; ++i)
@@ -2370,16 +2440,14 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
         if (!btime.empty() && grid_takes(h, smallest, biggest)) {
             if ((rc = run_scan_grid(h, d_pts, bstart, btime, biggest, nullptr))) return rc;
             lk_pose pose;
-            if ((rc = fetch_poses(h, &pose, 1))) return rc;
-            if ((rc = check_map_errors(h))) return rc;
+            if ((rc = finish_scan(h, &pose))) return rc;
             if (out) *out = pose;
             return LK_OK;
         }
         if (!btime.empty() && resident_enabled(h) && biggest <= LK_RESIDENT_MAX) {
             if ((rc = run_scan_resident(h, d_pts, bstart, btime, nullptr, 0, 0, nullptr))) return rc;
             lk_pose pose;
-            if ((rc = fetch_poses(h, &pose, 1))) return rc;
-            if ((rc = check_map_errors(h))) return rc;
+            if ((rc = finish_scan(h, &pose))) return rc;
             if (out) *out = pose;
             return LK_OK;
         }
@@ -2396,9 +2464,7 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
     }
     if ((rc = spec_join(h))) return rc;
     lk_pose pose;
-    rc = fetch_poses(h, &pose, 1);
-    if (rc) return rc;
-    rc = check_map_errors(h);
+    rc = finish_scan(h, &pose);
     if (rc) return rc;
     if (out) *out = pose;
     return LK_OK;

@@ -1490,6 +1490,9 @@ __global__ void __launch_bounds__(LK_MB)
     __syncthreads();
     dev_insert_fallback<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
 }
+// (Round 5, measured and not kept: apply + fallback as ONE launch - all workgroups apply, the last one (ticket) runs the fallback items.
+// A kernel that contains the fallback code needs 256 VGPRs + 6.3 KB of scratch per lane, and a 256-workgroup launch of THAT costs ~25 us
+// even when every workgroup leaves after two counter reads: 0.475 against 0.375 ms per 5 x 20 000-point scan.  profiles/EXPERIMENTS.md.)
 template <bool FROM_PV>
 __global__ void __launch_bounds__(LK_MB)
     lk_insert_apply_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts,
