@@ -1518,6 +1518,8 @@ using ResidualKernelFn = void (*)(LkMap, LkParams, const LkFilter*, const lk_poi
 static ResidualKernelFn batch_residual_kernel(const lk_handle* h, const LkMap& fmap) {
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     if (!fmap.grid_on) return lk_residual_kernel<false, 0, false>;
+    static const bool pair = getenv("LEGKILO_RES_PAIR") != nullptr && atoi(getenv("LEGKILO_RES_PAIR")) != 0;   // round-5 experiment: two tiles per wave (A/B; off)
+    if (pair) return (h->pr.ext_identity && xid_enable) ? lk_residual_pair_kernel<true> : lk_residual_pair_kernel<false>;
     return (h->pr.ext_identity && xid_enable) ? lk_residual_kernel<false, 1, true> : lk_residual_kernel<false, 1, false>;
 }
 

@@ -538,6 +538,129 @@ __global__ void LK_RES_BOUNDS
     }
 }
 
+// ---------------------------------------------------------------- round 5 experiment: TWO tiles per wave (-> profiles/EXPERIMENTS.md)
+// The batch kernel waits 46 % of a wave's life: one trip for the point, one for the candidate's record.  Here a wave takes two 64-point
+// tiles and requests BOTH tiles' points, then both tiles' cell records (18 pinned 16-B pieces per lane), before it evaluates either: the
+// second tile's trips overlap the first tile's arithmetic.  The price is the second record and point in registers.  Frozen-map grid only
+// (match_flat), no row emission; arithmetic and order of sums per tile exactly those of residual_tile (the same bits per partial record).
+struct TilePre {
+    PointLite g;
+    int root;
+    double2 q0, q1, q2;
+    float4 tail;
+    RecTail rt;
+};
+template <bool XID>
+__device__ __forceinline__ void tile_request(const LkMap& map, const LkParams& pr, const BucketConst& bc, const float4& p, bool in_range, TilePre& t) {
+    t.root = -1;
+    if (in_range) {
+        t.g = point_lite<XID>(p.x, p.y, p.z, bc, pr);
+        float loc[3];
+        int key[3];
+        key_trunc(t.g.p_w, pr, loc, key);
+        t.root = find_root<1>(map, key[0], key[1], key[2]);
+    }
+    const lk_match_rec* pl = &map.match[t.root >= 0 ? t.root : (int)map.grid_base];   // (clamped: every lane requests, nothing is merged in)
+    const double2* q = reinterpret_cast<const double2*>(pl);
+    t.q0 = q[0], t.q1 = q[1], t.q2 = q[2];
+    t.tail = *reinterpret_cast<const float4*>(&pl->d);
+    t.rt.v0 = q[4], t.rt.v1 = q[5], t.rt.v2 = q[6], t.rt.v3 = q[7], t.rt.v4 = q[8];
+}
+// match_flat with the cell's own record already requested (t): the first iteration uses it, list records are loaded as before
+template <bool XID>
+__device__ __forceinline__ bool match_flat_pre(const LkMap& m, TilePre& t, const BucketConst& bc, const LkParams& pr, bool& success, double& prob, Match& best) {
+    pin_chunk(t.q0), pin_chunk(t.q1), pin_chunk(t.q2), pin_chunk(t.tail);
+    pin_chunk(t.rt.v0), pin_chunk(t.rt.v1), pin_chunk(t.rt.v2), pin_chunk(t.rt.v3), pin_chunk(t.rt.v4);
+    const unsigned int fl0 = __float_as_uint(t.tail.z);
+    if (__float_as_uint(t.tail.w) == LK_GRID_EMPTY) return false;
+    if (fl0 & LK_PLANE_IS_PLANE) {
+        eval_plane<XID, true>(&m.match[t.root], t.q0, t.q1, t.q2, t.tail.x, t.tail.y, 0, 0, t.g, bc, pr, success, prob, best, &t.rt);
+        return true;
+    }
+    int idx = (int)(unsigned int)__double_as_longlong(t.q0.x), remaining = (int)(unsigned int)(__double_as_longlong(t.q0.x) >> 32);
+    while (remaining > 0) {
+        const lk_match_rec* pl = &m.match[idx];
+        const double2* q = reinterpret_cast<const double2*>(pl);
+        double2 q0 = q[0], q1 = q[1], q2 = q[2];
+        float4 tail = *reinterpret_cast<const float4*>(&pl->d);
+        RecTail rt;
+        rt.v0 = q[4], rt.v1 = q[5], rt.v2 = q[6], rt.v3 = q[7], rt.v4 = q[8];
+        pin_chunk(q0), pin_chunk(q1), pin_chunk(q2), pin_chunk(tail);
+        pin_chunk(rt.v0), pin_chunk(rt.v1), pin_chunk(rt.v2), pin_chunk(rt.v3), pin_chunk(rt.v4);
+        eval_plane<XID, true>(pl, q0, q1, q2, tail.x, tail.y, 0, 0, t.g, bc, pr, success, prob, best, &rt);
+        ++idx;
+        --remaining;
+    }
+    return true;
+}
+// the rest of a tile: K2 (home voxel from the requested record, one neighbour retry), row, K3
+template <bool XID>
+__device__ __forceinline__ double tile_finish(const LkMap& map, const LkParams& pr, const BucketConst& bc, TilePre& t, double* rows, int lane) {
+    bool success = false;
+    double prob = 0;
+    Match best;
+    best.row = rows + lane * LK_ROW2;
+    bool home = false;
+    if (t.root >= 0) home = match_flat_pre<XID>(map, t, bc, pr, success, prob, best);
+    if (home && !success) {
+        float loc[3];
+        int key[3], near[3];
+        key_trunc(t.g.p_w, pr, loc, key);
+        neighbour_key(pr, loc, key, near);
+        int nroot = -1;
+        if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) nroot = find_root<1>(map, near[0], near[1], near[2]);
+        if (nroot >= 0) match_flat<XID>(map, nroot, t.g, bc, pr, success, prob, best);
+    }
+    const bool ok = success;
+    if (!ok) {
+        double* r = rows + lane * LK_ROW2;
+#pragma unroll
+        for (int a = 0; a < LK_ROW2; ++a) r[a] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int q = lane & 31, half = lane >> 5;
+    const unsigned long long tw = (q < 8) ? 0x2818574737271707ull : (q < 16) ? 0x3a59493929584838ull : (q < 24) ? 0x6968675c5b4b5a4aull : 0xeeeeeeeeed6c6b6aull;
+    const unsigned int ab = (unsigned int)(tw >> ((q & 7) * 8)) & 0xffu;
+    const int a = (int)(ab & 15u), b = (int)(ab >> 4);
+    const double* base = rows + (half * 32) * LK_ROW2;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const double* r = base + j * LK_ROW2;
+        acc = __builtin_fma(r[a], r[b], acc);
+    }
+    acc += __shfl_xor(acc, 32, LK_WAVE);
+    return acc;
+}
+#ifndef LK_PAIR_WAVES
+#define LK_PAIR_WAVES 3
+#endif
+template <bool XID>
+__global__ void __launch_bounds__(LK_RB, LK_PAIR_WAVES)
+    lk_residual_pair_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, size_t pts_slot_stride, int n,
+                            double* __restrict__ partials, size_t part_slot_stride, ResidualOut out, size_t out_slot_stride) {
+    static_assert(LK_RB == LK_WAVE, "one wave per workgroup");
+    __shared__ double stage[64 * LK_ROW2];
+    if (blockIdx.x & 1u) return;   // the launch keeps lk_residual_kernel's grid: even workgroups take tiles b and b + 1
+    const int slot = blockIdx.y, lane = threadIdx.x;
+    BucketConst bc;
+    load_bucket_const<false>(&filters[slot], pr, bc);
+    const float4* spts = reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride);
+    const int i0 = blockIdx.x * LK_RB + lane, i1 = i0 + LK_RB;
+    const float4 p0 = spts[min(i0, n - 1)], p1 = spts[min(i1, n - 1)];   // both points first, clamped: no lane test in front of a load
+    TilePre t0, t1;
+    tile_request<XID>(map, pr, bc, p0, i0 < n, t0);
+    tile_request<XID>(map, pr, bc, p1, i1 < n, t1);
+    const double acc0 = tile_finish<XID>(map, pr, bc, t0, stage, lane);
+    if (lane < LK_NPART) partials[(size_t)slot * part_slot_stride + (size_t)blockIdx.x * LK_NPART + lane] = (lane < 29) ? acc0 : 0.0;
+    if ((int)((blockIdx.x + 1) * LK_RB) >= n) return;
+    __builtin_amdgcn_wave_barrier();   // tile 0's reads of the rows are complete
+    const double acc1 = tile_finish<XID>(map, pr, bc, t1, stage, lane);
+    if (lane < LK_NPART) partials[(size_t)slot * part_slot_stride + (size_t)(blockIdx.x + 1) * LK_NPART + lane] = (lane < 29) ? acc1 : 0.0;
+}
+
 // ---------------------------------------------------------------- pipelined stream path: verify pass
 // The stream path runs the insert of bucket k on its own HIP stream while bucket k+1's predict + residual pass (SPEC
 // instantiation: it also stores each point's two root codes) run on the main stream.  An insert changes what a point's match can
