@@ -59,14 +59,28 @@ def main():
             summary[k]["dispatches_in_trace_pass"] = n_disp.get(k)
             summary[k].update(regs.get(k, {}))
     json.dump(summary, open(os.path.join(out, f"{tag}_overlay_pmc_summary.json"), "w"), indent=1)
+    # registers / scratch / waves per SIMD as the COMPILER reports them (profiles/r05_resource_usage.txt, `make resource-usage`): the profiler's
+    # VGPR_Count column is an allocation granule count on gfx950, not the kernel's VGPRs
+    table = {}
+    rt = os.path.join(ROOT, "profiles", "r05_resource_usage.txt")
+    if os.path.exists(rt):
+        for line in open(rt).read().splitlines()[1:]:
+            f = line.split()
+            if len(f) >= 6:
+                name = " ".join(f[:-5])
+                table.setdefault(name.split("<")[0], []).append((name, int(f[-5]), int(f[-4]), int(f[-3]), int(f[-2])))
     kernels = {}
     for key, kn in KEYS.items():
         c = acc.get(kn)
         if not c:
             continue
-        rg = regs.get(kn, {})
+        rg = dict(regs.get(kn, {}))
         v = rg.get("vgprs", 0) + rg.get("agprs", 0)
         waves = 8 if v <= 64 else max(1, min(8, 512 // (((v + 7) // 8) * 8)))
+        if kn in table:   # the instantiation the replay launches: <true> (LEAN / XID) or <3, true> (generic root pass)
+            cand = [t for t in table[kn] if "<" not in t[0] or "true>" in t[0]] or table[kn]
+            rg.update({"vgprs": cand[0][1], "agprs": cand[0][2], "scratch": cand[0][3]})
+            waves = cand[0][4]
         e = {"hbm_bytes_per_replay": (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 / replays,
              "fetch_KiB_per_replay": c.get("FETCH_SIZE", 0.0) / replays, "write_KiB_per_replay": c.get("WRITE_SIZE", 0.0) / replays,
              "valu_insts_per_replay": c.get("SQ_INSTS_VALU", 0.0) / replays, "salu_insts_per_replay": c.get("SQ_INSTS_SALU", 0.0) / replays,
