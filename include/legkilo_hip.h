@@ -410,6 +410,11 @@ int lk_stream_pipeline(lk_handle* h, int on);
  * of one resident workgroup instead of several launches per bucket (on by default; on = 0 or LEGKILO_RESIDENT=0: per-bucket
  * launches).  Same device functions, identical results. */
 int lk_stream_resident(lk_handle* h, int on);
+/* out2 = { scans that went through the scan-resident kernel, launches it needed beyond one per scan } since lk_create.  The generic
+ * fallback items of the insert (a voxel that is cut - init_octo_tree / cut_octo_tree, voxel_map.cc:119-183 -, leftovers after a flip to a
+ * tree, a root with more than 64 queued points) are not part of the resident kernel: a bucket that produces one ends the launch, the
+ * items run as a launch of their own and the resident kernel is launched again from where it stopped (same results; ~30 us per event). */
+int lk_stream_resident_stats(lk_handle* h, uint64_t* out2);
 /* Grid-resident stream kernel: a scan whose time buckets all hold > 512 points (and no IMU / kinematic messages between them) runs
  * its whole bucket loop as ONE launch of co-resident workgroups - the phases of the per-bucket launches separated by grid barriers
  * (agent-scope release / acquire hand-offs) instead of kernel boundaries, the rarely needed phases entered only when the device

@@ -78,8 +78,10 @@ struct lk_handle {
     struct ScanResult {            // what a stream-path scan hands back: written by ONE kernel into host-mapped pinned memory (no copies, one sync)
         lk_pose pose;
         unsigned int ctr[LK_CTR_COUNT];
+        int resume[4];               // scan-resident kernel: LkResume's bf, bi, fb_bucket (where the launch stopped), 0
         unsigned int seq, pad_;      // written last: the host may poll it instead of blocking in hipStreamSynchronize
     };
+    uint64_t resident_scans = 0, resident_relaunches = 0;   // lk_stream_resident_stats
     unsigned int result_seq = 0;
     ScanResult* h_result = nullptr;   // hipHostMalloc(mapped)
     ScanResult* d_result = nullptr;   // its device-side address
@@ -883,12 +885,13 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 // false when the wait was given up - another wave has raised f_abort, or this one does after LK_RESIDENT_TIMEOUT ticks of the 100 MHz
 // clock (a device fault in the other role must fail the call, never hang the GPU): the caller leaves its bucket loop.
 #define LK_RESIDENT_TIMEOUT_MS 2000u   // default bound of every wait inside the resident kernel (LEGKILO_RESIDENT_TIMEOUT_MS overrides)
-#define LK_SPIN_UNTIL(cond)                                                                                                  \
+#define LK_SPIN_UNTIL(cond, watch_exit)                                                                                      \
     ([&]() -> bool {                                                                                                          \
         unsigned long long t0_ = 0;                                                                                           \
         unsigned int spins_ = 0;                                                                                              \
         while (!(cond)) {                                                                                                     \
             if (__hip_atomic_load(&f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;               \
+            if ((watch_exit) && __hip_atomic_load(&f_exit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false; \
             __builtin_amdgcn_s_sleep(1);                                                                                      \
             if ((++spins_ & 1023u) == 0u) {                                                                                   \
                 const unsigned long long now_ = wall_clock64();                                                               \
@@ -903,67 +906,127 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                                \
         return true;                                                                                                          \
     }())
-#define FLAG_WAIT(flag, need) LK_SPIN_UNTIL(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (need))
+#define FLAG_WAIT(flag, need) LK_SPIN_UNTIL(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (need), false)
+// the filter wave's waits for the insert team: also given up (false) when the team has LEFT the launch with fallback items pending (f_exit)
+#define FLAG_WAIT_X(flag, need) LK_SPIN_UNTIL(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (need), true)
 #define FLAG_POST(flag, value)                                                                                              \
     do {                                                                                                                    \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* this wave's stores (global and LDS) are complete */        \
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&(flag), (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
     } while (0)
 // barrier among the LK_INS_WAVES insert waves only (a monotonic LDS counter; `phase` counts this wave's arrivals); false = given up
-#define LK_INS_WAVES 3
+#ifndef LK_INS_WAVES
+#define LK_INS_WAVES 7   // with the filter wave: 512 threads = two waves per SIMD of one CU, 256 registers each
+#endif
 #define TEAM_BARRIER(ctr, phase)                                                                                            \
     (++(phase), __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"),                                                       \
      (((threadIdx.x & 63) == 0) ? (void)__hip_atomic_fetch_add(&(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (void)0), \
-     LK_SPIN_UNTIL(__hip_atomic_load(&(ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LK_INS_WAVES * (phase)))
+     LK_SPIN_UNTIL(__hip_atomic_load(&(ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LK_INS_WAVES * (phase), false))
+// Where a scan stands between two launches of the resident kernel.  The generic fallback items of the insert (a voxel that has to be cut,
+// leftovers after a flip to a tree, roots with more than 64 queued points: dev_insert_fallback, the per-point state machine) are NOT part of
+// the resident kernel: their code alone needs 250 more registers and 6.3 KB of scratch per lane, which held the workgroup at one wave per
+// SIMD = a team of three.  A config-1 stream meets such an item in a fraction of a percent of its buckets, a steady-state map in none.
+// When the team finds one after a bucket's apply phase it records the bucket here and leaves; the filter wave stops at its next wait for
+// the team (always with the predict to its bucket applied and that bucket's update not: stage1), both write their position, the host
+// runs lk_resident_fallback_kernel and launches the resident kernel again, which picks up exactly there (run_scan_resident / resident_rounds).
+struct LkResume {
+    int bf;            // filter wave: next bucket
+    int stage1;        // 1: the predict to bucket bf's time is applied, its messages are consumed - resume with the tiles
+    unsigned int qi;   // message cursor
+    int bi;            // insert team: next bucket
+    int fb_bucket;     // the bucket whose fallback items are pending (its snapshot: snap2[fb_bucket & 1]); -1: none
+    int pad_[3];
+};
+#ifdef LK_DEBUG_RES
+__device__ unsigned long long lk_res_dbg[32];   // DEBUG BUILD ONLY: 100 MHz ticks per phase of the resident kernel's two roles; [0..7] filter wave, [8..15] insert wave 1, [31] buckets
+__device__ unsigned long long lk_res_ts[6][1024];   // per bucket: 0 filter posted, 1 insert saw the post, 2 insert posted decided, 3 filter began to wait for decided, 4 filter saw decided, 5 insert done
+#define RS_TS(k, b) do { if ((threadIdx.x & 63) == 0 && (b) < 1024) lk_res_ts[k][b] = wall_clock64(); } while (0)
+#define RS_DECL unsigned long long rs_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0_ = wall_clock64()
+#define RS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); rs_[k] += t1_ - rt0_; rt0_ = t1_; } while (0)
+#define RS_FLUSH(o) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&lk_res_dbg[(o) + k_], rs_[k_]); } while (0)
+#else
+#define RS_TS(k, b) do { } while (0)
+#define RS_DECL do { } while (0)
+#define RS_STAMP(k) do { } while (0)
+#define RS_FLUSH(o) do { } while (0)
+#endif
 template <int MSG, bool XID>
 __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
-                          LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0, unsigned int timeout_ms) {
+                          LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0, unsigned int timeout_ms, LkResume* rs) {
     const unsigned long long resident_timeout_ = (unsigned long long)timeout_ms * 100000ull;   // ticks of the 100 MHz wall clock
     __shared__ WaveSmem sm;
     __shared__ double rows[64 * LK_ROW2];
     __shared__ int f_post, f_decided, f_done;   // bucket index of: latest posterior snapshot / stamps final / insert complete
     __shared__ int team_ctr;                    // arrivals at the insert team's barrier
     __shared__ int f_abort;                     // a wait was given up: every role leaves its loop
+    __shared__ int f_exit;                      // the insert team has left with fallback items pending (LkResume)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LkFilter* f = &filters[0];
     const int nbk = rag_nb(rg, 0);
     if (nbk == 0) return;
     const double* T = rag_t(rg, 0);
     const unsigned long long* po = rag_pt_off(rg, 0);
-    if (tid == 0) f_post = -1, f_decided = -1, f_done = -1, team_ctr = 0, f_abort = 0;
+    const int bf0 = rs->bf, bi0 = rs->bi, stage1_0 = rs->stage1;   // (0, 0, 0) in a scan's first launch
+    if (bf0 >= nbk && bi0 >= nbk) return;
+    if (tid == 0) f_post = bf0 - 1, f_decided = bi0 - 1, f_done = bi0 - 1, team_ctr = 0, f_abort = 0, f_exit = 0;
     __syncthreads();
     if (wv >= 1) {
         // ================================================================= insert team (waves 1 .. LK_INS_WAVES)
         const int rank = wv - 1;
         int phase = 0;
-        for (int b = 0; b < nbk; ++b) {
+        RS_DECL;
+        int b = bi0;
+        for (; b < nbk; ++b) {
             const unsigned long long base = po[b];
             const int n = (int)(po[b + 1] - base);
             LkMap m = map;
             m.epoch = epoch0 + (unsigned int)b;
             const LkFilter* sn = snap2 + (b & 1);
             if (!FLAG_WAIT(f_post, b)) break;
+            if (rank == 0) RS_TS(1, b);
+            RS_STAMP(0);
             if (rank == 0) dev_bucket_begin_wave(m);
             if (!TEAM_BARRIER(team_ctr, phase)) break;
+            RS_STAMP(1);
             for (int i = rank * LK_WAVE + lane; i < n; i += LK_INS_WAVES * LK_WAVE) dev_reproject_point(m, pr, sn, pts + base, world ? world + 4 * base : nullptr, 1, i);
             if (!TEAM_BARRIER(team_ctr, phase)) break;
+            RS_STAMP(2);
             const int n_touched = (int)__hip_atomic_load(&m.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (rank == 0) {
                 if (n_touched > 0) dev_stamp_dirty_roots(m, pr, n_touched);
                 FLAG_POST(f_decided, b);
+                RS_TS(2, b);
             }
             if (n_touched > 0) {
                 if (!TEAM_BARRIER(team_ctr, phase)) break;   // the stamping pass has read the roots' queues before the root pass resets them
+                RS_STAMP(3);
                 dev_insert_root<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
                 if (!TEAM_BARRIER(team_ctr, phase)) break;
+                RS_STAMP(4);
                 dev_insert_apply<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
                 if (!TEAM_BARRIER(team_ctr, phase)) break;
-                dev_insert_fallback<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
+                RS_STAMP(5);
+                // generic fallback items: not in this kernel (LkResume) - every team wave reads the same count behind the barrier and leaves
+                if (__hip_atomic_load(&m.counters[LK_CTR_FALLBACK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+#ifdef LK_DEBUG_RES
+                    rs_[7] += 1;
+#endif
+                    if (rank == 0) {
+                        if (lane == 0) rs->bi = b + 1, rs->fb_bucket = b;
+                        FLAG_POST(f_exit, 1);
+                    }
+                    b = -1;
+                    break;
+                }
             }
             if (!TEAM_BARRIER(team_ctr, phase)) break;
             if (rank == 0) FLAG_POST(f_done, b);
+            if (rank == 0) RS_TS(5, b);
+            RS_STAMP(6);
         }
+        if (rank == 0 && lane == 0 && b == nbk) rs->bi = nbk, rs->fb_bucket = -1;   // (a wait given up: the call fails, LkResume is not read)
+        if (rank == 0) RS_FLUSH(8);
         return;
     }
     // ===================================================================== filter wave
@@ -975,14 +1038,20 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     int last_N = f->last_N, updated = f->updated;
     core_sync<true>();
     unsigned int qi = 0, qn = 0;   // the scan's messages (KILO.cc:379-390: those stamped before the bucket come first)
-    if (MSG) qi = rg.imu_off[0], qn = rg.imu_off[1];
+    if (MSG) qi = rs->qi, qn = rg.imu_off[1];
     constexpr size_t mstride = MSG == 2 ? 33 : 7;
-    for (int b = 0; b < nbk;) {
+    RS_DECL;
+    bool predicted = stage1_0 != 0;   // picked up behind a predict (LkResume::stage1)
+    bool stopped = false;             // left the loop in a wait for the insert team
+    int b = bf0;
+    while (b < nbk) {
         const double tb_ = T[b];
-        const bool is_msg = MSG && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
+        const bool is_msg = !predicted && MSG && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
         const double t = is_msg ? rg.imu[mstride * (size_t)qi] : tb_;
-        wave_predict_core<true>(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
+        if (!predicted) wave_predict_core<true>(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
+        predicted = false;
         t_pred = t;
+        RS_STAMP(0);
         if (is_msg) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
             const double* mm = rg.imu + mstride * (size_t)qi;
             if (MSG == 2)
@@ -991,6 +1060,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
                 wave_imu_update_core<true>(sm, mm + 1, mm + 4, rg.acc_scale, rg.Rn, lane);
             t_upd = t;  // KILO.cc:256 / :312
             ++qi;
+            RS_STAMP(6);
             continue;
         }
         const unsigned long long base = po[b];
@@ -1020,8 +1090,12 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (w4 == 0) a0 += a; else if (w4 == 1) a1 += a; else if (w4 == 2) a2 += a; else a3 += a;
         }
         double totv = (lane < 29) ? (((0.0 + a0) + a1) + a2) + a3 : 0.0;  // tot[j] in lanes 0..31
+        RS_STAMP(1);
         if (b > 0) {
-            if (!FLAG_WAIT(f_decided, b - 1)) break;   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
+            RS_TS(3, b - 1);
+            if (!FLAG_WAIT_X(f_decided, b - 1)) { stopped = true; break; }   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
+            RS_TS(4, b - 1);
+            RS_STAMP(2);
             const unsigned int e_b = epoch0 + (unsigned int)b;
             const unsigned int from = b >= 2 ? e_b - 2u : epoch0;
             bool susp = false;
@@ -1030,7 +1104,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
                 susp = susp || spec_suspect(map, c.x, from) || spec_suspect(map, c.y, from);
             }
             if (__ballot(susp) != 0ull) {
-                if (!FLAG_WAIT(f_done, b - 1)) break;
+                if (!FLAG_WAIT_X(f_done, b - 1)) { stopped = true; break; }
                 if (lane == 0) atomicAdd(&map.counters[LK_CTR_RES_REDO], 1u);
                 a0 = a1 = a2 = a3 = 0.0;
                 for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
@@ -1044,14 +1118,17 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         }
         const int N = (int)(lane_bcast<28>(totv) + 0.5);
         n_buckets += 1, last_N = N, updated = N > 0;
+        RS_STAMP(3);
         if (N > 0) {
             n_updates += 1, n_effect += (unsigned long long)N;
             t_upd = t;  // KILO.cc:212
             wave_update_core<true>(sm, totv, N, lane);
         }
         core_sync<true>();
+        RS_STAMP(4);
         // the posterior for the insert (dev_snapshot_posterior's fields): the buffer of bucket b - 2 is free once that insert is done
-        if (b >= 2 && !FLAG_WAIT(f_done, b - 2)) break;
+        if (b >= 2 && !FLAG_WAIT(f_done, b - 2)) break;   // (never behind a team that has left: its f_decided(b - 1) came after f_done(b - 2))
+        RS_STAMP(7);
         {
             LkFilter* sn = snap2 + (b & 1);
             for (int e = lane; e < 180; e += LK_WAVE) sn->P[e] = sm.P[e];
@@ -1059,17 +1136,40 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (lane == 0) sn->updated = N > 0, sn->last_N = N;
         }
         FLAG_POST(f_post, b);
+        RS_TS(0, b);
         ++b;
+        RS_STAMP(5);
     }
+    RS_FLUSH(0);
+#ifdef LK_DEBUG_RES
+    if (lane == 0) atomicAdd(&lk_res_dbg[31], (unsigned long long)nbk);
+#endif
     // a wait was given up (a fault or a pre-empted GPU): the filter keeps its PRE-SCAN state - the call fails with LK_ERR_TIMEOUT, the
     // map holds a partial insert (restore it from a checkpoint / blob and replay the scan)
     if (__hip_atomic_load(&f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+    // the end of the scan, or the team has left with fallback items pending (stopped): bucket b is predicted to, not updated
+    if (lane == 0) rs->bf = b, rs->stage1 = stopped ? 1 : 0, rs->qi = qi;
     for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
     if (lane < 36) f->x[lane] = sm.x[lane];
     if (lane == 0) {
         f->last_update_t = t_upd, f->last_predict_t = t_pred;
         f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
     }
+}
+// The fallback items the scan-resident kernel left behind (LkResume::fb_bucket): the generic pass of that bucket's insert from the
+// bucket's own snapshot, as a launch of its own between two launches of the resident kernel.
+__global__ void __launch_bounds__(LK_MB)
+    lk_resident_fallback_kernel(LkMap map, LkParams pr, const LkFilter* snap2, const lk_point* __restrict__ pts, LkRagged rg, unsigned int epoch0, LkResume* rs) {
+    const int b = rs->fb_bucket;
+    if (b < 0) return;
+    const unsigned long long* po = rag_pt_off(rg, 0);
+    const unsigned long long base = po[b];
+    const int n = (int)(po[b + 1] - base);
+    LkMap m = map;
+    m.epoch = epoch0 + (unsigned int)b;
+    dev_insert_fallback<false>(m, pr, snap2 + (b & 1), pts + base, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
+    __syncthreads();
+    if (threadIdx.x == 0) rs->fb_bucket = -1;
 }
 extern "C" {
 
@@ -1559,8 +1659,11 @@ static int fetch_poses(lk_handle* h, lk_pose* out, int n) {
 // End of a stream-path scan: the pose of filter slot 0 and the map's counter words (pool overflow / timeout bits) written by ONE kernel
 // straight into host-mapped pinned memory, ONE stream synchronisation - instead of a gather kernel, two pageable device-to-host copies
 // and two synchronisations (round 5: ~100 us of every scan's 430 were spent between its last kernel and the next scan's first).
-__global__ void lk_scan_finish_kernel(const LkFilter* filters, const unsigned int* counters, lk_handle::ScanResult* out, unsigned int seq) {
+__global__ void lk_scan_finish_kernel(const LkFilter* filters, const unsigned int* counters, lk_handle::ScanResult* out, unsigned int seq, const int* resume) {
     const int i = threadIdx.x;
+    if (i == 1) {   // LkResume { bf, stage1, qi, bi, fb_bucket } of a scan-resident launch
+        out->resume[0] = resume ? resume[0] : 0, out->resume[1] = resume ? resume[3] : 0, out->resume[2] = resume ? resume[4] : -1, out->resume[3] = 0;
+    }
     if (i == 0) {
         const LkFilter* f = &filters[0];
         lk_pose p;
@@ -1576,14 +1679,14 @@ __global__ void lk_scan_finish_kernel(const LkFilter* filters, const unsigned in
         __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-static int finish_scan(lk_handle* h, lk_pose* pose) {
+static int finish_scan(lk_handle* h, lk_pose* pose, const void* d_resume = nullptr) {
     if (!h->h_result) {
         HIPCHK(h, hipHostMalloc((void**)&h->h_result, sizeof(lk_handle::ScanResult), hipHostMallocMapped));
         memset(h->h_result, 0, sizeof(lk_handle::ScanResult));
         HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
     }
     const unsigned int seq = ++h->result_seq ? h->result_seq : ++h->result_seq;   // never 0 (the buffer's initial value)
-    hipLaunchKernelGGL(lk_scan_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->d_filters, h->map.counters, h->d_result, seq);
+    hipLaunchKernelGGL(lk_scan_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->d_filters, h->map.counters, h->d_result, seq, static_cast<const int*>(d_resume));
     HIPCHK(h, hipGetLastError());
     // a scan is a fraction of a millisecond to a few: the caller's thread POLLS the sequence word the kernel writes last (a blocking
     // synchronisation wakes through an interrupt, 10-20 us later) - for at most 20 ms, then it blocks (which also surfaces device errors).
@@ -2200,11 +2303,14 @@ static int backup_filter(lk_handle* h) {
 }
 // The bucket loop of KILO::process for a scan of small buckets as ONE launch (lk_scan_stream_kernel).  bstart[k] / btime[k]: first
 // point and absolute time of bucket k (nb buckets, bstart[nb] = n); the messages are the scan's lk_imu or lk_kin_imu records.
+// The scan's result comes back through finish_scan; a launch that stopped at fallback items is followed by lk_resident_fallback_kernel and
+// another launch from where it stopped, until the scan is through (LkResume).
 static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vector<unsigned long long>& bstart, const std::vector<double>& btime,
-                             const void* msgs, size_t n_msg, int msg_kind, float* d_world) {
+                             const void* msgs, size_t n_msg, int msg_kind, float* d_world, lk_pose* pose) {
     const size_t nb = btime.size();
     const size_t msg_bytes = msg_kind == 2 ? sizeof(lk_kin_imu) : sizeof(lk_imu);
-    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_im = o_t + 8 * nb, o_nb = o_im + msg_bytes * n_msg, o_io = o_nb + 8, bytes = o_io + 8;
+    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_im = o_t + 8 * nb, o_nb = o_im + msg_bytes * n_msg, o_io = o_nb + 8, o_rs = o_io + 8,
+                 bytes = o_rs + sizeof(LkResume);
     int rc = rag_reserve(h, bytes);
     if (rc) return rc;
     unsigned char* stage = static_cast<unsigned char*>(h->h_rag);
@@ -2214,8 +2320,15 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
     const unsigned int nbu[2] = {(unsigned int)nb, 0u}, io[2] = {0u, (unsigned int)n_msg};
     memcpy(stage + o_nb, nbu, 8);
     memcpy(stage + o_io, io, 8);
+    {
+        LkResume r0;
+        memset(&r0, 0, sizeof(r0));
+        r0.fb_bucket = -1;
+        memcpy(stage + o_rs, &r0, sizeof(r0));
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
     unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
+    LkResume* d_rs = reinterpret_cast<LkResume*>(dr + o_rs);
     LkRagged rg;
     rg.pt_off = reinterpret_cast<const unsigned long long*>(dr + o_po);
     rg.t = reinterpret_cast<const double*>(dr + o_t);
@@ -2241,12 +2354,55 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
     h->epoch += (unsigned int)nb;
     h->spec_base = h->epoch + 1u;
     static const unsigned int timeout_ms = getenv("LEGKILO_RESIDENT_TIMEOUT_MS") ? (unsigned int)std::max(1, atoi(getenv("LEGKILO_RESIDENT_TIMEOUT_MS"))) : LK_RESIDENT_TIMEOUT_MS;
-    void (*k)(LkMap, LkParams, LkFilter*, const lk_point*, LkRagged, const double*, LkFilter*, float*, int2*, unsigned int, unsigned int) =
+    void (*k)(LkMap, LkParams, LkFilter*, const lk_point*, LkRagged, const double*, LkFilter*, float*, int2*, unsigned int, unsigned int, LkResume*) =
         msg_kind == 2 ? (xid ? lk_scan_stream_kernel<2, true> : lk_scan_stream_kernel<2, false>)
       : msg_kind == 1 ? (xid ? lk_scan_stream_kernel<1, true> : lk_scan_stream_kernel<1, false>)
                       : (xid ? lk_scan_stream_kernel<0, true> : lk_scan_stream_kernel<0, false>);
+    h->resident_scans += 1;
+    for (size_t round = 0;; ++round) {
     LAUNCH(h, "scan_stream", hipLaunchKernelGGL(k, dim3(1), dim3((1 + LK_INS_WAVES) * LK_WAVE), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                                h->d_ids, epoch0, timeout_ms));
+                                                h->d_ids, epoch0, timeout_ms, d_rs));
+#ifdef LK_DEBUG_RES
+    {
+        unsigned long long hb[32];
+        hipStreamSynchronize(h->stream);
+        hipMemcpyFromSymbol(hb, HIP_SYMBOL(lk_res_dbg), sizeof(hb));
+        const double nbk = (double)hb[31];
+        const char* fn[8] = {"predict", "tiles", "wait-decided", "suspects(+redo)", "update", "snapshot+post", "messages", "wait-done(b-2)"};
+        const char* in[8] = {"wait-post", "begin", "reproject", "stamp", "root", "apply", "fallback+done", "-"};
+        fprintf(stderr, "[resident] %.0f buckets; filter wave (us per bucket):", nbk);
+        for (int q = 0; q < 8; ++q) fprintf(stderr, " %s %.2f;", fn[q], (double)hb[q] / nbk * 0.01);
+        fprintf(stderr, "\n[resident] insert wave 1:");
+        for (int q = 0; q < 7; ++q) fprintf(stderr, " %s %.2f;", in[q], (double)hb[8 + q] / nbk * 0.01);
+        fprintf(stderr, " buckets with fallback items %llu\n", hb[15]);
+        {
+            static unsigned long long ts[6][1024];
+            hipMemcpyFromSymbol(ts, HIP_SYMBOL(lk_res_ts), sizeof(ts));
+            const int nbq = (int)std::min<size_t>(nb, 1024);
+            double a01 = 0, a12 = 0, a24 = 0, a34 = 0, a25 = 0, a00 = 0;
+            int c = 0;
+            for (int b = 2; b + 2 < nbq; ++b, ++c) {
+                a01 += (double)(long long)(ts[1][b] - ts[0][b]), a12 += (double)(long long)(ts[2][b] - ts[1][b]), a24 += (double)(long long)(ts[4][b] - ts[2][b]);
+                a34 += (double)(long long)(ts[4][b] - ts[3][b]), a25 += (double)(long long)(ts[5][b] - ts[2][b]), a00 += (double)(long long)(ts[0][b + 1] - ts[0][b]);
+            }
+            if (c) fprintf(stderr, "[resident] hand-offs (us, mean over %d buckets): post -> insert sees it %.2f; -> decided posted %.2f; -> filter sees it %.2f (filter had waited %.2f); decided -> done %.2f; post to post %.2f\n",
+                           c, a01 / c * 0.01, a12 / c * 0.01, a24 / c * 0.01, a34 / c * 0.01, a25 / c * 0.01, a00 / c * 0.01);
+            for (int b = 100; b < 104 && b + 1 < nbq; ++b)
+                fprintf(stderr, "[resident]   bucket %d: post 0, seen %+.2f, decided %+.2f, filter waits from %+.2f, sees %+.2f, done %+.2f, next post %+.2f\n", b,
+                        (double)(long long)(ts[1][b] - ts[0][b]) * 0.01, (double)(long long)(ts[2][b] - ts[0][b]) * 0.01, (double)(long long)(ts[3][b] - ts[0][b]) * 0.01,
+                        (double)(long long)(ts[4][b] - ts[0][b]) * 0.01, (double)(long long)(ts[5][b] - ts[0][b]) * 0.01, (double)(long long)(ts[0][b + 1] - ts[0][b]) * 0.01);
+        }
+        memset(hb, 0, sizeof(hb));
+        hipMemcpyToSymbol(HIP_SYMBOL(lk_res_dbg), hb, sizeof(hb));
+    }
+#endif
+        if ((rc = finish_scan(h, pose, d_rs))) return rc;
+        const int* rsm = h->h_result->resume;
+        if (rsm[0] >= (int)nb && rsm[1] >= (int)nb && rsm[2] < 0) break;   // filter wave and insert team are through
+        if (rsm[2] < 0 || round > nb + 4) return fail(h, LK_ERR_STATE, "the scan-resident kernel stopped without a reason: filter wave at bucket " + std::to_string(rsm[0]) + ", insert team at " + std::to_string(rsm[1]) + " of " + std::to_string(nb));
+        h->resident_relaunches += 1;
+        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, epoch0, d_rs));
+    }
     return LK_OK;
 }
 // The bucket loop of a scan of LARGE buckets as one grid-resident launch (lk_scan_grid_kernel); same table layout as run_scan_resident.
@@ -2349,16 +2505,16 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
             return LK_OK;
         }
         if (resident_enabled(h) && biggest <= LK_RESIDENT_MAX) {
+            lk_pose pose;
             rc = run_scan_resident(h, d_pts, bstart, btime, n_kin ? (const void*)kins : (const void*)imus, n_kin ? n_kin : n_imu, n_kin ? 2 : (n_imu ? 1 : 0),
-                                   xyz_world_out ? h->d_world : nullptr);
+                                   xyz_world_out ? h->d_world : nullptr, &pose);
             if (rc) return rc;
             std::vector<float> w;
             if (xyz_world_out) {
                 w.resize(4 * n);
                 HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
             }
-            lk_pose pose;
-            if ((rc = finish_scan(h, &pose))) return rc;
             if (xyz_world_out)
                 for (size_t i = 0; i < n; ++i)
                     for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
@@ -2447,9 +2603,8 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
             return LK_OK;
         }
         if (!btime.empty() && resident_enabled(h) && biggest <= LK_RESIDENT_MAX) {
-            if ((rc = run_scan_resident(h, d_pts, bstart, btime, nullptr, 0, 0, nullptr))) return rc;
             lk_pose pose;
-            if ((rc = finish_scan(h, &pose))) return rc;
+            if ((rc = run_scan_resident(h, d_pts, bstart, btime, nullptr, 0, 0, nullptr, &pose))) return rc;
             if (out) *out = pose;
             return LK_OK;
         }
@@ -3685,6 +3840,12 @@ int lk_stream_resident(lk_handle* h, int on) {
 int lk_stream_grid(lk_handle* h, int on) {
     CHECK_H(h);
     h->gridscan_mode = std::min(std::max(on, 0), 2);
+    return LK_OK;
+}
+int lk_stream_resident_stats(lk_handle* h, uint64_t* out2) {
+    CHECK_H(h);
+    if (!out2) return fail(h, LK_ERR_INVALID, "out2 is null");
+    out2[0] = h->resident_scans, out2[1] = h->resident_relaunches;
     return LK_OK;
 }
 int lk_stream_stats(lk_handle* h, uint64_t* out4) {

@@ -611,6 +611,7 @@ def test_scan_resident_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_
         assert np.array_equal(wg, wp)
     scenes.maps_identical(g.map_export(), g_pb.map_export())
     scenes.compare_maps(o.map_export(), g.map_export(), rtol=1e-5, ptol=1e-7)
+    print("scan-resident kernel: scans, launches beyond one per scan:", g.stream_resident_stats())
     for obj in (g, g_pb, o):
         obj.close()
 
@@ -635,6 +636,15 @@ def test_scan_resident_kernel_edge_buckets(scene, oracle_lib, hip_lib):
         pts = src.copy()
         curv = np.concatenate([np.full(n_, np.float32(0.002 * (i + 1))) for i, n_ in enumerate(sizes)])
         pts["curvature"] = curv
+        # generic fallback items inside the scan: 90 points piled into ONE new voxel (a root with more than 64 queued points) in the 257-point
+        # bucket, volumetric clutter (voxels that are cut, init_octo_tree / cut_octo_tree) in the 300-point one
+        rngk = np.random.default_rng(8100 + k)
+        o257, o300 = sum(sizes[:5]), sum(sizes[:7])
+        pile = np.array([60.0 + 3.0 * k, -45.0, 12.0]) + rngk.uniform(0.02, 0.23, (90, 3))
+        clutter = np.array([14.0, 9.0 + 2.0 * k, 2.0]) + rngk.uniform(-0.7, 0.7, (300, 3))
+        for c, ax in enumerate("xyz"):
+            pts[ax][o257:o257 + 90] = pile[:, c].astype(np.float32)
+            pts[ax][o300:o300 + 300] = clutter[:, c].astype(np.float32)
         imus = synth.imu_stream(scene.traj, tb - 0.004, tb + 0.1, seed=5003 + k)   # some stamped before the first bucket, some after the last
         po, _ = o.process_scan(pts, tb, imus=imus)
         pg, wg = g.process_scan(pts, tb, imus=imus, want_world=True)
@@ -646,6 +656,11 @@ def test_scan_resident_kernel_edge_buckets(scene, oracle_lib, hip_lib):
         assert np.abs(xo - xg).max() < 1e-7, (k, np.abs(xo - xg).max())
         assert np.array_equal(xg, xp) and np.array_equal(Pg, Pp) and np.array_equal(wg, wp), k
     scenes.maps_identical(g.map_export(), g_pb.map_export())
+    # buckets of hundreds of points on a young map queue more than 64 points on a root and cut voxels: generic fallback items, which end a
+    # launch of the resident kernel, run as a launch of their own and have the kernel launched again from where it stopped (LkResume)
+    n_scans, n_relaunch = g.stream_resident_stats()
+    print(f"scan-resident kernel: {n_scans} scans, {n_relaunch} launches beyond one per scan (fallback rounds)")
+    assert n_scans == 3 and n_relaunch >= 1, (n_scans, n_relaunch)
     # a one-bucket, one-point scan
     one = src[:1].copy()
     one["curvature"] = 0.0
