@@ -563,6 +563,12 @@ class LegKiloHip:
         self._chk(self.L.lk_stream_resident_stats(self.h, _p(out)))
         return int(out[0]), int(out[1])
 
+    def stream_resident_redo(self):
+        """Buckets the scan-resident kernel's filter wave evaluated again after a conflicting insert (lk_stream_stats' fourth word)."""
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(self.L.lk_stream_stats(self.h, _p(out)))
+        return int(out[3])
+
     def stream_stats(self):
         """(pipelined buckets, their residual tiles, tiles the verify pass evaluated again)."""
         out = np.zeros(4, dtype=np.uint64)

@@ -937,6 +937,9 @@ struct LkResume {
     int fb_bucket;     // the bucket whose fallback items are pending (its snapshot: snap2[fb_bucket & 1]); -1: none
     int pad_[3];
 };
+#ifndef LK_X_SLEEP
+#define LK_X_SLEEP 0   // sensitivity probes (never in the product build): ~1 us of sleep per bucket on 1 the filter wave, 2 the insert team before / 4 behind its stamps
+#endif
 #ifdef LK_DEBUG_RES
 __device__ unsigned long long lk_res_dbg[32];   // DEBUG BUILD ONLY: 100 MHz ticks per phase of the resident kernel's two roles; [0..7] filter wave, [8..15] insert wave 1, [31] buckets
 __device__ unsigned long long lk_res_ts[6][1024];   // per bucket: 0 filter posted, 1 insert saw the post, 2 insert posted decided, 3 filter began to wait for decided, 4 filter saw decided, 5 insert done
@@ -987,6 +990,9 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (rank == 0) RS_TS(1, b);
             RS_STAMP(0);
             if (rank == 0) dev_bucket_begin_wave(m);
+#if LK_X_SLEEP & 2
+            if (rank == 0) __builtin_amdgcn_s_sleep(38);   // sensitivity probe: ~1 us on the insert team's chain, before its stamps are final
+#endif
             if (!TEAM_BARRIER(team_ctr, phase)) break;
             RS_STAMP(1);
             for (int i = rank * LK_WAVE + lane; i < n; i += LK_INS_WAVES * LK_WAVE) dev_reproject_point(m, pr, sn, pts + base, world ? world + 4 * base : nullptr, 1, i);
@@ -1020,6 +1026,9 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
                     break;
                 }
             }
+#if LK_X_SLEEP & 4
+            if (rank == 0) __builtin_amdgcn_s_sleep(38);   // sensitivity probe: ~1 us on the insert team's chain, behind its stamps
+#endif
             if (!TEAM_BARRIER(team_ctr, phase)) break;
             if (rank == 0) FLAG_POST(f_done, b);
             if (rank == 0) RS_TS(5, b);
@@ -1046,6 +1055,9 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     int b = bf0;
     while (b < nbk) {
         const double tb_ = T[b];
+#if LK_X_SLEEP & 1
+        __builtin_amdgcn_s_sleep(38);   // sensitivity probe: ~1 us on the filter wave's chain
+#endif
         const bool is_msg = !predicted && MSG && qi < qn && rg.imu[mstride * (size_t)qi] < tb_;
         const double t = is_msg ? rg.imu[mstride * (size_t)qi] : tb_;
         if (!predicted) wave_predict_core<true>(sm, Q, t - t_upd, t - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115 / :240-244
@@ -2375,6 +2387,17 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
         fprintf(stderr, "\n[resident] insert wave 1:");
         for (int q = 0; q < 7; ++q) fprintf(stderr, " %s %.2f;", in[q], (double)hb[8 + q] / nbk * 0.01);
         fprintf(stderr, " buckets with fallback items %llu\n", hb[15]);
+        {
+            unsigned long long cd[16];
+            hipMemcpyFromSymbol(cd, HIP_SYMBOL(lk_core_dbg), sizeof(cd));
+            const double np_ = (double)(cd[7] ? cd[7] : 1), nu_ = (double)(cd[15] ? cd[15] : 1);
+            fprintf(stderr, "[resident] predict core (%llu calls), us: rotations %.2f; rows of Fx P %.2f; columns %.2f; Q + state %.2f\n", cd[7],
+                    cd[0] / np_ * 0.01, cd[1] / np_ * 0.01, cd[2] / np_ * 0.01, cd[3] / np_ * 0.01);
+            fprintf(stderr, "[resident] update core (%llu calls), us: columns %.2f; Gauss-Jordan %.2f; X + dx %.2f; P update %.2f; rotation(s) + state %.2f\n", cd[15],
+                    cd[8] / nu_ * 0.01, cd[9] / nu_ * 0.01, cd[10] / nu_ * 0.01, cd[11] / nu_ * 0.01, cd[12] / nu_ * 0.01);
+            memset(cd, 0, sizeof(cd));
+            hipMemcpyToSymbol(HIP_SYMBOL(lk_core_dbg), cd, sizeof(cd));
+        }
         {
             static unsigned long long ts[6][1024];
             hipMemcpyFromSymbol(ts, HIP_SYMBOL(lk_res_ts), sizeof(ts));

@@ -415,6 +415,16 @@ __device__ __forceinline__ void dev_snapshot_posterior(const LkFilter* f, LkFilt
 // test_batch_replay_frozen_map compares the two entry points that use them.
 // mode bit 0: reduce + update (eskf.cc:91-113 and the bookkeeping of KILO.cc:193,211-212);  bit 1: predict to t_next
 // (KILO.cc:111-115) in the same launch.
+#ifdef LK_DEBUG_RES
+__device__ unsigned long long lk_core_dbg[16];   // DEBUG BUILD ONLY: 100 MHz ticks per phase of the one-wave cores (MW instances): [0..4] predict, [8..13] update, [7] / [15] calls
+#define CORE_T0 unsigned long long ct0_ = MW ? wall_clock64() : 0ull
+#define CORE_STAMP(k) do { if (MW) { const unsigned long long t1_ = wall_clock64(); if (lane == 0) atomicAdd(&lk_core_dbg[k], t1_ - ct0_); ct0_ = t1_; } } while (0)
+#define CORE_COUNT(k) do { if (MW && lane == 0) atomicAdd(&lk_core_dbg[k], 1ull); } while (0)
+#else
+#define CORE_T0 do { } while (0)
+#define CORE_STAMP(k) do { } while (0)
+#define CORE_COUNT(k) do { } while (0)
+#endif
 struct WaveSmem {
     double P[900];
     double x[36];
@@ -424,14 +434,23 @@ struct WaveSmem {
 static_assert(sizeof(WaveSmem) == 7680, "one residual workgroup's worth of LDS");
 
 // Barrier of the one-wave filter cores.  They were written for single-wave workgroups, where __syncthreads() is the wave's own
-// barrier; MW = true lets ONE wave of a larger workgroup run them (the scan-resident stream kernel, legkilo_hip.hip): the LDS
-// traffic of one wave is ordered by a workgroup-scope fence + wave barrier, without involving the other waves.
+// barrier; MW = true lets ONE wave of a larger workgroup run them (the scan-resident stream kernel, legkilo_hip.hip).  The state they
+// work on (WaveSmem and the row area) is touched by that wave alone, and the LDS executes one wave's instructions in issue order: what
+// is needed is that the COMPILER keeps the order - wavefront-scope fences + a wave barrier, no s_waitcnt.  (Workgroup scope, as first
+// written, drains the wave's LDS AND vector-memory queues at every one of the ~15 barriers of a bucket.)
+#ifndef LK_CORE_SYNC_WG
+#define LK_CORE_SYNC_WG 0
+#endif
 template <bool MW>
 __device__ __forceinline__ void core_sync() {
-    if (MW) {
+    if (MW && LK_CORE_SYNC_WG) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else if (MW) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
         __syncthreads();
     }
@@ -450,6 +469,8 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         if (lane < 27) totv *= sc;
     }
     core_sync<MW>();  // sm.P, sm.x loaded
+    CORE_T0;
+    CORE_COUNT(15);
     // -- augmented column of this lane: lanes 0..5 S[:,lane] = I + (A P)[:,lane]; lanes 6..35 G[:,lane-6]; lane 36 b
     const int pc = lane < 6 ? lane : (lane < 36 ? lane - 6 : 29);
     double col[6];
@@ -461,6 +482,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         double bi = lane_bcast_u(totv, 21 + i);
         col[i] = lane == 36 ? bi : (lane < 6 ? ((i == lane) ? 1.0 : 0.0) + s : s);
     }
+    CORE_STAMP(8);
     // -- Gauss-Jordan with partial pivoting (dev_solve), one column per lane
 #pragma unroll
     for (int k = 0; k < ((LK_X_P & 8) ? 0 : 6); ++k) {
@@ -493,6 +515,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
             col[i] -= fi * col[k];
         }
     }
+    CORE_STAMP(9);
 #pragma unroll
     for (int i = 0; i < 6; ++i) col[i] = col[i] / lane_bcast_u(col[i], i);  // X = G / diag(S)
     // -- dx = P[:,0:6] X[:,30]
@@ -562,6 +585,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         core_sync<MW>();
     }
 #else
+    CORE_STAMP(10);
     // -- P -= P[:,0:6] X[:,0:30]: lane -> column lane % 30, rows 15 * (lane / 30) ...  A row's new values depend on
     // that row only, so five rows at a time are read, then written.
     {
@@ -589,6 +613,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         }
     }
 #endif
+    CORE_STAMP(11);
     // -- x (+)= dx (eskf.cc:18-29): rotation by lane 0, the 27 additive components by lanes 3..29
     const double d0 = lane_bcast_u(dxv, 0), d1 = lane_bcast_u(dxv, 1), d2 = lane_bcast_u(dxv, 2);
     if (lane == 0 && !(LK_X_P & 32)) {
@@ -599,6 +624,7 @@ __device__ __forceinline__ void wave_update_core(WaveSmem& sm, double totv, int 
         for (int i = 0; i < 9; ++i) sm.x[i] = Rn[i];
     }
     if (lane >= 3 && lane < 30) sm.x[6 + lane] += dxv;
+    CORE_STAMP(12);
 }
 
 // The point update of the 256-thread kernels (lk_update_kernel, lk_update_snap_kernel, lk_small_bucket_kernel) through the one-wave core:
@@ -924,6 +950,8 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
     // ~4 k-cycle dependent chain each).  Lane 1 keeps the propagated rotation / position / velocity in registers until the
     // covariance product has read the old rotation out of sm.x.
     double Rn[9], dpv[6];
+    CORE_T0;
+    CORE_COUNT(7);
     if (lane < 2 && !(LK_X_P & 1)) {
         const double* x = sm.x;
         const double sc = lane == 0 ? -dt_cov : dt;
@@ -945,6 +973,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
         }
     }
     core_sync<MW>();
+    CORE_STAMP(0);
     const double* E = sm.fx;
     const double* B60 = sm.fx + 9;
     // Fx differs from I in three row blocks of different shape (eskf.cc:72-81): rows 0..2 = [E | dt I at col 21], rows 3..5 =
@@ -991,6 +1020,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
         }
     }
     core_sync<MW>();
+    CORE_STAMP(1);
     if (!(LK_X_P & 2)) {  // columns 0..8 of B * Fx^T, in place: the same three shapes, 30 rows x 3 columns each
         double nc[6];
 #pragma unroll
@@ -1035,6 +1065,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
         }
     }
     core_sync<MW>();
+    CORE_STAMP(2);
     const double dt2 = dt_cov * dt_cov;
     if (LK_X_P & 4) {
     } else if (q_diag) {   // Q of initProcessCovQ (eskf.cc:47-62) is diagonal: the other 870 terms are + dt^2 * 0
@@ -1048,6 +1079,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
         for (int i = 0; i < 6; ++i) x[9 + i] += dpv[i];
     }
     core_sync<MW>();
+    CORE_STAMP(3);
 }
 
 __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const double* __restrict__ part, int nblk, double t,

@@ -44,6 +44,9 @@ if args.spec >= 0:
     g.stream_pipeline(args.spec)
 B.build_map(g, traj, P, first, warm, warm_t)
 print("map", g.map_stats(), file=sys.stderr)
+g.stream_stats()   # (debug builds print and RESET their device-side histograms here: what follows is the timed stream alone)
+print("---- timed stream", file=sys.stderr)
+redo0 = g.stream_resident_redo()
 for rep in range(args.reps):
     g.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30))
     g.set_times(t_after, t_after)
@@ -66,5 +69,5 @@ for rep in range(args.reps):
             o += sc.nbytes
         g.device_free(d)
     print(f"kind {args.kind} spec {args.spec} xcc_mask {g.stream_grid_placement():#x} rep {rep}: ms/scan median {1e3 * float(np.median(tl[1:])):.3f} min {1e3 * min(tl[1:]):.3f} "
-          f"buckets/scan {len(synth.buckets_of(scans[-1])[0]) - 1} points {len(scans[-1])} stats {g.stream_stats()}")
+          f"buckets/scan {len(synth.buckets_of(scans[-1])[0]) - 1} points {len(scans[-1])} stats {g.stream_stats()} resident: redo {g.stream_resident_redo() - redo0} of {sum(len(synth.buckets_of(sc)[0]) - 1 for sc in scans)} buckets, (scans, relaunches) {g.stream_resident_stats()}")
 g.close()
