@@ -81,7 +81,7 @@ struct lk_handle {
         int resume[4];               // scan-resident kernel: LkResume's bf, bi, fb_bucket (where the launch stopped), 0
         unsigned int seq, pad_;      // written last: the host may poll it instead of blocking in hipStreamSynchronize
     };
-    uint64_t resident_scans = 0, resident_relaunches = 0;   // lk_stream_resident_stats
+    uint64_t resident_scans = 0, resident_relaunches = 0, grid_scans = 0, grid_relaunches = 0;   // lk_stream_resident_stats
     unsigned int result_seq = 0;
     ScanResult* h_result = nullptr;   // hipHostMalloc(mapped)
     ScanResult* d_result = nullptr;   // its device-side address
@@ -1168,20 +1168,21 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         f->n_effect = n_effect, f->n_updates = n_updates, f->n_buckets = n_buckets, f->last_N = last_N, f->updated = updated;
     }
 }
-// The fallback items the scan-resident kernel left behind (LkResume::fb_bucket): the generic pass of that bucket's insert from the
-// bucket's own snapshot, as a launch of its own between two launches of the resident kernel.
+// The fallback items a resident kernel (scan-resident or grid-resident) left behind (LkResume::fb_bucket): the generic pass of that bucket's
+// insert from the bucket's own snapshot, as a launch of its own between two launches of the resident kernel.  two_snaps: the scan-resident
+// kernel's snapshots alternate (snap[b & 1]) and its buckets carry their own epoch; the grid-resident kernel has one snapshot, epoch as it is.
 __global__ void __launch_bounds__(LK_MB)
-    lk_resident_fallback_kernel(LkMap map, LkParams pr, const LkFilter* snap2, const lk_point* __restrict__ pts, LkRagged rg, unsigned int epoch0, LkResume* rs) {
+    lk_resident_fallback_kernel(LkMap map, LkParams pr, const LkFilter* snap, const lk_point* __restrict__ pts, LkRagged rg, unsigned int epoch0, int two_snaps,
+                                const LkResume* rs) {
     const int b = rs->fb_bucket;
     if (b < 0) return;
     const unsigned long long* po = rag_pt_off(rg, 0);
     const unsigned long long base = po[b];
     const int n = (int)(po[b + 1] - base);
     LkMap m = map;
-    m.epoch = epoch0 + (unsigned int)b;
-    dev_insert_fallback<false>(m, pr, snap2 + (b & 1), pts + base, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
-    __syncthreads();
-    if (threadIdx.x == 0) rs->fb_bucket = -1;
+    if (two_snaps) m.epoch = epoch0 + (unsigned int)b;
+    dev_insert_fallback<false>(m, pr, snap + (two_snaps ? (b & 1) : 0), pts + base, (const lk_pt_rec*)nullptr, n, (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6),
+                               (int)((gridDim.x * LK_MB) >> 6));
 }
 extern "C" {
 
@@ -1203,7 +1204,7 @@ template <bool XID>
 __global__ void __launch_bounds__(LK_FB)
     lk_scan_grid_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
                         LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort, [2] XCC ids seen */, unsigned int timeout_ms,
-                        int stride) {
+                        int stride, int b0 /* first bucket; > 0: the predict to its time has been applied */, LkResume* rs) {
     __shared__ FilterSmem sm;
     __shared__ double red[8][LK_NPART];
     __shared__ double tot[LK_NPART];
@@ -1271,9 +1272,9 @@ __global__ void __launch_bounds__(LK_FB)
         return s_abort == 0;
     };
     __syncthreads();
-    if (wg == 0) dev_predict(&filters[0], Q, T[0], sm);   // KILO.cc:111-115 for the first bucket
+    if (wg == 0 && b0 == 0) dev_predict(&filters[0], Q, T[0], sm);   // KILO.cc:111-115 for the first bucket
     if (!grid_barrier()) return;
-    for (int b = 0; b < nbk; ++b) {
+    for (int b = b0; b < nbk; ++b) {
         const unsigned long long base = po[b];
         const int n = (int)(po[b + 1] - base);
         const int ntiles = (n + LK_WAVE - 1) / LK_WAVE;
@@ -1318,13 +1319,17 @@ __global__ void __launch_bounds__(LK_FB)
                 dev_insert_apply<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
                 if (!grid_barrier()) return;
             }
+            // generic fallback items (dev_insert_fallback: 250 more registers, 6.5 KB of scratch per lane) are not part of this kernel: every
+            // workgroup reads the same count behind the barrier and leaves; lk_resident_fallback_kernel runs them from the snapshot, the next
+            // launch picks up at bucket b + 1, whose predict workgroup 0 has applied beside the re-projection (LkResume, run_scan_grid)
             const unsigned int n_fb = __hip_atomic_load(&map.counters[LK_CTR_FALLBACK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n_fb) {
-                dev_insert_fallback<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
-                if (!grid_barrier()) return;
+                if (wg == 0 && tid == 0) rs->bf = b + 1, rs->bi = b + 1, rs->fb_bucket = b;
+                return;
             }
         }
     }
+    if (wg == 0 && tid == 0) rs->bf = nbk, rs->bi = nbk, rs->fb_bucket = -1;
 }
 extern "C" {
 
@@ -2420,19 +2425,26 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
     }
 #endif
         if ((rc = finish_scan(h, pose, d_rs))) return rc;
-        const int* rsm = h->h_result->resume;
-        if (rsm[0] >= (int)nb && rsm[1] >= (int)nb && rsm[2] < 0) break;   // filter wave and insert team are through
-        if (rsm[2] < 0 || round > nb + 4) return fail(h, LK_ERR_STATE, "the scan-resident kernel stopped without a reason: filter wave at bucket " + std::to_string(rsm[0]) + ", insert team at " + std::to_string(rsm[1]) + " of " + std::to_string(nb));
+        const int* rsm = h->h_result->resume;   // { filter wave's next bucket, insert team's next bucket, bucket with fallback items pending }
+        if (rsm[2] < 0) {
+            if (rsm[0] >= (int)nb && rsm[1] >= (int)nb) break;   // both roles are through
+            return fail(h, LK_ERR_STATE, "the scan-resident kernel stopped without a reason: filter wave at bucket " + std::to_string(rsm[0]) + ", insert team at " + std::to_string(rsm[1]) + " of " + std::to_string(nb));
+        }
+        if (round > nb + 4) return fail(h, LK_ERR_STATE, "the scan-resident kernel does not advance");
         h->resident_relaunches += 1;
-        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, epoch0, d_rs));
+        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, epoch0, 1, d_rs));
+        if (rsm[0] >= (int)nb && rsm[1] >= (int)nb) {   // they were the last bucket's: nothing to pick up
+            if ((rc = finish_scan(h, pose, nullptr))) return rc;
+            break;
+        }
     }
     return LK_OK;
 }
 // The bucket loop of a scan of LARGE buckets as one grid-resident launch (lk_scan_grid_kernel); same table layout as run_scan_resident.
 static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<unsigned long long>& bstart, const std::vector<double>& btime,
-                         size_t biggest, float* d_world) {
+                         size_t biggest, float* d_world, lk_pose* pose) {
     const size_t nb = btime.size();
-    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_nb = o_t + 8 * nb, o_io = o_nb + 8, o_sync = o_io + 8, bytes = o_sync + 16;
+    const size_t o_po = 0, o_t = o_po + 8 * (nb + 1), o_nb = o_t + 8 * nb, o_io = o_nb + 8, o_sync = o_io + 8, o_rs = o_sync + 16, bytes = o_rs + sizeof(LkResume);
     int rc = rag_reserve(h, bytes);
     if (rc) return rc;
     unsigned char* stage = static_cast<unsigned char*>(h->h_rag);
@@ -2442,6 +2454,12 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     memcpy(stage + o_nb, nbu, 8);
     memcpy(stage + o_io, io, 8);
     memcpy(stage + o_sync, zero4, 16);
+    {
+        LkResume r0;
+        memset(&r0, 0, sizeof(r0));
+        r0.fb_bucket = -1;
+        memcpy(stage + o_rs, &r0, sizeof(r0));
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_rag, stage, bytes, hipMemcpyHostToDevice, h->stream));
     if ((rc = backup_filter(h))) return rc;
     unsigned char* dr = static_cast<unsigned char*>(h->d_rag);
@@ -2481,8 +2499,28 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     static const bool one_xcd_en = getenv("LEGKILO_GRIDSCAN_XCD") == nullptr || atoi(getenv("LEGKILO_GRIDSCAN_XCD")) != 0;
     const int stride = (one_xcd_en && G <= 32) ? 8 : 1;
     const auto k = xid ? lk_scan_grid_kernel<true> : lk_scan_grid_kernel<false>;
-    LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                              h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride));
+    LkResume* d_rs = reinterpret_cast<LkResume*>(dr + o_rs);
+    h->grid_scans += 1;
+    int b0 = 0;
+    for (size_t round = 0;; ++round) {
+        LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
+                                                  h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride, b0, d_rs));
+        if ((rc = finish_scan(h, pose, d_rs))) return rc;
+        const int* rsm = h->h_result->resume;   // { next bucket, next bucket, bucket with fallback items pending }
+        if (rsm[2] < 0) {
+            if (rsm[0] >= (int)nb) break;
+            return fail(h, LK_ERR_STATE, "the grid-resident kernel stopped without a reason at bucket " + std::to_string(rsm[0]) + " of " + std::to_string(nb));
+        }
+        if (round > nb + 4 || rsm[0] <= b0) return fail(h, LK_ERR_STATE, "the grid-resident kernel does not advance");
+        h->grid_relaunches += 1;
+        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(8), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, 0u, 0, d_rs));
+        b0 = rsm[0];
+        if (b0 >= (int)nb) {   // they were the last bucket's
+            if ((rc = finish_scan(h, pose, nullptr))) return rc;
+            break;
+        }
+        HIPCHK(h, hipMemsetAsync(dr + o_sync, 0, 16, h->stream));   // barrier arrivals, abort word, XCC ids of the next launch
+    }
     return LK_OK;
 }
 // a scan is taken by the resident kernel when all its buckets are small (LEGKILO_RESIDENT=0: always per-bucket launches)
@@ -2512,15 +2550,15 @@ static int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, si
         }
         bstart.push_back(n);
         if (grid_takes(h, smallest, biggest) && n_imu == 0 && n_kin == 0) {   // every bucket takes the large-bucket kernels: one grid-resident launch
-            rc = run_scan_grid(h, d_pts, bstart, btime, biggest, xyz_world_out ? h->d_world : nullptr);
+            lk_pose pose;
+            rc = run_scan_grid(h, d_pts, bstart, btime, biggest, xyz_world_out ? h->d_world : nullptr, &pose);
             if (rc) return rc;
             std::vector<float> w;
             if (xyz_world_out) {
                 w.resize(4 * n);
                 HIPCHK(h, hipMemcpyAsync(w.data(), h->d_world, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
             }
-            lk_pose pose;
-            if ((rc = finish_scan(h, &pose))) return rc;
             if (xyz_world_out)
                 for (size_t i = 0; i < n; ++i)
                     for (int c = 0; c < 3; ++c) xyz_world_out[3 * i + c] = w[4 * i + c];
@@ -2619,9 +2657,8 @@ int lk_process_scan_dev(lk_handle* h, const lk_point* d_pts, size_t n, double t_
         }
         bstart.push_back(bucket_off[n_buckets]);
         if (!btime.empty() && grid_takes(h, smallest, biggest)) {
-            if ((rc = run_scan_grid(h, d_pts, bstart, btime, biggest, nullptr))) return rc;
             lk_pose pose;
-            if ((rc = finish_scan(h, &pose))) return rc;
+            if ((rc = run_scan_grid(h, d_pts, bstart, btime, biggest, nullptr, &pose))) return rc;
             if (out) *out = pose;
             return LK_OK;
         }
@@ -3868,7 +3905,7 @@ int lk_stream_grid(lk_handle* h, int on) {
 int lk_stream_resident_stats(lk_handle* h, uint64_t* out2) {
     CHECK_H(h);
     if (!out2) return fail(h, LK_ERR_INVALID, "out2 is null");
-    out2[0] = h->resident_scans, out2[1] = h->resident_relaunches;
+    out2[0] = h->resident_scans + h->grid_scans, out2[1] = h->resident_relaunches + h->grid_relaunches;
     return LK_OK;
 }
 int lk_stream_stats(lk_handle* h, uint64_t* out4) {
