@@ -1201,7 +1201,7 @@ extern "C" {
 #define LK_CTR_GRID_XCC 15   // LkMap.counters[15]: XCC ids (one bit each) the working blocks of the last one-XCD launch ran on
 }  // extern "C" (a kernel template follows)
 template <bool XID>
-__global__ void __launch_bounds__(LK_FB)
+__global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD - 256 registers, 240 B of spills - it is 6-10 % slower: profiles/EXPERIMENTS.md)
     lk_scan_grid_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
                         LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort, [2] XCC ids seen */, unsigned int timeout_ms,
                         int stride, int b0 /* first bucket; > 0: the predict to its time has been applied */, LkResume* rs) {
@@ -1274,6 +1274,12 @@ __global__ void __launch_bounds__(LK_FB)
     __syncthreads();
     if (wg == 0 && b0 == 0) dev_predict(&filters[0], Q, T[0], sm);   // KILO.cc:111-115 for the first bucket
     if (!grid_barrier()) return;
+#ifdef LK_DEBUG_RES
+    unsigned long long gt0_ = wall_clock64();
+#define GS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); if (wg == 0 && tid == 0) atomicAdd(&lk_res_dbg[16 + (k)], t1_ - gt0_); gt0_ = t1_; } while (0)
+#else
+#define GS_STAMP(k) do { } while (0)
+#endif
     for (int b = b0; b < nbk; ++b) {
         const unsigned long long base = po[b];
         const int n = (int)(po[b + 1] - base);
@@ -1291,13 +1297,17 @@ __global__ void __launch_bounds__(LK_FB)
                 if (lane < LK_NPART) partials[(size_t)tile * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
             }
         }
+        GS_STAMP(0);
         if (!grid_barrier()) return;
+        GS_STAMP(1);
         if (wg == 0) {   // lk_update_snap_kernel: fixed-order sum of the tiles' records, update, posterior snapshot, pool bookkeeping
             dev_update_reduce(&filters[0], partials, ntiles, T[b], Q, 0.0, 0, sm, red, tot);
             dev_snapshot_posterior(&filters[0], snap);
             dev_bucket_begin(map);
         }
+        GS_STAMP(2);
         if (!grid_barrier()) return;
+        GS_STAMP(3);
         // re-projection + root hashing from the snapshot; workgroup 0 propagates the live filter to the next bucket meanwhile
         if (wg == 0 && G > 1) {
             if (b + 1 < nbk) dev_predict(&filters[0], Q, T[b + 1], sm);
@@ -1309,15 +1319,21 @@ __global__ void __launch_bounds__(LK_FB)
                 dev_predict(&filters[0], Q, T[b + 1], sm);
             }
         }
+        GS_STAMP(4);
         if (!grid_barrier()) return;
+        GS_STAMP(5);
         const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_touched > 0) {
             dev_insert_root<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+            GS_STAMP(6);
             if (!grid_barrier()) return;
+            GS_STAMP(7);
             const unsigned int n_groups = __hip_atomic_load(&map.counters[LK_CTR_GROUPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n_groups) {
                 dev_insert_apply<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+                GS_STAMP(8);
                 if (!grid_barrier()) return;
+                GS_STAMP(9);
             }
             // generic fallback items (dev_insert_fallback: 250 more registers, 6.5 KB of scratch per lane) are not part of this kernel: every
             // workgroup reads the same count behind the barrier and leaves; lk_resident_fallback_kernel runs them from the snapshot, the next
@@ -2478,8 +2494,8 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     static const unsigned int timeout_ms = getenv("LEGKILO_RESIDENT_TIMEOUT_MS") ? (unsigned int)std::max(1, atoi(getenv("LEGKILO_RESIDENT_TIMEOUT_MS"))) : LK_RESIDENT_TIMEOUT_MS;
     static const int wg_env = getenv("LEGKILO_GRIDSCAN_WG") ? atoi(getenv("LEGKILO_GRIDSCAN_WG")) : 0;
     const int tiles = (int)((biggest + LK_WAVE - 1) / LK_WAVE);
-    int G = wg_env > 0 ? wg_env : std::max(8, (tiles + 3) / 4 + 4);   // a wave per tile of the largest bucket and a few more for the per-root passes; every
-                                                                      // further workgroup makes each barrier dearer (51 x 1 960 points: 12 workgroups 2.33 ms, 32: 2.43, 128: 2.81)
+    int G = wg_env > 0 ? wg_env : std::max(16, (tiles + 3) / 4 + 12);  // a wave per tile of the largest bucket and some more for the per-root passes; every
+                                                                      // further workgroup makes each barrier dearer (51 x 1 960 points, round 5: 8 workgroups 2.67 ms, 12: 2.37, 16: 2.30, 24: 2.29, 32: 2.31; round 4: 128: 2.81)
     G = std::min(G, LK_GRIDSCAN_WG_MAX);                             // 128 workgroups of 4 waves are resident on 256 CUs whatever else is true
     {   // a partitioned / smaller device (CPX: 32 CUs): never more spinning workgroups than can be resident at once
         static int resident_max = -1;
@@ -2506,6 +2522,19 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
         LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
                                                   h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride, b0, d_rs));
         if ((rc = finish_scan(h, pose, d_rs))) return rc;
+#ifdef LK_DEBUG_RES
+        {
+            unsigned long long hb[32];
+            hipMemcpyFromSymbol(hb, HIP_SYMBOL(lk_res_dbg), sizeof(hb));
+            const char* nm[10] = {"residual tiles", "barrier", "update+snapshot+begin (wg 0)", "barrier", "predict (wg 0; others re-project)", "barrier", "root pass (wg 0's share)", "barrier",
+                                  "emitted groups (wg 0's share)", "barrier"};
+            fprintf(stderr, "[grid] %zu buckets, G = %d; workgroup 0, us per bucket:", nb, G);
+            for (int q = 0; q < 10; ++q) fprintf(stderr, " %s %.2f;", nm[q], (double)hb[16 + q] / (double)nb * 0.01);
+            fprintf(stderr, "\n");
+            memset(hb, 0, sizeof(hb));
+            hipMemcpyToSymbol(HIP_SYMBOL(lk_res_dbg), hb, sizeof(hb));
+        }
+#endif
         const int* rsm = h->h_result->resume;   // { next bucket, next bucket, bucket with fallback items pending }
         if (rsm[2] < 0) {
             if (rsm[0] >= (int)nb) break;
