@@ -1205,7 +1205,7 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
     lk_scan_grid_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
                         LkFilter* snap, float* world, double* partials, unsigned int* sync /* [0] arrivals, [1] abort, [2] XCC ids seen */, unsigned int timeout_ms,
                         int stride, int b0 /* first bucket; > 0: the predict to its time has been applied */, LkResume* rs) {
-    __shared__ FilterSmem sm;
+    __shared__ WaveSmem w;   // workgroup 0: the filter's covariance and state, resident for the whole scan (below)
     __shared__ double red[8][LK_NPART];
     __shared__ double tot[LK_NPART];
     __shared__ double rows[LK_FB / LK_WAVE][64 * LK_ROW2];
@@ -1271,8 +1271,36 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         __syncthreads();
         return s_abort == 0;
     };
+    // The filter lives in workgroup 0's LDS from the first predict to the last update (the one-wave cores of the batch replay, run by its
+    // wave 0: the same arithmetic as lk_update_snap_kernel / lk_insert_root_predict_kernel of the per-bucket launches, which stage the
+    // state through LDS around the same cores) - per bucket that is two loads and two stores of the 7.2-KB covariance less on the chain.
+    // What the OTHER workgroups need of it goes to global memory when it changes: the predicted rotation / position and rows 0..5 of P for
+    // the residual tiles (load_bucket_const), the posterior's snapshot for the insert.  The whole state is written back when the launch
+    // ends (the scan's end, or fallback items pending); a launch given up leaves filters[0] to the host's backup.
+    LkFilter* f = &filters[0];
+    double t_upd = 0.0, t_pred = 0.0;
+    auto publish = [&]() {   // workgroup 0: what load_bucket_const reads
+        if (tid < 36) f->x[tid] = w.x[tid];
+        if (tid < 180) f->P[tid] = w.P[tid];
+    };
+    auto write_back = [&]() {   // workgroup 0, behind a barrier of its own
+        for (int e = tid; e < 900; e += LK_FB) f->P[e] = w.P[e];
+        if (tid < 36) f->x[tid] = w.x[tid];
+    };
     __syncthreads();
-    if (wg == 0 && b0 == 0) dev_predict(&filters[0], Q, T[0], sm);   // KILO.cc:111-115 for the first bucket
+    if (wg == 0) {
+        for (int e = tid; e < 900; e += LK_FB) w.P[e] = f->P[e];
+        if (tid < 36) w.x[tid] = f->x[tid];
+        t_upd = f->last_update_t, t_pred = f->last_predict_t;
+        __syncthreads();
+        if (b0 == 0) {   // KILO.cc:111-115 for the first bucket
+            if (wv == 0) wave_predict_core<true>(w, Q, T[0] - t_upd, T[0] - t_pred, lane, rg.q_diag != 0);
+            t_pred = T[0];
+            if (tid == 0) f->last_predict_t = T[0];
+            __syncthreads();
+            publish();
+        }
+    }
     if (!grid_barrier()) return;
 #ifdef LK_DEBUG_RES
     unsigned long long gt0_ = wall_clock64();
@@ -1301,22 +1329,49 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         if (!grid_barrier()) return;
         GS_STAMP(1);
         if (wg == 0) {   // lk_update_snap_kernel: fixed-order sum of the tiles' records, update, posterior snapshot, pool bookkeeping
-            dev_update_reduce(&filters[0], partials, ntiles, T[b], Q, 0.0, 0, sm, red, tot);
-            dev_snapshot_posterior(&filters[0], snap);
-            dev_bucket_begin(map);
+            dev_reduce_partials(partials, ntiles, red, tot);   // the sum of dev_update_reduce
+            const int N = (int)(tot[28] + 0.5);
+            if (tid == 0) {   // the bookkeeping of dev_update_from_totals (KILO.cc:193,211-212)
+                f->n_buckets += 1;
+                f->last_N = N;
+                f->updated = N > 0;
+                if (N > 0) {
+                    f->n_updates += 1;
+                    f->n_effect += (unsigned long long)N;
+                    f->last_update_t = T[b];
+                }
+            }
+            if (N > 0) {
+                t_upd = T[b];
+                if (wv == 0) wave_update_core<true>(w, lane < 32 ? tot[lane] : 0.0, N, lane);
+            }
+            __syncthreads();
+            if (tid < LK_STATE_DOUBLES) snap->x[tid] = w.x[tid];   // dev_snapshot_posterior's fields, from LDS
+            if (tid < 180) snap->P[tid] = w.P[tid];
+            if (tid == 0) snap->updated = N > 0, snap->last_N = N;
         }
+        if (wg == (G > 1 ? 1 : 0)) dev_bucket_begin(map);   // the pools' bookkeeping (three dependent trips to the counters) beside the update, not behind it
         GS_STAMP(2);
         if (!grid_barrier()) return;
         GS_STAMP(3);
         // re-projection + root hashing from the snapshot; workgroup 0 propagates the live filter to the next bucket meanwhile
+        auto predict_next = [&]() {   // workgroup 0
+            if (b + 1 < nbk) {
+                if (wv == 0) wave_predict_core<true>(w, Q, T[b + 1] - t_upd, T[b + 1] - t_pred, lane, rg.q_diag != 0);
+                t_pred = T[b + 1];
+                if (tid == 0) f->last_predict_t = T[b + 1];
+                __syncthreads();
+                publish();
+            }
+        };
         if (wg == 0 && G > 1) {
-            if (b + 1 < nbk) dev_predict(&filters[0], Q, T[b + 1], sm);
+            predict_next();
         } else {
             const int w0 = G > 1 ? wg - 1 : 0, nw = G > 1 ? G - 1 : 1;
             for (int i = w0 * LK_FB + tid; i < n; i += nw * LK_FB) dev_reproject_point(map, pr, snap, bp, bw, 1, i);
-            if (G == 1 && b + 1 < nbk) {
+            if (G == 1) {
                 __syncthreads();
-                dev_predict(&filters[0], Q, T[b + 1], sm);
+                predict_next();
             }
         }
         GS_STAMP(4);
@@ -1340,12 +1395,18 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
             // launch picks up at bucket b + 1, whose predict workgroup 0 has applied beside the re-projection (LkResume, run_scan_grid)
             const unsigned int n_fb = __hip_atomic_load(&map.counters[LK_CTR_FALLBACK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n_fb) {
-                if (wg == 0 && tid == 0) rs->bf = b + 1, rs->bi = b + 1, rs->fb_bucket = b;
+                if (wg == 0) {
+                    write_back();
+                    if (tid == 0) rs->bf = b + 1, rs->bi = b + 1, rs->fb_bucket = b;
+                }
                 return;
             }
         }
     }
-    if (wg == 0 && tid == 0) rs->bf = nbk, rs->bi = nbk, rs->fb_bucket = -1;
+    if (wg == 0) {
+        write_back();
+        if (tid == 0) rs->bf = nbk, rs->bi = nbk, rs->fb_bucket = -1;
+    }
 }
 extern "C" {
 

@@ -355,8 +355,8 @@ __device__ void dev_update_from_totals(LkFilter* f, FilterSmem& sm, double* tot,
 // reduce the per-wave partial records (fixed order -> deterministic) and update; partials: [nblk][LK_NPART] per slot.
 // do_predict != 0 (batch replay on a frozen map, where nothing reads the state between update(k) and predict(k+1)):
 // the predict of the NEXT bucket (time t_next) runs in the same launch.
-__device__ __forceinline__ void dev_update_reduce(LkFilter* f, const double* __restrict__ part, int nblk, double t, const double* __restrict__ Q,
-                                                  double t_next, int do_predict, FilterSmem& sm, double (*red)[LK_NPART], double* tot) {
+// the bucket's totals from the per-wave partial records, in a fixed order (all LK_FB threads; tot[] is valid behind the last barrier)
+__device__ __forceinline__ void dev_reduce_partials(const double* __restrict__ part, int nblk, double (*red)[LK_NPART], double* tot) {
     const int tid = threadIdx.x;
     {
         const int j = tid % LK_NPART, g = tid / LK_NPART;  // 8 groups x 32 components
@@ -379,6 +379,10 @@ __device__ __forceinline__ void dev_update_reduce(LkFilter* f, const double* __r
         tot[tid] = s;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void dev_update_reduce(LkFilter* f, const double* __restrict__ part, int nblk, double t, const double* __restrict__ Q,
+                                                  double t_next, int do_predict, FilterSmem& sm, double (*red)[LK_NPART], double* tot) {
+    dev_reduce_partials(part, nblk, red, tot);
     dev_update_from_totals(f, sm, tot, t);
     if (do_predict) {
         __syncthreads();  // f->x, f->P, f->last_update_t written above are re-read by dev_predict
