@@ -937,6 +937,9 @@ struct LkResume {
     int fb_bucket;     // the bucket whose fallback items are pending (its snapshot: snap2[fb_bucket & 1]); -1: none
     int pad_[3];
 };
+#ifndef LK_X_DYNROOT
+#define LK_X_DYNROOT 1   // A/B builds: 0 = the grid-resident kernel's root pass strides the touched list
+#endif
 #ifndef LK_X_SLEEP
 #define LK_X_SLEEP 0   // sensitivity probes (never in the product build): ~1 us of sleep per bucket on 1 the filter wave, 2 the insert team before / 4 behind its stamps
 #endif
@@ -964,6 +967,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     __shared__ int team_ctr;                    // arrivals at the insert team's barrier
     __shared__ int f_abort;                     // a wait was given up: every role leaves its loop
     __shared__ int f_exit;                      // the insert team has left with fallback items pending (LkResume)
+    __shared__ unsigned int root_ticket;        // the root pass's next untaken root beyond the waves' own first ones (dev_insert_root's dyn_next)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LkFilter* f = &filters[0];
     const int nbk = rag_nb(rg, 0);
@@ -1001,13 +1005,14 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             const int n_touched = (int)__hip_atomic_load(&m.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (rank == 0) {
                 if (n_touched > 0) dev_stamp_dirty_roots(m, pr, n_touched);
+                if (lane == 0) root_ticket = 0u;
                 FLAG_POST(f_decided, b);
                 RS_TS(2, b);
             }
             if (n_touched > 0) {
                 if (!TEAM_BARRIER(team_ctr, phase)) break;   // the stamping pass has read the roots' queues before the root pass resets them
                 RS_STAMP(3);
-                dev_insert_root<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
+                dev_insert_root<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES, nullptr, nullptr, 0, LK_X_DYNROOT ? &root_ticket : nullptr);
                 if (!TEAM_BARRIER(team_ctr, phase)) break;
                 RS_STAMP(4);
                 dev_insert_apply<false>(m, pr, sn, pts + base, (const lk_pt_rec*)nullptr, n, rank, LK_INS_WAVES);
@@ -1271,37 +1276,40 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         __syncthreads();
         return s_abort == 0;
     };
-    // The filter lives in workgroup 0's LDS from the first predict to the last update (the one-wave cores of the batch replay, run by its
-    // wave 0: the same arithmetic as lk_update_snap_kernel / lk_insert_root_predict_kernel of the per-bucket launches, which stage the
-    // state through LDS around the same cores) - per bucket that is two loads and two stores of the 7.2-KB covariance less on the chain.
-    // What the OTHER workgroups need of it goes to global memory when it changes: the predicted rotation / position and rows 0..5 of P for
-    // the residual tiles (load_bucket_const), the posterior's snapshot for the insert.  The whole state is written back when the launch
-    // ends (the scan's end, or fallback items pending); a launch given up leaves filters[0] to the host's backup.
+    // The filter is REPLICATED: every workgroup keeps the covariance and the state in its own LDS from the first predict to the last update
+    // and runs the same predict and the same update on it (the one-wave cores of the batch replay in its wave 0: the arithmetic of
+    // lk_update_snap_kernel / lk_insert_root_predict_kernel of the per-bucket launches; a deterministic function of the same inputs, so the
+    // copies never differ).  Nothing of the filter then has to cross a grid barrier: the residual tiles read the predicted state, the
+    // re-projection the posterior, from the workgroup's own LDS; the update needs the tiles' partial records (one barrier) and that is all.
+    // Workgroup 0 is the copy of record: it keeps the bookkeeping words, writes the posterior's snapshot for the root pass (which is behind
+    // the next barrier anyway) and the whole state when the launch ends (the scan's end, or fallback items pending); a launch given up leaves
+    // filters[0] to the host's backup.
     LkFilter* f = &filters[0];
     double t_upd = 0.0, t_pred = 0.0;
-    auto publish = [&]() {   // workgroup 0: what load_bucket_const reads
-        if (tid < 36) f->x[tid] = w.x[tid];
-        if (tid < 180) f->P[tid] = w.P[tid];
-    };
     auto write_back = [&]() {   // workgroup 0, behind a barrier of its own
         for (int e = tid; e < 900; e += LK_FB) f->P[e] = w.P[e];
         if (tid < 36) f->x[tid] = w.x[tid];
     };
+    auto bucket_const_of_w = [&](BucketConst& bc) {   // load_bucket_const<false> from the LDS-resident state
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bc.R[i] = w.x[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bc.p[i] = w.x[9 + i];
+        const double* P = w.P;
+        bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
+        bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
+    };
     __syncthreads();
-    if (wg == 0) {
-        for (int e = tid; e < 900; e += LK_FB) w.P[e] = f->P[e];
-        if (tid < 36) w.x[tid] = f->x[tid];
-        t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    for (int e = tid; e < 900; e += LK_FB) w.P[e] = f->P[e];
+    if (tid < 36) w.x[tid] = f->x[tid];
+    t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    if (!grid_barrier()) return;   // (every copy is loaded before workgroup 0 writes a word of filters[0]; the working blocks' XCC ids are in)
+    if (b0 == 0) {   // KILO.cc:111-115 for the first bucket
+        if (wv == 0) wave_predict_core<true>(w, Q, T[0] - t_upd, T[0] - t_pred, lane, rg.q_diag != 0);
+        t_pred = T[0];
+        if (wg == 0 && tid == 0) f->last_predict_t = T[0];
         __syncthreads();
-        if (b0 == 0) {   // KILO.cc:111-115 for the first bucket
-            if (wv == 0) wave_predict_core<true>(w, Q, T[0] - t_upd, T[0] - t_pred, lane, rg.q_diag != 0);
-            t_pred = T[0];
-            if (tid == 0) f->last_predict_t = T[0];
-            __syncthreads();
-            publish();
-        }
     }
-    if (!grid_barrier()) return;
 #ifdef LK_DEBUG_RES
     unsigned long long gt0_ = wall_clock64();
 #define GS_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); if (wg == 0 && tid == 0) atomicAdd(&lk_res_dbg[16 + (k)], t1_ - gt0_); gt0_ = t1_; } while (0)
@@ -1314,9 +1322,11 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         const int ntiles = (n + LK_WAVE - 1) / LK_WAVE;
         const lk_point* bp = pts + base;
         float* bw = world ? world + 4 * base : nullptr;
+        // the pools' bookkeeping for this bucket's insert (the previous insert is complete, the tiles do not read what it touches)
+        if (wg == (G > 1 ? 1 : 0)) dev_bucket_begin(map);
         {   // residual pass: tile t by wave t of the grid (lk_residual_kernel's body, one partial record per tile)
             BucketConst bc;
-            load_bucket_const<false>(&filters[0], pr, bc);
+            bucket_const_of_w(bc);
             ResidualOut ro;
             ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = bw, ro.ids = nullptr;
             for (int tile = wg * (LK_FB / LK_WAVE) + wv; tile < ntiles; tile += G * (LK_FB / LK_WAVE)) {
@@ -1328,50 +1338,46 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         GS_STAMP(0);
         if (!grid_barrier()) return;
         GS_STAMP(1);
-        if (wg == 0) {   // lk_update_snap_kernel: fixed-order sum of the tiles' records, update, posterior snapshot, pool bookkeeping
-            dev_reduce_partials(partials, ntiles, red, tot);   // the sum of dev_update_reduce
-            const int N = (int)(tot[28] + 0.5);
-            if (tid == 0) {   // the bookkeeping of dev_update_from_totals (KILO.cc:193,211-212)
-                f->n_buckets += 1;
-                f->last_N = N;
-                f->updated = N > 0;
-                if (N > 0) {
-                    f->n_updates += 1;
-                    f->n_effect += (unsigned long long)N;
-                    f->last_update_t = T[b];
-                }
-            }
+        // lk_update_snap_kernel in every workgroup: fixed-order sum of the tiles' records, update; workgroup 0: bookkeeping + snapshot
+        dev_reduce_partials(partials, ntiles, red, tot);   // the sum of dev_update_reduce
+        const int N = (int)(tot[28] + 0.5);
+        if (wg == 0 && tid == 0) {   // the bookkeeping of dev_update_from_totals (KILO.cc:193,211-212)
+            f->n_buckets += 1;
+            f->last_N = N;
+            f->updated = N > 0;
             if (N > 0) {
-                t_upd = T[b];
-                if (wv == 0) wave_update_core<true>(w, lane < 32 ? tot[lane] : 0.0, N, lane);
+                f->n_updates += 1;
+                f->n_effect += (unsigned long long)N;
+                f->last_update_t = T[b];
             }
-            __syncthreads();
-            if (tid < LK_STATE_DOUBLES) snap->x[tid] = w.x[tid];   // dev_snapshot_posterior's fields, from LDS
+        }
+        if (N > 0) {
+            t_upd = T[b];
+            if (wv == 0) wave_update_core<true>(w, lane < 32 ? tot[lane] : 0.0, N, lane);
+        }
+        __syncthreads();
+        if (wg == 0) {   // dev_snapshot_posterior's fields, from LDS: what the root pass reads
+            if (tid < LK_STATE_DOUBLES) snap->x[tid] = w.x[tid];
             if (tid < 180) snap->P[tid] = w.P[tid];
             if (tid == 0) snap->updated = N > 0, snap->last_N = N;
         }
-        if (wg == (G > 1 ? 1 : 0)) dev_bucket_begin(map);   // the pools' bookkeeping (three dependent trips to the counters) beside the update, not behind it
         GS_STAMP(2);
-        if (!grid_barrier()) return;
         GS_STAMP(3);
-        // re-projection + root hashing from the snapshot; workgroup 0 propagates the live filter to the next bucket meanwhile
-        auto predict_next = [&]() {   // workgroup 0
-            if (b + 1 < nbk) {
-                if (wv == 0) wave_predict_core<true>(w, Q, T[b + 1] - t_upd, T[b + 1] - t_pred, lane, rg.q_diag != 0);
-                t_pred = T[b + 1];
-                if (tid == 0) f->last_predict_t = T[b + 1];
-                __syncthreads();
-                publish();
+        // re-projection + root hashing with the posterior (waves 1..3 of every workgroup, the posterior in their registers) while wave 0
+        // propagates the workgroup's copy to the next bucket
+        {
+            BucketConst bc;
+            bucket_const_of_w(bc);
+            __syncthreads();   // every thread has read the posterior
+            if (wv == 0) {
+                if (b + 1 < nbk) wave_predict_core<true>(w, Q, T[b + 1] - t_upd, T[b + 1] - t_pred, lane, rg.q_diag != 0);
+            } else {
+                const int per = LK_FB - LK_WAVE;
+                for (int i = wg * per + (tid - LK_WAVE); i < n; i += G * per) dev_reproject_point_bc(map, pr, bc, N > 0, bp, bw, 1, i);
             }
-        };
-        if (wg == 0 && G > 1) {
-            predict_next();
-        } else {
-            const int w0 = G > 1 ? wg - 1 : 0, nw = G > 1 ? G - 1 : 1;
-            for (int i = w0 * LK_FB + tid; i < n; i += nw * LK_FB) dev_reproject_point(map, pr, snap, bp, bw, 1, i);
-            if (G == 1) {
-                __syncthreads();
-                predict_next();
+            if (b + 1 < nbk) {
+                t_pred = T[b + 1];
+                if (wg == 0 && tid == 0) f->last_predict_t = T[b + 1];
             }
         }
         GS_STAMP(4);
@@ -1379,7 +1385,8 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         GS_STAMP(5);
         const int n_touched = (int)__hip_atomic_load(&map.counters[LK_CTR_TOUCHED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_touched > 0) {
-            dev_insert_root<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE));
+            dev_insert_root<false>(map, pr, snap, bp, (const lk_pt_rec*)nullptr, n, wg * (LK_FB / LK_WAVE) + wv, G * (LK_FB / LK_WAVE), nullptr, nullptr, 0,
+                                   LK_X_DYNROOT ? &map.counters[LK_CTR_HEAVY] : nullptr);   // (LK_CTR_HEAVY: zeroed by dev_bucket_begin, otherwise unused on this path)
             GS_STAMP(6);
             if (!grid_barrier()) return;
             GS_STAMP(7);
@@ -1392,7 +1399,7 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
             }
             // generic fallback items (dev_insert_fallback: 250 more registers, 6.5 KB of scratch per lane) are not part of this kernel: every
             // workgroup reads the same count behind the barrier and leaves; lk_resident_fallback_kernel runs them from the snapshot, the next
-            // launch picks up at bucket b + 1, whose predict workgroup 0 has applied beside the re-projection (LkResume, run_scan_grid)
+            // launch picks up at bucket b + 1, to whose time every copy of the filter has been propagated (LkResume, run_scan_grid)
             const unsigned int n_fb = __hip_atomic_load(&map.counters[LK_CTR_FALLBACK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n_fb) {
                 if (wg == 0) {

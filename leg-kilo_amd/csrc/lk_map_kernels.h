@@ -1039,7 +1039,10 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 template <bool FROM_PV, bool OV = false, bool CPLX = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                                                 const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr,
-                                                LkFitJob* jobs = nullptr, const size_t job_stride = 0) {
+                                                LkFitJob* jobs = nullptr, const size_t job_stride = 0, unsigned int* dyn_next = nullptr) {
+    // dyn_next (not OV): a wave's FIRST root is its own index in the touched list, every further one the next nobody has taken (a ticket
+    // counter, zero at the start of the pass) instead of index + nwaves: a wave that drew a plane fit (12-16 us) does not also own the
+    // root nwaves further on while its neighbours, done with an append after 2 us, idle at the barrier (grid-resident stream kernel)
     const int lane = threadIdx.x & 63;
     const int n_touched = CPLX ? (int)min(map.counters[LK_CTR_HEAVY], map.max_scan) : (int)map.counters[LK_CTR_TOUCHED];
     if (CPLX && n_touched == 0) return;
@@ -1076,7 +1079,15 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         pf_root2 = wave + nwaves < n_touched ? bcast0(item_root(wave + nwaves)) : -1;
         prefetch_record(pf_root1);
     }
-    for (int t = wave; t < n_touched; t += nwaves) {
+    auto next_item = [&](int t) -> int {
+        if (!OV && dyn_next) {
+            unsigned int k = 0;
+            if (lane == 0) k = atomicAdd(dyn_next, 1u);
+            return nwaves + bcast0((int)k);
+        }
+        return t + nwaves;
+    };
+    for (int t = wave; t < n_touched; t = next_item(t)) {
 #ifdef LK_DEBUG_INS
         const unsigned long long tr_ = wall_clock64();
         if (any_) ROOT_HIST(4, tw_);   // a wave with a second root: its time so far

@@ -818,16 +818,14 @@ __device__ __forceinline__ void queue_point_on_root(const LkMap& map, int root, 
 }
 
 // KILO.cc:216-230 + voxel_map.cc:343-358 (hash half).  pts are the bucket's points (bucket-local i).
-__device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkParams& pr, const LkFilter* __restrict__ filters,
-                                                    const lk_point* __restrict__ pts, float* __restrict__ world /* n x 4 or null */,
-                                                    const int do_insert, const int i) {
-    const LkFilter* f = &filters[0];
-    BucketConst bc;
-    load_bucket_const<false>(f, pr, bc);   // R, p only matter here (no R * ext_R product, no covariance blocks used)
+// bc: R, p of the posterior (nothing else of it is used); updated: the bucket's update took place (KILO.cc:213-215)
+__device__ __forceinline__ void dev_reproject_point_bc(const LkMap& map, const LkParams& pr, const BucketConst& bc, const bool updated,
+                                                       const lk_point* __restrict__ pts, float* __restrict__ world /* n x 4 or null */,
+                                                       const int do_insert, const int i) {
     const float4 p = reinterpret_cast<const float4*>(pts)[i];
     struct { V3 p_w; } g;
     g.p_w = point_world(p.x, p.y, p.z, bc, pr);
-    if (world && f->updated) {
+    if (world && updated) {
         reinterpret_cast<float4*>(world)[i] = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 255.f);
     }
     if (!do_insert) return;
@@ -885,6 +883,14 @@ __device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkPa
         if (ignore) return;
     }
     queue_point_on_root(map, root, i);
+}
+__device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkParams& pr, const LkFilter* __restrict__ filters,
+                                                    const lk_point* __restrict__ pts, float* __restrict__ world /* n x 4 or null */,
+                                                    const int do_insert, const int i) {
+    const LkFilter* f = &filters[0];
+    BucketConst bc;
+    load_bucket_const<false>(f, pr, bc);   // R, p only matter here (no R * ext_R product, no covariance blocks used)
+    dev_reproject_point_bc(map, pr, bc, world ? f->updated != 0 : false, pts, world, do_insert, i);
 }
 __global__ void __launch_bounds__(LK_PB)
     lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
