@@ -983,6 +983,10 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         const int rank = wv - 1;
         int phase = 0;
         RS_DECL;
+        // the pools' bookkeeping for a bucket's insert (dev_bucket_begin) only needs the PREVIOUS insert to be complete: it runs behind that
+        // one (and once before the first), not between the posterior's arrival and the stamps the filter wave waits for
+        if (rank == 0) dev_bucket_begin_wave(map);
+        if (!TEAM_BARRIER(team_ctr, phase)) return;
         int b = bi0;
         for (; b < nbk; ++b) {
             const unsigned long long base = po[b];
@@ -993,11 +997,10 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (!FLAG_WAIT(f_post, b)) break;
             if (rank == 0) RS_TS(1, b);
             RS_STAMP(0);
-            if (rank == 0) dev_bucket_begin_wave(m);
 #if LK_X_SLEEP & 2
             if (rank == 0) __builtin_amdgcn_s_sleep(38);   // sensitivity probe: ~1 us on the insert team's chain, before its stamps are final
-#endif
             if (!TEAM_BARRIER(team_ctr, phase)) break;
+#endif
             RS_STAMP(1);
             for (int i = rank * LK_WAVE + lane; i < n; i += LK_INS_WAVES * LK_WAVE) dev_reproject_point(m, pr, sn, pts + base, world ? world + 4 * base : nullptr, 1, i);
             if (!TEAM_BARRIER(team_ctr, phase)) break;
@@ -1037,6 +1040,8 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             if (!TEAM_BARRIER(team_ctr, phase)) break;
             if (rank == 0) FLAG_POST(f_done, b);
             if (rank == 0) RS_TS(5, b);
+            if (rank == 0 && b + 1 < nbk) dev_bucket_begin_wave(map);   // for the next bucket (its re-projection is behind a team barrier of that bucket... the one below)
+            if (!TEAM_BARRIER(team_ctr, phase)) break;
             RS_STAMP(6);
         }
         if (rank == 0 && lane == 0 && b == nbk) rs->bi = nbk, rs->fb_bucket = -1;   // (a wait given up: the call fails, LkResume is not read)
@@ -1096,6 +1101,8 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr;
         ro.world = world ? world + 4 * base : nullptr;
         ro.ids = ids + base;
+        int2 my_ids = make_int2(LK_SPEC_NONE, LK_SPEC_NONE);   // a one-tile bucket's lookup codes stay in the lane that made them
+        ro.ids_lane = n <= LK_WAVE ? &my_ids : nullptr;
         // speculative pass (the insert of bucket b - 1, possibly the tail of b - 2, may be running beside it)
         // A bucket's tile sums are combined in the order lk_small_bucket_kernel combines them (its four waves take the tiles round
         // robin, then the wave sums are added in wave order): the two paths give the same bits for any bucket size.
@@ -1116,9 +1123,13 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             const unsigned int e_b = epoch0 + (unsigned int)b;
             const unsigned int from = b >= 2 ? e_b - 2u : epoch0;
             bool susp = false;
-            for (int i = lane; i < n; i += LK_WAVE) {
-                const int2 c = ro.ids[i];
-                susp = susp || spec_suspect(map, c.x, from) || spec_suspect(map, c.y, from);
+            if (n <= LK_WAVE) {
+                susp = lane < n && (spec_suspect(map, my_ids.x, from) || spec_suspect(map, my_ids.y, from));
+            } else {
+                for (int i = lane; i < n; i += LK_WAVE) {
+                    const int2 c = ro.ids[i];
+                    susp = susp || spec_suspect(map, c.x, from) || spec_suspect(map, c.y, from);
+                }
             }
             if (__ballot(susp) != 0ull) {
                 if (!FLAG_WAIT_X(f_done, b - 1)) { stopped = true; break; }

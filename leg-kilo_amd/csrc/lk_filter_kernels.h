@@ -956,6 +956,10 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
     double Rn[9], dpv[6];
     CORE_T0;
     CORE_COUNT(7);
+    // the diagonal of Q is the only global-memory operand of a predict: requested here, used behind the covariance products (a load issued
+    // where it is used is a trip to the L2 on a chain that has nothing else to do)
+    double qd = 0.0;
+    if (q_diag && lane < 30) qd = Q[lane * 31];
     if (lane < 2 && !(LK_X_P & 1)) {
         const double* x = sm.x;
         const double sc = lane == 0 ? -dt_cov : dt;
@@ -1073,7 +1077,7 @@ __device__ __forceinline__ void wave_predict_core(WaveSmem& sm, const double* __
     const double dt2 = dt_cov * dt_cov;
     if (LK_X_P & 4) {
     } else if (q_diag) {   // Q of initProcessCovQ (eskf.cc:47-62) is diagonal: the other 870 terms are + dt^2 * 0
-        if (lane < 30) sm.P[lane * 31] = sm.P[lane * 31] + dt2 * Q[lane * 31];
+        if (lane < 30) sm.P[lane * 31] = sm.P[lane * 31] + dt2 * qd;
     } else {
         for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = sm.P[e] + dt2 * Q[e];
     }

@@ -320,6 +320,7 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
     unsigned char* valid;
     float* world;          // n x 4 (x y z intensity), cloud_down_world
     int2* ids;             // SPEC instantiations only: per point {home, neighbour} root code of the lookups (spec_code)
+    int2* ids_lane = nullptr;   // SPEC: if set, THIS lane's codes go here (a register of the caller) instead of ids[] - a one-tile bucket's checker is the same wave
 };
 // What a speculative residual pass (the pipelined stream path) remembers of a point's two root lookups, so that the verify pass
 // can tell whether an insert that ran beside it may have changed the point's result: a root id (>= 0), or - the lookup found no
@@ -372,7 +373,10 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             key_trunc(g.p_w, pr, loc, key);
             root = GRID == 3 ? find_root_ov(map, *ovv, key[0], key[1], key[2]) : find_root<GRID>(map, key[0], key[1], key[2]);  // KILO.cc:149
             // stored at once (not carried through the match): registers set this kernel's occupancy
-            if (SPEC) out.ids[out_base + i] = make_int2(spec_code(root, key), LK_SPEC_NONE);
+            if (SPEC) {
+                if (out.ids_lane) *out.ids_lane = make_int2(spec_code(root, key), LK_SPEC_NONE);
+                else out.ids[out_base + i] = make_int2(spec_code(root, key), LK_SPEC_NONE);
+            }
         }
         // K2: home voxel first (the root's 144-B record is fetched in one round trip inside match_root)
         bool success = false;
@@ -394,7 +398,10 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             // the "neighbour" can be the home voxel itself; evaluating it again reproduces the same failure
             if (near[0] != key[0] || near[1] != key[1] || near[2] != key[2]) {
                 nroot = GRID == 3 ? find_root_ov(map, *ovv, near[0], near[1], near[2]) : find_root<GRID>(map, near[0], near[1], near[2]);
-                if (SPEC) out.ids[out_base + i].y = spec_code(nroot, near);
+                if (SPEC) {
+                    if (out.ids_lane) out.ids_lane->y = spec_code(nroot, near);
+                    else out.ids[out_base + i].y = spec_code(nroot, near);
+                }
             }
             if (nroot >= 0) {
                 if (grid_cell) match_flat<XID>(map, nroot, g, bc, pr, success, prob, best);
