@@ -91,6 +91,11 @@ res = {
     "map_root_sets_equal": ko == kg, "map_roots": len(kg),
     "cpu_port_ms_per_scan": round(1e3 * t_cpu / args.scans, 3), "gpu_ms_per_scan_incl_host_preprocess_call": round(1e3 * t_gpu / args.scans, 3),
 }
+try:   # round 5: how often the resident stream kernels stopped at fallback items and were launched again
+    rs_ = g.stream_resident_stats()
+    res["resident_kernel_scans"], res["resident_kernel_relaunches"] = rs_[0], rs_[1]
+except Exception:
+    pass
 print(json.dumps(res))
 assert res["map_root_sets_equal"] and e_tum < 1e-6
 json.dump(res, open(args.out, "w"), indent=1)
