@@ -1189,7 +1189,8 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
 // kernel's snapshots alternate (snap[b & 1]) and its buckets carry their own epoch; the grid-resident kernel has one snapshot, epoch as it is.
 __global__ void __launch_bounds__(LK_MB)
     lk_resident_fallback_kernel(LkMap map, LkParams pr, const LkFilter* snap, const lk_point* __restrict__ pts, LkRagged rg, unsigned int epoch0, int two_snaps,
-                                const LkResume* rs) {
+                                const LkResume* rs, unsigned int* grid_sync) {
+    if (grid_sync && blockIdx.x == 0 && threadIdx.x < 4) grid_sync[threadIdx.x] = 0u;   // the grid-resident kernel's barrier words for its next launch
     const int b = rs->fb_bucket;
     if (b < 0) return;
     const unsigned long long* po = rag_pt_off(rg, 0);
@@ -2527,7 +2528,7 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
         }
         if (round > nb + 4) return fail(h, LK_ERR_STATE, "the scan-resident kernel does not advance");
         h->resident_relaunches += 1;
-        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, epoch0, 1, d_rs));
+        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(1), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, epoch0, 1, d_rs, (unsigned int*)nullptr));
         if (rsm[0] >= (int)nb && rsm[1] >= (int)nb) {   // they were the last bucket's: nothing to pick up
             if ((rc = finish_scan(h, pose, nullptr))) return rc;
             break;
@@ -2621,13 +2622,13 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
         }
         if (round > nb + 4 || rsm[0] <= b0) return fail(h, LK_ERR_STATE, "the grid-resident kernel does not advance");
         h->grid_relaunches += 1;
-        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(8), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, 0u, 0, d_rs));
+        LAUNCH(h, "resident_fallback", hipLaunchKernelGGL(lk_resident_fallback_kernel, dim3(8), dim3(LK_MB), 0, h->stream, h->map, h->pr, h->d_snap, d_pts, rg, 0u, 0, d_rs,
+                                                          reinterpret_cast<unsigned int*>(dr + o_sync)));   // (also zeroes the barrier arrivals, abort word and XCC ids for the next launch)
         b0 = rsm[0];
         if (b0 >= (int)nb) {   // they were the last bucket's
             if ((rc = finish_scan(h, pose, nullptr))) return rc;
             break;
         }
-        HIPCHK(h, hipMemsetAsync(dr + o_sync, 0, 16, h->stream));   // barrier arrivals, abort word, XCC ids of the next launch
     }
     return LK_OK;
 }

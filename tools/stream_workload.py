@@ -29,7 +29,7 @@ B._init_worker()
 world, traj = B._W, B._T
 t0 = 5.0
 warm_t = [t0 + 0.1 + 2.5 * k for k in range(args.warm)]
-t_after = warm_t[-1] + 0.5
+t_after = (warm_t[-1] if warm_t else t0) + 0.5
 jobs = [("first", (t0,))] + [("dense", (tb, 5, 2002 + k, 3003 + k)) for k, tb in enumerate(warm_t)]
 if args.kind == "vlp":
     jobs += [("vlp", (t_after + 0.1 * k, 7007 + k)) for k in range(args.scans)]
