@@ -571,12 +571,51 @@ __global__ void __launch_bounds__(LK_FB)
     __shared__ FilterSmem sm;
     __shared__ double red[8][LK_NPART];
     __shared__ double tot[LK_NPART];
-    dev_update_reduce(&filters[0], partials, nblk, t, Q, 0.0, 0, sm, red, tot);
-    dev_snapshot_posterior(&filters[0], snap);
-    if (do_predict >= 0) dev_bucket_begin(map);
+    // A launch of TWO workgroups when the pool bookkeeping belongs to it: workgroup 1 does that (three dependent trips to the counters and the
+    // free lists - it has nothing to do with the filter), workgroup 0 the update.  Round 5: the state is requested BEFORE the partial records
+    // (it does not depend on them: one trip instead of two), and the snapshot is written from LDS together with the posterior instead of
+    // being read back from what was just stored - the launch is one link of a bucket's chain of five, 11 us of ~70.
+    if (blockIdx.x == 1) {
+        if (do_predict >= 0) dev_bucket_begin(map);
+        return;
+    }
+    const int tid = threadIdx.x;
+    LkFilter* f = &filters[0];
+    static_assert(sizeof(WaveSmem) <= sizeof(double) * 1800, "WaveSmem must fit FilterSmem::A + B");
+    WaveSmem& w = *reinterpret_cast<WaveSmem*>(&sm.A[0]);   // the staging area of dev_point_update_wave0
+    double pr_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr_[k] = tid + LK_FB * k < 900 ? f->P[tid + LK_FB * k] : 0.0;
+    const double xr_ = tid < 36 ? f->x[tid] : 0.0;
+    dev_reduce_partials(partials, nblk, red, tot);   // the sum of dev_update_reduce
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tid + LK_FB * k < 900) w.P[tid + LK_FB * k] = pr_[k];
+    if (tid < 36) w.x[tid] = xr_;
+    const int N = (int)(tot[28] + 0.5);
+    if (tid == 0) {   // the bookkeeping of dev_update_from_totals (KILO.cc:193,211-212)
+        f->n_buckets += 1;
+        f->last_N = N;
+        f->updated = N > 0;
+        if (N > 0) {
+            f->n_updates += 1;
+            f->n_effect += (unsigned long long)N;
+            f->last_update_t = t;  // KILO.cc:212
+        }
+    }
+    __syncthreads();
+    if (N > 0 && tid < LK_WAVE) wave_update_core<true>(w, tid < 32 ? tot[tid] : 0.0, N, tid);   // dev_point_update_wave0's core
+    __syncthreads();
+    if (N > 0) {
+        for (int i = tid; i < 900; i += LK_FB) f->P[i] = w.P[i];
+        if (tid < 36) f->x[tid] = w.x[tid];
+    }
+    if (tid < LK_STATE_DOUBLES) snap->x[tid] = w.x[tid];   // dev_snapshot_posterior's fields
+    if (tid < 180) snap->P[tid] = w.P[tid];
+    if (tid == 0) snap->updated = N > 0, snap->last_N = N;
     if (do_predict == 1) {
         __syncthreads();  // f->x, f->P, f->last_update_t written by the update are re-read by dev_predict
-        dev_predict(&filters[0], Q, t_next, sm);
+        dev_predict(f, Q, t_next, sm);
     }
 }
 
@@ -1616,7 +1655,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
         static const int lds_res = lds_knob("LEGKILO_LDS_RES");
         LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk_r, 1), dim3(LK_RB), lds_res, h->stream, m, h->pr, h->d_filters, d_pts, (size_t)0, n,
                                                  h->d_partials, h->part_stride, ro, (size_t)0));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(1), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
+        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_snap_kernel, dim3(2), dim3(LK_FB), 0, h->stream, m, h->d_filters, h->d_partials,
                                                nblk_r * (LK_RB / LK_WAVE), t, h->d_Q, fuse_next ? t_next : 0.0, fuse_next && !predict_in_root ? 1 : 0, h->d_snap));
         if (fuse_next) *pre_predicted = true;
         ins_filters = h->d_snap;
