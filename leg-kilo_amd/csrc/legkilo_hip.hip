@@ -195,8 +195,9 @@ static int check_map_errors(lk_handle* h, const unsigned int* fetched = nullptr)
         const unsigned int rest = ctr[LK_CTR_ERR] & ~LK_E_SPEC_TIMEOUT;
         HIPCHK(h, hipMemcpyAsync(h->map.counters + LK_CTR_ERR, &rest, sizeof(rest), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        // the filter keeps its PRE-SCAN state on every path: the scan-resident kernel holds x / P in LDS and returns before its write-back;
-        // the grid-resident kernel and the pipelined launches work on filters[0] directly, so their scans start with a copy that is put back here
+        // the filter keeps its PRE-SCAN state on every path: the resident kernels' and the pipelined launches' scans start with a copy of
+        // filters[0] that is put back here (a scan-resident launch given up returns before its write-back, but a scan picked up again after
+        // fallback items has written the filter once)
         if (h->fbackup_valid) {
             HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_fbackup, sizeof(LkFilter), hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2510,8 +2511,12 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
         msg_kind == 2 ? (xid ? lk_scan_stream_kernel<2, true> : lk_scan_stream_kernel<2, false>)
       : msg_kind == 1 ? (xid ? lk_scan_stream_kernel<1, true> : lk_scan_stream_kernel<1, false>)
                       : (xid ? lk_scan_stream_kernel<0, true> : lk_scan_stream_kernel<0, false>);
+    // a launch given up keeps the filter in LDS and returns before its write-back - but a scan that is picked up again after fallback items
+    // has written it once: every scan starts with a copy, which a LK_ERR_TIMEOUT in any of its launches puts back (check_map_errors)
+    if ((rc = backup_filter(h))) return rc;
     h->resident_scans += 1;
     for (size_t round = 0;; ++round) {
+        h->fbackup_valid = true;   // (finish_scan's error check ends the previous launch's claim on the copy; it is still the pre-scan state)
     LAUNCH(h, "scan_stream", hipLaunchKernelGGL(k, dim3(1), dim3((1 + LK_INS_WAVES) * LK_WAVE), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
                                                 h->d_ids, epoch0, timeout_ms, d_rs));
 #ifdef LK_DEBUG_RES
@@ -2638,6 +2643,7 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     h->grid_scans += 1;
     int b0 = 0;
     for (size_t round = 0;; ++round) {
+        h->fbackup_valid = true;   // the copy taken above is the pre-scan state for every launch of this scan
         LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
                                                   h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride, b0, d_rs));
         if ((rc = finish_scan(h, pose, d_rs))) return rc;
