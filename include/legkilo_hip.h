@@ -415,6 +415,10 @@ int lk_stream_resident(lk_handle* h, int on);
  * tree, a root with more than 64 queued points) are not part of the resident kernel: a bucket that produces one ends the launch, the
  * items run as a launch of their own and the resident kernel is launched again from where it stopped (same results; ~30 us per event). */
 int lk_stream_resident_stats(lk_handle* h, uint64_t* out2);
+/* TEST HOOK (fault injection for the LK_ERR_TIMEOUT path; no product use): bound_ms > 0 - the resident stream kernels' next launches run with
+ * this bound on their device-side waits AND one role stops answering at the scan's fourth bucket, so the call fails with LK_ERR_TIMEOUT and
+ * must leave the filter at its pre-scan state; 0 - back to normal. */
+int lk_test_stall(lk_handle* h, unsigned int bound_ms);
 /* Grid-resident stream kernel: a scan whose time buckets all hold > 512 points (and no IMU / kinematic messages between them) runs
  * its whole bucket loop as ONE launch of co-resident workgroups - the phases of the per-bucket launches separated by grid barriers
  * (agent-scope release / acquire hand-offs) instead of kernel boundaries, the rarely needed phases entered only when the device

@@ -21,7 +21,7 @@ EXPORTS = [
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
     "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
-    "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats", "lk_stream_resident_stats",
+    "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats", "lk_stream_resident_stats", "lk_test_stall",
 ]
 
 
@@ -556,6 +556,10 @@ class LegKiloHip:
         m = C.c_uint32(0)
         self._chk(self.L.lk_stream_grid_placement(self.h, C.byref(m)))
         return int(m.value)
+
+    def test_stall(self, bound_ms):
+        """Fault injection for the LK_ERR_TIMEOUT path of the resident stream kernels (include/legkilo_hip.h: lk_test_stall); 0 = off."""
+        self._chk(self.L.lk_test_stall(self.h, C.c_uint(int(bound_ms))))
 
     def stream_resident_stats(self):
         """(scans through the scan-resident kernel, launches beyond one per scan: its fallback rounds)."""

@@ -82,6 +82,7 @@ struct lk_handle {
         unsigned int seq, pad_;      // written last: the host may poll it instead of blocking in hipStreamSynchronize
     };
     uint64_t resident_scans = 0, resident_relaunches = 0, grid_scans = 0, grid_relaunches = 0;   // lk_stream_resident_stats
+    unsigned int test_stall_ms = 0;   // lk_test_stall: the next resident launches run with this bound and an injected stall (error-path test)
     unsigned int result_seq = 0;
     ScanResult* h_result = nullptr;   // hipHostMalloc(mapped)
     ScanResult* d_result = nullptr;   // its device-side address
@@ -1000,7 +1001,10 @@ template <int MSG, bool XID>
 __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
                           LkFilter* snap2 /* two snapshots */, float* world, int2* ids, unsigned int epoch0, unsigned int timeout_ms, LkResume* rs) {
-    const unsigned long long resident_timeout_ = (unsigned long long)timeout_ms * 100000ull;   // ticks of the 100 MHz wall clock
+    // bit 31 of timeout_ms (lk_test_stall: fault injection for the error-path test, never set otherwise): the insert team stops answering at
+    // bucket 3, so the filter wave's bounded wait is given up and the call fails with LK_ERR_TIMEOUT
+    const bool inject_stall = (timeout_ms >> 31) != 0u;
+    const unsigned long long resident_timeout_ = (unsigned long long)(timeout_ms & 0x7fffffffu) * 100000ull;   // ticks of the 100 MHz wall clock
     __shared__ WaveSmem sm;
     __shared__ double rows[64 * LK_ROW2];
     __shared__ int f_post, f_decided, f_done;   // bucket index of: latest posterior snapshot / stamps final / insert complete
@@ -1034,7 +1038,7 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             LkMap m = map;
             m.epoch = epoch0 + (unsigned int)b;
             const LkFilter* sn = snap2 + (b & 1);
-            if (!FLAG_WAIT(f_post, b)) break;
+            if (!FLAG_WAIT(f_post, inject_stall && b >= 3 ? nbk + 1 : b)) break;   // (injected stall: a post that never comes)
             if (rank == 0) RS_TS(1, b);
             RS_STAMP(0);
 #if LK_X_SLEEP & 2
@@ -1276,7 +1280,8 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
     if (nbk == 0) return;
     const double* T = rag_t(rg, 0);
     const unsigned long long* po = rag_pt_off(rg, 0);
-    const unsigned long long timeout_ticks = (unsigned long long)timeout_ms * 100000ull;
+    const bool inject_stall = (timeout_ms >> 31) != 0u;   // lk_test_stall (fault injection for the error-path test): workgroup 1 leaves at bucket 3
+    const unsigned long long timeout_ticks = (unsigned long long)(timeout_ms & 0x7fffffffu) * 100000ull;
     unsigned int phase = 0;
     if (tid == 0) {
         s_abort = 0, s_one_xcd = 0;
@@ -1374,6 +1379,7 @@ __global__ void __launch_bounds__(LK_FB)   // (compiled for two waves per SIMD -
         const int ntiles = (n + LK_WAVE - 1) / LK_WAVE;
         const lk_point* bp = pts + base;
         float* bw = world ? world + 4 * base : nullptr;
+        if (inject_stall && b >= 3 && wg == 1) return;   // (injected stall: the others' barrier wait is given up after the bound)
         // the pools' bookkeeping for this bucket's insert (the previous insert is complete, the tiles do not read what it touches)
         if (wg == (G > 1 ? 1 : 0)) dev_bucket_begin(map);
         {   // residual pass: tile t by wave t of the grid (lk_residual_kernel's body, one partial record per tile)
@@ -2518,7 +2524,7 @@ static int run_scan_resident(lk_handle* h, const lk_point* d_pts, const std::vec
     for (size_t round = 0;; ++round) {
         h->fbackup_valid = true;   // (finish_scan's error check ends the previous launch's claim on the copy; it is still the pre-scan state)
     LAUNCH(h, "scan_stream", hipLaunchKernelGGL(k, dim3(1), dim3((1 + LK_INS_WAVES) * LK_WAVE), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                                h->d_ids, epoch0, timeout_ms, d_rs));
+                                                h->d_ids, epoch0, h->test_stall_ms ? (h->test_stall_ms | 0x80000000u) : timeout_ms, d_rs));
 #ifdef LK_DEBUG_RES
     {
         unsigned long long hb[32];
@@ -2645,7 +2651,7 @@ static int run_scan_grid(lk_handle* h, const lk_point* d_pts, const std::vector<
     for (size_t round = 0;; ++round) {
         h->fbackup_valid = true;   // the copy taken above is the pre-scan state for every launch of this scan
         LAUNCH(h, "scan_grid", hipLaunchKernelGGL(k, dim3(G * stride), dim3(LK_FB), 0, h->stream, h->map, h->pr, h->d_filters, d_pts, rg, h->d_Q, h->d_snap, d_world,
-                                                  h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), timeout_ms, stride, b0, d_rs));
+                                                  h->d_partials, reinterpret_cast<unsigned int*>(dr + o_sync), h->test_stall_ms ? (h->test_stall_ms | 0x80000000u) : timeout_ms, stride, b0, d_rs));
         if ((rc = finish_scan(h, pose, d_rs))) return rc;
 #ifdef LK_DEBUG_RES
         {
@@ -4054,6 +4060,11 @@ int lk_stream_resident(lk_handle* h, int on) {
 int lk_stream_grid(lk_handle* h, int on) {
     CHECK_H(h);
     h->gridscan_mode = std::min(std::max(on, 0), 2);
+    return LK_OK;
+}
+int lk_test_stall(lk_handle* h, unsigned int bound_ms) {
+    CHECK_H(h);
+    h->test_stall_ms = bound_ms & 0x7fffffffu;
     return LK_OK;
 }
 int lk_stream_resident_stats(lk_handle* h, uint64_t* out2) {

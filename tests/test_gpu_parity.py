@@ -671,6 +671,54 @@ def test_scan_resident_kernel_edge_buckets(scene, oracle_lib, hip_lib):
         obj.close()
 
 
+@pytest.mark.parametrize("kind", ["scan-resident", "grid-resident"])
+def test_resident_kernel_timeout_restores_the_filter(scene, hip_lib, kind):
+    """The error contract of the resident stream kernels (include/legkilo_hip.h, LK_ERR_TIMEOUT): a bounded device-side wait that is given up
+    fails the call, the FILTER keeps its pre-scan state (the scan started with a copy that is put back), the status is not sticky, and the handle
+    goes on once its map has been restored.  lk_test_stall injects the fault: one role stops answering at the scan's fourth bucket, every wait is
+    bounded by 30 ms.  The same scan through an untouched second handle is the reference for "goes on"."""
+    from legkilo_amd import binding
+
+    g = hip_lib.LegKiloHip(scene.cfg())
+    g_ref = hip_lib.LegKiloHip(scene.cfg())
+    t0 = 51.0
+    for obj in (g, g_ref):
+        x0 = scenes.init_filter(obj, scene, t0)
+        scenes.first_frame(obj, scene, t0, x0, **({"dense": 20000} if kind == "grid-resident" else {}))
+        if kind == "grid-resident":
+            obj.stream_grid(2)
+
+    def scan_of(k):
+        tb = t0 + 0.1 * k
+        if kind == "scan-resident":
+            return scenes.vlp_scan_input(scene, tb, k), tb
+        return synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=100000, n_buckets=51, seed_scan=9700 + k, seed_noise=9800 + k), tb
+
+    pts, tb = scan_of(0)
+    g.process_scan(pts, tb)
+    g_ref.process_scan(pts, tb)
+    blob = g.map_export()
+    x_pre, P_pre = g.get_state()
+    t_pre = g.get_times()
+    pts, tb = scan_of(1)
+    g.test_stall(30)
+    with pytest.raises(binding.LegKiloError, match="error -6"):   # LK_ERR_TIMEOUT
+        g.process_scan(pts, tb)
+    g.test_stall(0)
+    x_after, P_after = g.get_state()
+    assert np.array_equal(x_pre, x_after) and np.array_equal(P_pre, P_after), "the filter must keep its pre-scan state"
+    g.map_import(blob)       # the map may hold a partial insert: restore it ...
+    g.set_times(*t_pre)
+    pg, _ = g.process_scan(pts, tb)   # ... and replay the scan
+    pr, _ = g_ref.process_scan(pts, tb)
+    assert (pg.n_buckets, pg.n_updates, int(pg.n_effect)) == (pr.n_buckets, pr.n_updates, int(pr.n_effect))
+    (xg, Pg), (xr, Pr) = g.get_state(), g_ref.get_state()
+    assert np.array_equal(xg, xr) and np.array_equal(Pg, Pr)
+    scenes.maps_identical(g.map_export(), g_ref.map_export())
+    for obj in (g, g_ref):
+        obj.close()
+
+
 @pytest.mark.parametrize("nb", [5, 51, -51])
 def test_scan_grid_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_lib, nb):
     """The grid-resident stream kernel (lk_scan_grid_kernel: the whole bucket loop of a scan of LARGE buckets as one launch of
