@@ -518,6 +518,7 @@ def main():
     # bucket, in voxel-grid cell order (synth.dense_scan(layout="cell"): the order pcl::VoxelGrid leaves its output in, KILO.cc:356-360), which
     # puts neighbouring lanes into neighbouring voxels; a recorded scan that was not voxel-filtered has no such order.
     shuf = None
+    resorted = None
     if rank == 0 and world_size == 1 and args.shuffle_check > 0 and not args.shuffle_main:
         d_shuf = shuffled_in_bucket(d_batch, 4242)
         torch.cuda.synchronize()
@@ -549,27 +550,15 @@ def main():
             except Exception as e:  # noqa: BLE001
                 warnings.append(f"profiles/latest_shuffled_pmc.json unreadable: {e}")
         shuf = (sh_host, sh_last)
-        # ... and what it costs to put such a batch back into voxel order on the device: per scan, world position from the scan's PRIOR pose ->
-        # voxel key -> stable sort of every bucket by key (torch = rocPRIM radix sort; once per loaded batch, not per replay), and the step on it
+        # ... and what it costs to put such a batch back into voxel order on the device (lk_batch_sort_by_voxel_dev: root-voxel key under the slot's
+        # PRIOR pose, stable segmented radix sort of every bucket, one gather; once per loaded batch, not per replay), and the step on it
         try:
-            vs = float(P["voxel_size"])
-            R_ = d_x[:, :9].reshape(S, 3, 3)
-            E_ = torch.tensor(np.array(P["extrinsic_R"], float).reshape(3, 3), device=dev)
-            T_ = torch.tensor(np.array(P["extrinsic_T"], float), device=dev)
+            g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S)
+            d_res = torch.empty_like(d_shuf)
+            g.batch_sort_by_voxel_dev(d_shuf.data_ptr(), d_res.data_ptr(), S, N_PTS, off)   # warm (allocations, rocPRIM's first call)
             torch.cuda.synchronize()
             ts = time.perf_counter()
-            d_res = torch.empty_like(d_shuf)
-            for b in range(len(dt)):
-                a_, e_ = int(off[b]), int(off[b + 1])
-                if e_ <= a_:
-                    continue
-                xyz = d_shuf[:, a_:e_, :3].contiguous().view(torch.float32).to(torch.float64)
-                pw = torch.matmul(torch.matmul(xyz, E_.T) + T_, R_.transpose(1, 2)) + d_x[:, None, 9:12]
-                kk = torch.floor(pw / vs).to(torch.int64) + 2048
-                key = (kk[..., 2] * 4096 + kk[..., 1]) * 4096 + kk[..., 0]
-                order = torch.argsort(key, dim=1, stable=True)
-                d_res[:, a_:e_] = torch.gather(d_shuf[:, a_:e_], 1, order[..., None].expand(-1, -1, 4))
-                del xyz, pw, kk, key, order
+            g.batch_sort_by_voxel_dev(d_shuf.data_ptr(), d_res.data_ptr(), S, N_PTS, off)
             torch.cuda.synchronize()
             t_sort = time.perf_counter() - ts
             for k in range(max(args.warmup, 3)):
@@ -582,12 +571,19 @@ def main():
             finish(args.steps)
             sync_all()
             el_rs = time.perf_counter() - ts
+            rs_last = ring[(args.steps - 1) % ring_rows][: S * pose_sz].numpy().view(_abi.pose_dtype()).copy()
+            n_rs = min(max(args.shuffle_check // 3, 1), S)
+            rs_host = d_res[:n_rs].cpu().numpy().view(scans[0].dtype).reshape(n_rs, N_PTS)
+            resorted = (rs_host, rs_last)
             extra["shuffled_resort_by_voxel_ms_per_batch_once"] = round(t_sort * 1e3, 2)
+            extra["shuffled_resort_ps_per_point"] = round(t_sort * 1e12 / (S * N_PTS), 1)
+            extra["shuffled_resort_entry"] = "lk_batch_sort_by_voxel_dev"
             extra["shuffled_resorted_ms_per_step"] = round(el_rs / args.steps * 1e3, 3)
             extra["shuffled_resort_breaks_even_after_steps"] = None if el_sh <= el_rs else int(math.ceil(t_sort / ((el_sh - el_rs) / args.steps)))
             del d_res
         except Exception as e:  # noqa: BLE001
             extra["shuffled_resort_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+            warnings.append("device re-sort of the shuffled batch failed: " + extra["shuffled_resort_error"])
         del d_shuf
 
     # ---- kernel-level timing pass (HIP events on the handle's stream, whole-batch launches on ONE stream), outside the timed region
@@ -956,6 +952,18 @@ def main():
                 sh_dpos = max(sh_dpos, float(np.abs(np.array(pose.pos) - sl_["pos"]).max()))
             parity["shuffled_in_bucket"] = {"n": len(sh_host), "counts_equal": sh_eq, "max_pos_delta_m": sh_dpos, "tolerance_m": 1e-7}
             parity["ok"] = bool(parity["ok"] and sh_dpos <= 1e-7 and sh_eq >= len(sh_host) - max(1, len(sh_host) // 50))
+        if resorted is not None:   # the device-sorted batch: the oracle replays the scans as lk_batch_sort_by_voxel_dev left them
+            rs_host, rs_last = resorted
+            rs_eq, rs_dpos = 0, 0.0
+            for s_ in range(len(rs_host)):
+                o.set_state(xs[s_], Ps[s_])
+                o.set_times(0.0, 0.0)
+                pose, _ = o.process_scan(rs_host[s_], 0.0, with_sort=True)
+                sl_ = rs_last[s_]
+                rs_eq += int((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect)) == (int(sl_["n_buckets"]), int(sl_["n_updates"]), int(sl_["n_effect"])))
+                rs_dpos = max(rs_dpos, float(np.abs(np.array(pose.pos) - sl_["pos"]).max()))
+            parity["shuffled_resorted"] = {"n": len(rs_host), "counts_equal": rs_eq, "max_pos_delta_m": rs_dpos, "tolerance_m": 1e-7}
+            parity["ok"] = bool(parity["ok"] and rs_dpos <= 1e-7 and rs_eq >= len(rs_host) - 1)
         # and the full config-3 path with insert (the reference's own timed lambda, KILO.cc:367-396)
         o.set_map_insert(True)
         o.set_state(synth.initial_state(traj, t_after, P), 1e-6 * np.eye(30))

@@ -300,6 +300,12 @@ int lk_batch_set_priors(lk_handle* h, const double* x36, const double* P900, siz
 /* same, priors already resident in HBM (d_x36: n_scans x 36, d_P900: n_scans x 900); asynchronous on the handle's
  * stream - a replay loop re-arms its batch without touching the host */
 int lk_batch_set_priors_dev(lk_handle* h, const double* d_x36, const double* d_P900, size_t n_scans);
+/* Puts every time bucket of every scan of a device-resident batch (layout of lk_batch_replay_dev) into root-voxel order under the slots' PRIOR
+ * poses (lk_batch_set_priors(_dev) first): the 64 points of a residual wave then look at a handful of voxels instead of sixty.  Points keep
+ * their bucket; the order inside a bucket is one of the legal outcomes of the reference's sort of equal time stamps (KILO.cc:369), so the
+ * replay of d_out is a replay of the same scans.  Once per loaded batch.  d_in and d_out must not overlap; needs 16 B of scratch per point. */
+int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_out, size_t n_scans, size_t n_pts, const uint32_t* bucket_off,
+                               size_t n_buckets);
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
 /* Bulk read-out of the filters a batch replay left in slots [first_slot, first_slot + n): state (n x 36: rot 9, pos, vel, ba, bw,

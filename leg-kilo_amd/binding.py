@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_replay_dev", "lk_batch_sort_by_voxel_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats", "lk_stream_resident_stats", "lk_test_stall",
 ]
 
@@ -334,6 +334,13 @@ class LegKiloHip:
         self._chk(self.L.lk_batch_replay_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts),
                                              C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
         return poses
+
+    def batch_sort_by_voxel_dev(self, d_in, d_out, n_scans, n_pts, bucket_off):
+        """Every bucket of every scan of a device-resident batch into root-voxel order under the slots' prior poses (lk_batch_sort_by_voxel_dev):
+        d_out = the same scans, a residual wave's points a handful of voxels apart.  Priors first (batch_set_priors(_dev))."""
+        off = np.ascontiguousarray(bucket_off, dtype=np.uint32)
+        self._chk(self.L.lk_batch_sort_by_voxel_dev(self.h, C.c_void_p(d_in), C.c_void_p(d_out), C.c_size_t(n_scans), C.c_size_t(n_pts), _p(off),
+                                                    C.c_size_t(len(off) - 1)))
 
     def batch_replay_async_dev(self, d_pts, first_slot, n_scans, n_pts, t_begin, bucket_off, bucket_dt, d_x36=None, d_P900=None,
                                host_out_ptr=None):

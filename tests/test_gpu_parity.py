@@ -849,6 +849,80 @@ def test_config2_full_size_residuals(big, hip_lib):
 
 
 # ----------------------------------------------------------------------------- batch replay (config 5, reduced)
+def test_batch_sort_by_voxel(scene, oracle_lib, hip_lib):
+    """lk_batch_sort_by_voxel_dev: every time bucket of every scan of a device-resident batch put into root-voxel order under the slots' prior
+    poses.  The buckets come in RANDOM order; afterwards every bucket holds exactly its own points (a permutation: curvature untouched), the 64
+    points of a residual tile lie in far fewer root voxels than before, and the replay of the sorted batch equals the oracle's replay of the SAME
+    sorted scans (counts exact, state 1e-8) - the order inside a bucket is one of the legal outcomes of the reference's sort (KILO.cc:369)."""
+    S, n_pts, nb = 6, 8000, 5
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    g.init_process_cov_q()
+    o.set_map_insert(False)
+    rng = np.random.default_rng(6116)
+    xs, Ps, scans = [], [], []
+    for s in range(S):
+        tb = t0 + 1.2 + 0.37 * s
+        sc = synth.dense_scan(scene.world, scene.traj, tb, scene.P, n=n_pts, n_buckets=nb, seed_scan=6116 + s, seed_noise=7227 + s)
+        off, dt = synth.buckets_of(sc)
+        for b in range(nb):   # random order inside every bucket
+            a, e = int(off[b]), int(off[b + 1])
+            sc[a:e] = sc[a:e][rng.permutation(e - a)]
+        scans.append(sc)
+        xs.append(synth.initial_state(scene.traj, tb, scene.P, rng, 0.02, 0.5))
+        Ps.append(1e-4 * np.eye(30))
+    off, dt = synth.buckets_of(scans[0])
+    allpts = np.ascontiguousarray(np.concatenate(scans))
+    d_in, d_out = g.device_malloc(allpts.nbytes), g.device_malloc(allpts.nbytes)
+    g.h2d(d_in, allpts)
+    g.batch_set_priors(np.array(xs), np.array(Ps))
+    g.batch_sort_by_voxel_dev(d_in, d_out, S, n_pts, off)
+    srt = np.empty_like(allpts)
+    g.d2h(srt, d_out)
+    vs = float(scene.P["voxel_size"])
+    E = np.array(scene.P["extrinsic_R"], float).reshape(3, 3)
+    T = np.array(scene.P["extrinsic_T"], float)
+
+    def voxels_per_tile(sc_, x_):   # mean number of distinct root voxels among the 64 points of a residual tile
+        R, p = x_[:9].reshape(3, 3), x_[9:12]
+        cnt = []
+        for b in range(nb):
+            a, e = int(off[b]), int(off[b + 1])
+            xyz = np.stack([sc_["x"][a:e], sc_["y"][a:e], sc_["z"][a:e]], 1).astype(np.float64)
+            key = np.floor(((xyz @ E.T + T) @ R.T + p) / vs).astype(np.int64)
+            lin = (key[:, 2] * 4096 + key[:, 1]) * 4096 + key[:, 0]
+            cnt += [len(np.unique(lin[i:i + 64])) for i in range(0, e - a, 64)]
+        return float(np.mean(cnt))
+
+    for s in range(S):
+        a_in, a_out = allpts[s * n_pts:(s + 1) * n_pts], srt[s * n_pts:(s + 1) * n_pts]
+        for b in range(nb):
+            a, e = int(off[b]), int(off[b + 1])
+            u_in, u_out = (np.ascontiguousarray(q[a:e]).view(np.uint64).reshape(-1, 2) for q in (a_in, a_out))   # 16-byte records as two words
+            assert np.array_equal(u_in[np.lexsort((u_in[:, 1], u_in[:, 0]))], u_out[np.lexsort((u_out[:, 1], u_out[:, 0]))]), (s, b)
+        v_in, v_out = voxels_per_tile(a_in, xs[s]), voxels_per_tile(a_out, xs[s])
+        assert v_out < 0.7 * v_in, (s, v_in, v_out)   # (1 600 points per bucket: ~2 per voxel, so ~32 voxels per tile is the floor here)
+    print(f"distinct root voxels per 64-point tile: {voxels_per_tile(allpts[:n_pts], xs[0]):.1f} in random order, {voxels_per_tile(srt[:n_pts], xs[0]):.1f} sorted")
+    poses = g.batch_replay_dev(d_out, S, n_pts, 0.0, off, dt)
+    for s in range(S):
+        o.set_state(xs[s], Ps[s])
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(srt[s * n_pts:(s + 1) * n_pts], 0.0)
+        xo, _ = o.get_state()
+        xg, _ = g.get_state(slot=s)
+        assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
+        assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+    g.device_free(d_in)
+    g.device_free(d_out)
+    with pytest.raises(hip_lib.LegKiloError):   # buckets must cover the scan
+        g.batch_sort_by_voxel_dev(d_in, d_out, S, n_pts, off[:-1])
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("S", [6, 7, 3])   # 6/7: three slot groups on three HIP streams (even / ragged split); 3: single stream
 def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
     n_pts, nb = 8000, 5

@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r05t2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for KIND in vlp 51; do
+for KIND in ${KINDS:-vlp 51}; do
   D=/tmp/trace_$KIND
   rm -rf $D
   timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $D -o t -- python $REPO/tools/stream_workload.py --kind $KIND --scans 4 --warm 6 > $OUT/trace_$KIND.log 2>&1
