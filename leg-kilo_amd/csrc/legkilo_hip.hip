@@ -149,7 +149,13 @@ static int launch(lk_handle* h, const char* name, F&& f) {
         p.launches += 1;
         p.total_ms += ms;
     } else {
+        // LEGKILO_TRACE_LAUNCH=<prefix> (debug aid): every launch whose name starts with the prefix is announced on stderr and waited for -
+        // the last name printed before a "Memory access fault by GPU" is the kernel that made it
+        static const char* trace = getenv("LEGKILO_TRACE_LAUNCH");
+        const bool tr = trace && strncmp(name, trace, strlen(trace)) == 0;
+        if (tr) fprintf(stderr, "[launch] %s\n", name), fflush(stderr);
         f();
+        if (tr) HIPCHK(h, hipDeviceSynchronize());
     }
     HIPCHK(h, hipGetLastError());
     return LK_OK;
@@ -3628,6 +3634,13 @@ static void ov_free(lk_handle* h) {
     h->ov_pool_bytes = 0;
     h->ov_last_slots = 0;   // nothing of the last replay is left to export / count (lk_overlay_export, lk_overlay_stats)
 }
+// LEGKILO_POISON_POOLS (test aid): node records that look plausible - a few points, no children - and point at a block far outside any pool
+__global__ void __launch_bounds__(256) lk_ov_poison_nodes_kernel(lk_node_rec* nodes, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    nodes[i].npts = 3, nodes[i].new_points = 1, nodes[i].block = 0x3fffff00, nodes[i].layer = 0, nodes[i].state = LK_NODE_UPDATE_ENABLE | LK_NODE_INIT_OCTO;
+    for (int c = 0; c < 8; ++c) nodes[i].child[c] = -1;
+}
 // Per-scan capacities.  lk_overlay_reserve's numbers if given; else, when an earlier replay of scans of this size has left its
 // high-water marks, those + 25 % (pools more than twice that are released and re-made: round 4 reserved n_pts / 6 roots = 110 MB per scan,
 // 113 GB for 1 024 scans, where the bench's scans use 4 700 roots); else a first guess of n_pts / 18 roots.  `grow` (bits of the slots' error
@@ -3710,6 +3723,16 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.cplx, s * n.scan_cap * 2 * sizeof(int));
     if (e == hipSuccess) e = get(&o.ptroot, s * n.scan_cap * sizeof(int));
     if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
+    if (e == hipSuccess && getenv("LEGKILO_POISON_POOLS")) {
+        // test aid: fresh pools hold 0x5a bytes instead of whatever the allocator hands out (usually zeros) - a kernel that trusts a record
+        // nobody has written then faults HERE AND NOW, not in the one process whose allocation history leaves garbage there
+        (void)hipMemsetAsync(o.nodes, 0x5a, s * n.nodes_cap * sizeof(lk_node_rec), h->stream);
+        hipLaunchKernelGGL(lk_ov_poison_nodes_kernel, dim3((unsigned int)((s * n.nodes_cap + 255) / 256)), dim3(256), 0, h->stream, o.nodes, s * n.nodes_cap);
+        (void)hipMemsetAsync(o.planes, 0x5a, s * n.nodes_cap * sizeof(lk_plane_rec), h->stream);
+        (void)hipMemsetAsync(o.match, 0x5a, s * n.nodes_cap * sizeof(lk_match_rec), h->stream);
+        (void)hipMemsetAsync(o.slots, 0x5a, s * n.hash_cap * LK_SLOTS * sizeof(float4), h->stream);
+        (void)hipMemsetAsync(o.ptroot, 0x5a, s * n.scan_cap * sizeof(int), h->stream);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         ov_free(h);

@@ -187,6 +187,11 @@ __device__ __forceinline__ void ov_root_record_reset(lk_node_rec* nd) {   // a r
     nd->pad_[LK_PAD_QCOUNT] = 0;
     nd->pad_[LK_PAD_LIVE] = 0;
     nd->pad_[LK_PAD_BASE] = 0;
+    // "no block": what lk_ov_point_geom_kernel (thread per point, no error test of its own) sees in a root the re-projection has claimed but
+    // lk_ov_materialise_kernel never filled in because the slot's pools had overflowed - whatever the memory held before would be a block id
+#ifndef LK_X_NO_BLOCK_RESET   // (build switch of the regression check only: tools/gpu_r05_poison.sh shows the fault without this line)
+    nd->block = -1;
+#endif
 }
 // once per allocation: every table entry empty, every root record's queue fields clean
 __global__ void __launch_bounds__(256) lk_ov_init_kernel(LkOverlay ov) {
