@@ -166,6 +166,24 @@ static int launch(lk_handle* h, const char* name, F&& f) {
         if (rc_ != LK_OK) return rc_;                          \
     } while (0)
 
+// Every device allocation of this library.  LEGKILO_POISON_POOLS=1 (test aid): the fresh memory is filled with 0x5a bytes instead of whatever the
+// allocator hands out - in a young process zeros, in a long-lived one somebody's old data - so that a kernel which trusts memory nobody has
+// written meets garbage in EVERY run (the whole GPU suite is run that way once per round: tools/gpu_poison_suite.sh)
+static hipError_t lk_hip_malloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    static const bool poison = getenv("LEGKILO_POISON_POOLS") != nullptr;
+    if (e == hipSuccess && (poison || getenv("LEGKILO_POISON_POOLS")) && bytes) {
+        e = hipMemset(*p, 0x5a, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();   // (the fill runs on the null stream, the library's streams do not wait for that one)
+    }
+    return e;
+}
+template <typename T>
+static hipError_t lk_hip_malloc(T** p, size_t bytes) {
+    return lk_hip_malloc(reinterpret_cast<void**>(p), bytes);
+}
+#define hipMalloc(p, n) lk_hip_malloc((p), (n))
+
 // device temporaries of one call: freed on every return path
 struct DevTemps {
     std::vector<void*> ptrs;
@@ -3726,12 +3744,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess && getenv("LEGKILO_POISON_POOLS")) {
         // test aid: fresh pools hold 0x5a bytes instead of whatever the allocator hands out (usually zeros) - a kernel that trusts a record
         // nobody has written then faults HERE AND NOW, not in the one process whose allocation history leaves garbage there
-        (void)hipMemsetAsync(o.nodes, 0x5a, s * n.nodes_cap * sizeof(lk_node_rec), h->stream);
         hipLaunchKernelGGL(lk_ov_poison_nodes_kernel, dim3((unsigned int)((s * n.nodes_cap + 255) / 256)), dim3(256), 0, h->stream, o.nodes, s * n.nodes_cap);
-        (void)hipMemsetAsync(o.planes, 0x5a, s * n.nodes_cap * sizeof(lk_plane_rec), h->stream);
-        (void)hipMemsetAsync(o.match, 0x5a, s * n.nodes_cap * sizeof(lk_match_rec), h->stream);
-        (void)hipMemsetAsync(o.slots, 0x5a, s * n.hash_cap * LK_SLOTS * sizeof(float4), h->stream);
-        (void)hipMemsetAsync(o.ptroot, 0x5a, s * n.scan_cap * sizeof(int), h->stream);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -1198,6 +1198,7 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
         # handle stays usable.  The fresh pools are poisoned (LEGKILO_POISON_POOLS): a kernel that follows a record which the overflowing
         # slot never got to write must meet garbage here, not the zeros a young process's allocator happens to hand out (round 5: the
         # thread-per-point geometry pass did exactly that and faulted in ONE test order only)
+        poison_before = os.environ.get("LEGKILO_POISON_POOLS")
         os.environ["LEGKILO_POISON_POOLS"] = "1"
         g.overlay_reserve(64, 128, 64)
         g.batch_set_priors(np.array(xs), np.array(Ps))
@@ -1205,7 +1206,8 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
             with pytest.raises(hip_lib.LegKiloError, match="overlay pool overflow"):
                 g.batch_replay_overlay_dev(d_pts, S, n_pts, 0.0, off, dt)
         finally:
-            os.environ.pop("LEGKILO_POISON_POOLS", None)
+            if poison_before is None:
+                os.environ.pop("LEGKILO_POISON_POOLS", None)
         g.overlay_reserve(16384, 32768, 16384)   # a young map: a scattered 30 000-point scan touches most of its voxels
     if case == "groups":
         g.overlay_reserve(2048, 4096, 2048)
