@@ -17,6 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """LK_TEST_ORDER=reverse | shuffle:<seed>: the collected tests in another order (tools/gpu_order_suite.sh).  The tests share one process and
+    one GPU: anything that only works behind a particular predecessor - memory an earlier handle left behind, a static of the library - shows up
+    under another order (round 5 found such a fault in the default order)."""
+    order = os.environ.get("LK_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     import oracle_binding as ob
