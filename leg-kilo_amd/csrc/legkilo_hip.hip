@@ -3915,7 +3915,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         static const int ov_apply_wg = getenv("LEGKILO_OV_APPLY_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_APPLY_WG"))) : 0;
         static const int ov_fb_wg = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
         LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(ov_apply_wg ? ov_apply_wg : per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
-        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(ov_fb_wg ? ov_fb_wg : std::min(per_slot, 8), Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
+        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(Sg, ov_fb_wg ? ov_fb_wg : 128)), dim3(LK_MB), 0, st, ov, h->pr, fl, src, Sg));   // (1 024 slots, workgroups 8 / 32 / 128 / 256 / 512: 0.54 / 0.26 / 0.15 / 0.17 / 0.16 ms per batch; a workgroup or more per slot: 0.34)
         if (k + 1 < live.size())
             LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
                                                     t_begin + bucket_dt[live[k + 1]], 2));
@@ -4034,7 +4034,8 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
             LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, ov, h->pr));
             LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
             LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
-            LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(per_slot, 8), S), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
+            static const int ov_fb_wg_r = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
+            LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min((int)S, ov_fb_wg_r ? ov_fb_wg_r : 128)), dim3(LK_MB), 0, st, ov, h->pr, fl, src, (int)S));
         }
         HIPCHK(h, hipGetLastError());
         h->ov_last_slots = (uint32_t)S;

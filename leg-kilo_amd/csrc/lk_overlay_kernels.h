@@ -1002,15 +1002,37 @@ __global__ void __launch_bounds__(LK_MB)
     dev_insert_apply<false>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                             (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
 }
+// A FEW workgroups for the whole batch.  The code needs 254 + 126 registers and 6.3 KB of scratch per lane, and a launch with a workgroup per
+// slot costs ~70 us whether or not a single item exists - on the bench's map none does in most buckets, and the recorded-run replay pays
+// that once per bucket LEVEL (360 of them: half of its time).  Every workgroup reads ALL slots' counters (one contiguous array: S / 256
+// coalesced loads per thread) and keeps the list of the slots that have items; the workgroups then share that list, a slot's items are
+// shared by the four waves of the workgroup that takes it.
+#define LK_OV_FB_LIST 4096
 __global__ void __launch_bounds__(LK_MB)
-    lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
-    const LkMap pm = ov_slot_map(ov, blockIdx.y);
-    if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
-    const lk_point* pts;
-    const int n = ov_pt_src(src, blockIdx.y, &pts);
-    if (n == 0) return;
-    dev_insert_fallback<false>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
-                               (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+    lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src, const int n_slots) {
+    __shared__ int active[LK_OV_FB_LIST];
+    __shared__ int n_active;
+    for (int s0 = 0; s0 < n_slots; s0 += LK_OV_FB_LIST) {   // (one round unless the batch has more than 4 096 slots)
+        __syncthreads();
+        if (threadIdx.x == 0) n_active = 0;
+        __syncthreads();
+        const int s1 = min(n_slots, s0 + LK_OV_FB_LIST);
+        for (int s = s0 + (int)threadIdx.x; s < s1; s += LK_MB) {
+            const unsigned int* c = ov.counters + (size_t)s * LK_CTR_COUNT;
+            // (a slot whose pools overflowed: the call fails, nothing more is built on clamped ids)
+            if (c[LK_CTR_FALLBACK] != 0u && c[LK_CTR_ERR] == 0u) active[atomicAdd(&n_active, 1)] = s;
+        }
+        __syncthreads();
+        const int na = n_active;
+        for (int a = (int)blockIdx.x; a < na; a += (int)gridDim.x) {
+            const int slot = active[a];
+            const LkMap pm = ov_slot_map(ov, (unsigned int)slot);
+            const lk_point* pts;
+            const int n = ov_pt_src(src, (unsigned int)slot, &pts);
+            if (n == 0) continue;
+            dev_insert_fallback<false>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- residual pass against base grid + overlay
