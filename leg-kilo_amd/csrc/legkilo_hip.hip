@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
+#include "lk_prim.h"   // rocPRIM's sorts and scans, instantiated in lk_prim.hip
 
 #include "lk_device.h"
 #include "lk_filter_kernels.h"
@@ -1924,9 +1924,9 @@ int lk_map_build(lk_handle* h, const float* xyz_world, const float* xyz_body, si
     LAUNCH(h, "build_points", hipLaunchKernelGGL(lk_build_points_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, h->pr,
                                                  h->d_filters, d_w, d_b, (int)n, d_bpts, d_k0, d_i0));
     // stable sort by root id: groups each root's points, preserving input order (voxel_map.cc:313-332)
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
+    HIPCHK(h, lk_prim_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
     HIPCHK(h, tmp.alloc(&d_tmp, tmp_bytes));
-    HIPCHK(h, rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
+    HIPCHK(h, lk_prim_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_i0, d_i1, n, 0, 32, h->stream));
     LAUNCH(h, "build_segments",
            hipLaunchKernelGGL(lk_build_segments_kernel, dim3(nb), dim3(256), 0, h->stream, h->map, d_k1, (int)n));
     int grid = std::min(std::max((int)((n + 3) / 4), 1), 256);
@@ -2037,13 +2037,13 @@ static int clear_outside(lk_handle* h, const LkSlideBox& box, uint32_t* n_remove
     if (hc[1] == 0) return LK_OK;
     // dense new ids
     size_t t1 = 0, t2 = 0;
-    HIPCHK(h, rocprim::exclusive_scan(nullptr, t1, alive_node, new_node, 0u, n_nodes, rocprim::plus<unsigned int>(), h->stream));
-    HIPCHK(h, rocprim::exclusive_scan(nullptr, t2, alive_block, new_block, 0u, std::max(n_blocks, 1u), rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(nullptr, t1, alive_node, new_node, n_nodes, h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(nullptr, t2, alive_block, new_block, std::max(n_blocks, 1u), h->stream));
     void* tmp = sc.get(std::max(t1, t2));
     if (!tmp) return fail(h, LK_ERR_HIP, "map slide: out of device memory");
-    HIPCHK(h, rocprim::exclusive_scan(tmp, t1, alive_node, new_node, 0u, n_nodes, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(tmp, t1, alive_node, new_node, n_nodes, h->stream));
     if (n_blocks)
-        HIPCHK(h, rocprim::exclusive_scan(tmp, t2, alive_block, new_block, 0u, n_blocks, rocprim::plus<unsigned int>(), h->stream));
+        HIPCHK(h, lk_prim_exclusive_scan(tmp, t2, alive_block, new_block, n_blocks, h->stream));
     unsigned int last[4] = {0, 0, 0, 0};  // new_node[n-1], alive_node[n-1], new_block[n-1], alive_block[n-1]
     HIPCHK(h, hipMemcpyAsync(&last[0], new_node + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&last[1], alive_node + n_nodes - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
@@ -2892,8 +2892,8 @@ static int pre_reserve(lk_handle* h, size_t n) {
     HIPCHK(h, hipMalloc(&h->pre_v1, sizeof(int) * cap));
     HIPCHK(h, hipMalloc(&h->pre_starts, sizeof(int) * cap));
     size_t t1 = 0, t2 = 0;
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, t1, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, cap, 0, 32, h->stream));
-    HIPCHK(h, rocprim::exclusive_scan(nullptr, t2, h->pre_flags, h->pre_pos, 0u, cap, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_sort_pairs(nullptr, t1, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, cap, 0, 32, h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(nullptr, t2, h->pre_flags, h->pre_pos, cap, h->stream));
     h->pre_tmp_bytes = std::max(t1, t2);
     HIPCHK(h, hipMalloc(&h->pre_tmp, h->pre_tmp_bytes));
     h->pre_cap = cap;
@@ -2921,7 +2921,7 @@ int lk_decode_scan_dev(lk_handle* h, const void* d_msg, size_t n_points, const l
     LAUNCH(h, "decode_flags", hipLaunchKernelGGL(lk_decode_flags_kernel, dim3(nb), dim3(256), 0, h->stream,
                                                  (const unsigned char*)d_msg, n, a, h->pre_flags));
     size_t tb = h->pre_tmp_bytes;
-    HIPCHK(h, rocprim::exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, 0u, n_points, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, n_points, h->stream));
     LAUNCH(h, "decode_scatter", hipLaunchKernelGGL(lk_decode_scatter_kernel, dim3(nb), dim3(256), 0, h->stream,
                                                    (const unsigned char*)d_msg, n, a, h->pre_flags, h->pre_pos, d_out, n_out_d, fl));
     unsigned int cnt = 0;
@@ -2974,10 +2974,10 @@ int lk_preprocess_scan_dev(lk_handle* h, const lk_point* d_raw, size_t n_raw, fl
     LAUNCH(h, "pre_cellidx", hipLaunchKernelGGL(lk_pre_cellidx_kernel, dim3(nb), dim3(256), 0, h->stream, d_raw, n, inv, mm, h->pre_k0,
                                                 h->pre_v0, err));
     size_t tb = h->pre_tmp_bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, n_raw, 0, 32, h->stream));
+    HIPCHK(h, lk_prim_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, n_raw, 0, 32, h->stream));
     LAUNCH(h, "pre_heads", hipLaunchKernelGGL(lk_pre_heads_kernel, dim3(nb), dim3(256), 0, h->stream, h->pre_k1, n, h->pre_flags));
     tb = h->pre_tmp_bytes;
-    HIPCHK(h, rocprim::exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, 0u, n_raw, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(h->pre_tmp, tb, h->pre_flags, h->pre_pos, n_raw, h->stream));
     LAUNCH(h, "pre_starts", hipLaunchKernelGGL(lk_pre_starts_kernel, dim3(nb), dim3(256), 0, h->stream, h->pre_flags, h->pre_pos, n,
                                                h->pre_starts, ncells_d));
     LAUNCH(h, "pre_centroid", hipLaunchKernelGGL(lk_pre_centroid_kernel, dim3(nb), dim3(256), 0, h->stream, d_raw, h->pre_v1,
@@ -2988,7 +2988,7 @@ int lk_preprocess_scan_dev(lk_handle* h, const lk_point* d_raw, size_t n_raw, fl
     if (host_misc[0]) return fail(h, LK_ERR_INVALID, "voxel grid leaf too small for the cloud extent (index overflow)");
     const size_t nc = host_misc[1];
     tb = h->pre_tmp_bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, nc, 0, 32, h->stream));
+    HIPCHK(h, lk_prim_sort_pairs(h->pre_tmp, tb, h->pre_k0, h->pre_k1, h->pre_v0, h->pre_v1, nc, 0, 32, h->stream));
     LAUNCH(h, "pre_gather", hipLaunchKernelGGL(lk_pre_gather_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream,
                                                h->pre_cells, h->pre_v1, (int)nc, d_out));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3105,9 +3105,9 @@ int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_o
     hipLaunchKernelGGL(lk_sort_keys_kernel, dim3((unsigned int)((n_pts + 255) / 256), (unsigned int)n_scans), dim3(256), 0, h->stream, h->pr, h->d_filters, d_in, n_pts, k0, v0);
     HIPCHK(h, hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (unsigned int)total, (unsigned int)nseg, d_off, d_off + 1, 0, 30, h->stream));
+    HIPCHK(h, lk_prim_segmented_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (unsigned int)total, (unsigned int)nseg, d_off, d_off + 1, 0, 30, h->stream));
     HIPCHK(h, tmp.alloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(d_tmp, tmp_bytes, k0, k1, v0, v1, (unsigned int)total, (unsigned int)nseg, d_off, d_off + 1, 0, 30, h->stream));
+    HIPCHK(h, lk_prim_segmented_sort_pairs(d_tmp, tmp_bytes, k0, k1, v0, v1, (unsigned int)total, (unsigned int)nseg, d_off, d_off + 1, 0, 30, h->stream));
     hipLaunchKernelGGL(lk_sort_gather_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, h->stream, d_in, d_out, v1, total);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // offs and the temporaries go out of scope
@@ -3513,14 +3513,14 @@ int lk_batch_replay_scans_dev(lk_handle* h, const lk_point* d_pts, size_t n_scan
     const unsigned int nblk = (unsigned int)((n + 255) / 256);
     hipLaunchKernelGGL(lk_rag_flag_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl, d_st);
     size_t tmp_bytes = 0;
-    HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, d_fl, d_rk, 0u, n, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(nullptr, tmp_bytes, d_fl, d_rk, n, h->stream));
     if (tmp_bytes > h->ragtmp_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_ragtmp) hipFree(h->d_ragtmp), h->d_ragtmp = nullptr, h->ragtmp_cap = 0;
         HIPCHK(h, hipMalloc(&h->d_ragtmp, tmp_bytes));
         h->ragtmp_cap = tmp_bytes;
     }
-    HIPCHK(h, rocprim::exclusive_scan(h->d_ragtmp, tmp_bytes, d_fl, d_rk, 0u, n, rocprim::plus<unsigned int>(), h->stream));
+    HIPCHK(h, lk_prim_exclusive_scan(h->d_ragtmp, tmp_bytes, d_fl, d_rk, n, h->stream));
     hipLaunchKernelGGL(lk_rag_scatter_kernel, dim3(nblk), dim3(256), 0, h->stream, d_pts, (unsigned long long)n, d_so, (int)S, d_fl, d_rk, d_t0,
                        d_ps, d_tb, d_bs, d_st);
     hipLaunchKernelGGL(lk_rag_stats_kernel, dim3(nblk), dim3(256), 0, h->stream, d_ps, d_bs, (int)S, d_st);
