@@ -1005,22 +1005,46 @@ __global__ void __launch_bounds__(LK_MB)
 // A FEW workgroups for the whole batch.  The code needs 254 + 126 registers and 6.3 KB of scratch per lane, and a launch with a workgroup per
 // slot costs ~70 us whether or not a single item exists - on the bench's map none does in most buckets, and the recorded-run replay pays
 // that once per bucket LEVEL (360 of them: half of its time).  Every workgroup reads ALL slots' counters (one contiguous array: S / 256
-// coalesced loads per thread) and keeps the list of the slots that have items; the workgroups then share that list, a slot's items are
-// shared by the four waves of the workgroup that takes it.
+// coalesced loads per thread) and builds the list of the slots that have items - in slot order, so that it is the SAME list in every
+// workgroup -; the workgroups then split that list by position, a slot's items are shared by the four waves of the workgroup that takes it.
 #define LK_OV_FB_LIST 4096
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src, const int n_slots) {
     __shared__ int active[LK_OV_FB_LIST];
+    __shared__ unsigned int bits[LK_OV_FB_LIST / 32];
     __shared__ int n_active;
+    const int lane = (int)(threadIdx.x & 63);
     for (int s0 = 0; s0 < n_slots; s0 += LK_OV_FB_LIST) {   // (one round unless the batch has more than 4 096 slots)
         __syncthreads();
-        if (threadIdx.x == 0) n_active = 0;
+        if (threadIdx.x < LK_OV_FB_LIST / 32) bits[threadIdx.x] = 0u;
         __syncthreads();
         const int s1 = min(n_slots, s0 + LK_OV_FB_LIST);
         for (int s = s0 + (int)threadIdx.x; s < s1; s += LK_MB) {
             const unsigned int* c = ov.counters + (size_t)s * LK_CTR_COUNT;
             // (a slot whose pools overflowed: the call fails, nothing more is built on clamped ids)
-            if (c[LK_CTR_FALLBACK] != 0u && c[LK_CTR_ERR] == 0u) active[atomicAdd(&n_active, 1)] = s;
+            if (c[LK_CTR_FALLBACK] != 0u && c[LK_CTR_ERR] == 0u) atomicOr(&bits[(s - s0) >> 5], 1u << ((s - s0) & 31));
+        }
+        __syncthreads();
+        // the list in SLOT ORDER, the same in every workgroup (they split it among themselves by position): wave 0, two bitmap words per lane
+        if (threadIdx.x < LK_WAVE) {
+            unsigned int w0 = bits[2 * lane], w1 = bits[2 * lane + 1];
+            const int cnt = __popc(w0) + __popc(w1);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < LK_WAVE; o <<= 1) {
+                const int v = __shfl_up(incl, o, LK_WAVE);
+                if (lane >= o) incl += v;
+            }
+            int k = incl - cnt;
+            while (w0) {
+                active[k++] = s0 + 64 * lane + (__ffs((int)w0) - 1);
+                w0 &= w0 - 1u;
+            }
+            while (w1) {
+                active[k++] = s0 + 64 * lane + 32 + (__ffs((int)w1) - 1);
+                w1 &= w1 - 1u;
+            }
+            if (lane == LK_WAVE - 1) n_active = incl;
         }
         __syncthreads();
         const int na = n_active;
