@@ -22,7 +22,14 @@
 
 #include "legkilo_hip.h"
 
-namespace legkilo {
+// The mirror lives in namespace legkilo, like the classes it stands in for.  Inside the reference's own tree that namespace already
+// holds the Eigen typedefs of common/eigen_types.hpp (Vec3D, Mat3D, ...): there legkilo_host_eigen.hpp includes this header under
+// another name (LEGKILO_HOST_NAMESPACE = legkilo_hip) and puts Eigen-typed classes with the reference's names on top of it.
+#ifndef LEGKILO_HOST_NAMESPACE
+#define LEGKILO_HOST_NAMESPACE legkilo
+#endif
+
+namespace LEGKILO_HOST_NAMESPACE {
 
 constexpr int DIM_STATE = LK_DIM_STATE;
 using Vec3D = std::array<double, 3>;
@@ -486,4 +493,4 @@ class KiloPath {
     std::unique_ptr<VoxelMapManager> map_manager_;
 };
 
-}  // namespace legkilo
+}  // namespace LEGKILO_HOST_NAMESPACE
