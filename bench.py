@@ -57,6 +57,8 @@ PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X datasheet: peak fp64 vector = fp64 matrix = 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 row; 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6)
 COMPULSORY_BYTES_PER_POINT = 20   # what HBM must carry per point of the batch residual pass: 16 B scan point + 4 B of its tile's partial record
 OV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_overlay_pmc.json")
+C2_PMC_FILE = os.path.join(ROOT, "profiles", "latest_config2_pmc.json")
+C2_BYTES_PER_POINT = 81    # config 2 with the rows materialised: 16 B scan point in + h6 48 + z 8 + R 8 + valid 1 out ("+64 B/pt if h/z/R rows are materialised")
 OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_point_geom", "ov_root_lane", "ov_insert_root", "ov_fit_eig", "ov_fit_lane",
               "ov_insert_apply", "ov_insert_fallback")
 OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
@@ -236,6 +238,9 @@ def main():
     ap.add_argument("--shuffle-main", action="store_true", help="profiling aid: the MAIN timed loop runs on the batch with a random permutation inside every bucket "
                     "(tools/gpu_prof_shuffled.sh collects the residual kernel's counters for that order -> profiles/latest_shuffled_pmc.json); the line says so")
     ap.add_argument("--overlay-scans", type=int, default=1024, help="scans of the batch replayed WITH the map insert (per-scan overlay, extra.overlay_*; 0 = skip)")
+    ap.add_argument("--config2-scans", type=int, default=256, help="extra.config2_*: scans of the batch whose residual ROWS are materialised in HBM in one launch (BASELINE config 2 "
+                    "at bandwidth size: lk_batch_residuals_dev; 0 = skip)")
+    ap.add_argument("--config2-check", type=int, default=4, help="of those, scans whose rows the oracle's residual build checks (valid mask, h / z / R)")
     ap.add_argument("--overlay-check", type=int, default=24, help="of those, scans the oracle replays (insert on, private copy of the map) for extra.overlay_parity")
     ap.add_argument("--max-roots-log2", type=int, default=15, help="root-voxel capacity (hash table = 8x, 16 B/slot)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (slot ranges / streams they rotate over: 2 or 3; 3 gains 2 % in steady state - 1.753 vs 1.789 ms at 60 steps - and loses it to the longer drain of a 20-step region)")
@@ -712,6 +717,78 @@ def main():
             extra["overlay_error"] = f"{type(e).__name__}: {str(e)[:300]}"
             warnings.append("overlay replay failed: " + extra["overlay_error"])
 
+    # ---- extra: BASELINE config 2 ("100k-pt scan, voxel kNN + point-to-plane residuals only vs CPU") at bandwidth size: the residual build
+    # of KILO.cc:122-210 for S2 x 100 000 points in ONE launch, every scan under its prior state, rows h (1x6) / z / R / valid MATERIALISED in
+    # HBM (lk_batch_residuals_dev).  This is the one place SURVEY 8(d)'s HBM roofline applies as written: 16 B in + 65 B out per point.
+    c2 = None
+    S2 = min(args.config2_scans, S) if (rank == 0 and world_size == 1) else 0
+    if S2 > 0:
+        try:
+            N2 = S2 * N_PTS
+            d_h6 = torch.empty((N2, 6), dtype=torch.float64, device=dev)
+            d_z = torch.empty(N2, dtype=torch.float64, device=dev)
+            d_R = torch.empty(N2, dtype=torch.float64, device=dev)
+            d_v = torch.empty(N2, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+
+            def run_c2():
+                g.batch_residuals_dev(d_batch.data_ptr(), S2, N_PTS, d_h6.data_ptr(), d_z.data_ptr(), d_R.data_ptr(), d_v.data_ptr())
+
+            g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S2)
+            for _ in range(3):
+                run_c2()
+            g.synchronize()
+            K2 = 10
+            ts = time.perf_counter()
+            for _ in range(K2):
+                run_c2()
+            g.synchronize()
+            t_c2 = (time.perf_counter() - ts) / K2
+            g.profile_reset()
+            g.profile_enable(1)     # HIP events around the launch, on the handle's stream
+            for _ in range(5):
+                run_c2()
+            g.profile_enable(0)
+            n_ev, ms_ev = g.profile_get("residual_rows")
+            ev_ms = ms_ev / max(n_ev, 1)
+            n_chk2 = min(args.config2_check, S2)
+            c2 = (d_h6[:n_chk2 * N_PTS].cpu().numpy(), d_z[:n_chk2 * N_PTS].cpu().numpy(), d_R[:n_chk2 * N_PTS].cpu().numpy(), d_v[:n_chk2 * N_PTS].cpu().numpy())
+            matched = float(d_v.to(torch.float32).mean().item())
+            del d_h6, d_z, d_R, d_v
+            c2pmc = None
+            if os.path.exists(C2_PMC_FILE):
+                c2pmc = json.load(open(C2_PMC_FILE))
+                if c2pmc.get("kernel_sources_sha16") != kernel_sources_sha16():
+                    warnings.append(f"config-2 counters (profiles/latest_config2_pmc.json, tag {c2pmc.get('tag')}) were collected on a different version of "
+                                    f"{', '.join(KERNEL_SOURCES)}: re-run tools/gpu_prof_config2.sh")
+            else:
+                warnings.append("profiles/latest_config2_pmc.json missing: extra.config2_roofline has no counter-derived traffic (tools/gpu_prof_config2.sh)")
+            hbm2 = c2pmc.get("hbm_bytes_per_point") if c2pmc else None
+            extra["config2_scans"] = S2
+            extra["config2_points_per_launch"] = N2
+            extra["config2_ms_per_launch"] = round(t_c2 * 1e3, 4)
+            extra["config2_ps_per_point"] = round(t_c2 * 1e12 / N2, 2)
+            extra["config2_scans_per_s"] = round(S2 / t_c2, 1)
+            extra["config2_matched_fraction"] = round(matched, 4)
+            extra["config2_roofline"] = {
+                "kernel": "lk_residual_kernel<true> (rows emitted)", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "launch_ms_events": round(ev_ms, 4), "launch_ms_wall": round(t_c2 * 1e3, 4), "launches_event_pass": n_ev,
+                "alg_bytes_per_point": C2_BYTES_PER_POINT, "achieved": round(C2_BYTES_PER_POINT * N2 / (ev_ms * 1e-3) / 1e9, 1),
+                "frac": round(C2_BYTES_PER_POINT * N2 / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_of_copy_ceiling": round(C2_BYTES_PER_POINT * N2 / (ev_ms * 1e-3) / 1e9 / HBM_COPY_CEILING_GBS, 4),
+                "traffic": None if hbm2 is None else round(hbm2 * N2),
+                "hbm_bytes_per_point_counters": hbm2,
+                "achieved_counters_GBs": None if hbm2 is None else round(hbm2 * N2 / (ev_ms * 1e-3) / 1e9, 1),
+                "frac_counters": None if hbm2 is None else round(hbm2 * N2 / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic_over_algorithmic": None if hbm2 is None else round(hbm2 / C2_BYTES_PER_POINT, 3),
+                "pmc_source": None if not c2pmc else f"profiles/latest_config2_pmc.json (tag {c2pmc.get('tag')}, commit {c2pmc.get('commit')}, {c2pmc.get('slots')} slots)",
+                "valu_insts_per_wave": c2pmc.get("valu_insts_per_wave") if c2pmc else None,
+                "wait_any_frac_of_wave_cycles": c2pmc.get("wait_any_frac_of_wave_cycles") if c2pmc else None,
+            }
+        except Exception as e:  # noqa: BLE001
+            extra["config2_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+            warnings.append("config-2 rows launch failed: " + extra["config2_error"])
+
     extra["ramp_steps_before_warmup"] = args.ramp_steps
     extra.update({"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
                   "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok, "rccl_map_broadcast_ms": bcast_ms,
@@ -905,6 +982,31 @@ def main():
         parity = {"n": n_chk, "compared_with": "poses of the last timed step, same slots, same map (device blob imported into the oracle)",
                   "counts_equal": cnt_eq, "max_pos_delta_m": d_pos, "max_rot_delta": d_rot, "tolerance_m": 1e-7,
                   "ok": bool(d_pos <= 1e-7 and d_rot <= 1e-7 and cnt_eq >= n_chk - max(1, n_chk // 50)), "worst_slot": worst}
+        if c2 is not None:   # config 2: the oracle's residual build (KILO.cc:122-210) on the same scans under the same states, rows compared
+            h6d, zd, Rd, vd = c2
+            n_c2 = len(vd) // N_PTS
+            t2s, c2_flips, c2_dh, c2_dz, c2_dR, c2_ok = [], 0, 0.0, 0.0, 0.0, True
+            for s in range(n_c2):
+                a_, b_ = s * N_PTS, (s + 1) * N_PTS
+                xb_ = xyz_of(scans[tile[s]])
+                o.set_state(xs[s], Ps[s])
+                tc = time.perf_counter()
+                ho, zo, Ro, vo = o.residuals(xb_)
+                t2s.append(time.perf_counter() - tc)
+                c2_flips += int((vo != vd[a_:b_]).sum())
+                m = (vo & vd[a_:b_]).astype(bool)
+                sg = np.sign(np.sum(h6d[a_:b_][m, 3:] * ho[m, 3:], axis=1))     # rows are defined up to the sign of the plane normal
+                c2_dh = max(c2_dh, float(np.abs(h6d[a_:b_][m] - ho[m] * sg[:, None]).max()))
+                c2_dz = max(c2_dz, float(np.abs(zd[a_:b_][m] - zo[m] * sg).max()))
+                c2_dR = max(c2_dR, float(np.abs(Rd[a_:b_][m] / Ro[m] - 1.0).max()))
+            # the allowance of test_config2_full_size_residuals: a point whose 3-sigma gate sits within rounding of its threshold may flip
+            c2_ok = bool(c2_flips <= n_c2 and c2_dh <= 1e-8 and c2_dz <= 1e-7 and c2_dR <= 1e-7)
+            parity["config2_rows"] = {"n_scans": n_c2, "points": n_c2 * N_PTS, "valid_mask_flips": c2_flips, "max_abs_dh": c2_dh, "max_abs_dz": c2_dz,
+                                      "max_rel_dR": c2_dR, "ok": c2_ok, "checker": "oracle.residuals (KILO.cc:122-210) per scan on the device's map blob, same state"}
+            parity["ok"] = bool(parity["ok"] and c2_ok)
+            extra["config2_cpu_port_scans_per_s"] = round(1.0 / float(np.median(t2s)), 2)
+            extra["config2_cpu_port_ns_per_point"] = round(float(np.median(t2s)) * 1e9 / N_PTS, 1)
+            extra["config2_speedup_vs_cpu_port"] = round(extra["config2_scans_per_s"] / extra["config2_cpu_port_scans_per_s"], 1)
         if c1 is not None:   # the same config-1 scans on the CPU port, one at a time (frozen map), and the same comparison
             c1_scans_, c1_tb_, xs1, Ps1, tile1, p1, p1ov = c1
             t1s, c1_dpos, c1_eq = [], 0.0, 0

@@ -308,6 +308,13 @@ int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_o
                                size_t n_buckets);
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
+/* Config 2 ("voxel kNN + point-to-plane residuals only") for a device-resident batch: the residual build of KILO.cc:122-210 for
+ * n_scans x n_pts points in one launch, scan s (layout of lk_batch_replay_dev) under the CURRENT state of filter slot s (lk_batch_set_priors(_dev);
+ * no predict, no update, no insert), with the rows MATERIALISED in HBM exactly as lk_residuals returns them: d_h6 [n_scans * n_pts][6]
+ * row-major, d_z, d_R, d_valid (0 / 1) - rows of unmatched points are zero.  16 B read + 65 B written per point.  Asynchronous on the
+ * handle's stream (lk_synchronize). */
+int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_h6, double* d_z, double* d_R,
+                           uint8_t* d_valid);
 /* Bulk read-out of the filters a batch replay left in slots [first_slot, first_slot + n): state (n x 36: rot 9, pos, vel, ba, bw,
  * grav, imu_a, imu_w, bv, contact) and covariance (n x 900, row-major) - what ESKF::state() / cov() and getRotCov / getPosCov /
  * getVelCov (blocks (0,0), (3,3), (6,6) of P, eskf.h:46-109) give per filter, for all of them with ONE gather kernel instead of one

@@ -3257,6 +3257,34 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     return LK_OK;
 }
 
+// Config 2 at bandwidth size: the residual build of KILO.cc:122-210 - transform, covariance terms, voxel lookup, plane match with the one
+// neighbour retry, observation row - for n_scans x n_pts points in ONE launch, scan s under the CURRENT state of filter slot s (no predict,
+// no update, no insert), rows MATERIALISED in HBM the way lk_residuals hands them to the host: h6 (n x 6 row-major), z, R, valid.
+// 16 B in + 65 B out per point; the map side is the frozen-map grid of the batch replay (L2 / Infinity-Cache resident).
+int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_h6, double* d_z, double* d_R, uint8_t* d_valid) {
+    CHECK_H(h);
+    if (!d_pts || !d_h6 || !d_z || !d_R || !d_valid) return fail(h, LK_ERR_INVALID, "null argument");
+    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
+    if (n_pts == 0) return fail(h, LK_ERR_INVALID, "empty scans");
+    if (n_pts > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n_pts exceeds max_scan_points");
+    LkMap fmap;
+    int rc = frozen_map(h, &fmap);
+    if (rc) return rc;
+    rc = join_side_streams(h);
+    if (rc) return rc;
+    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
+    const ResidualKernelFn k = !fmap.grid_on ? lk_residual_kernel<true, 0, false>
+                                             : ((h->pr.ext_identity && xid_enable) ? lk_residual_kernel<true, 1, true> : lk_residual_kernel<true, 1, false>);
+    ResidualOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.h6 = d_h6, ro.z = d_z, ro.R = d_R, ro.valid = d_valid;
+    const int nblk = (int)((n_pts + LK_RB - 1) / LK_RB);
+    LAUNCH(h, "residual_rows", hipLaunchKernelGGL(k, dim3(nblk, (unsigned int)n_scans), dim3(LK_RB), 0, h->stream, fmap, h->pr, h->d_filters, d_pts, n_pts, (int)n_pts,
+                                                  h->d_partials, h->part_stride, ro, n_pts));
+    HIPCHK(h, hipGetLastError());
+    return LK_OK;
+}
+
 // The launches of a ragged batch once its tables (padded or CSR, LkRagged) are in HBM.  msg_kind: 0 none, 1 lk_imu, 2 lk_kin_imu.
 // max_n: largest bucket of every bucket index (null: `biggest` for all of them).
 static int ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,

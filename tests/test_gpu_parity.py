@@ -850,6 +850,63 @@ def test_config2_full_size_residuals(big, hip_lib):
     g2.close()
 
 
+def test_config2_batch_rows_resident(big, oracle_lib, hip_lib):
+    """Config 2 for a device-resident batch (lk_batch_residuals_dev): 12 slots x 100 000 points, every slot under its own state, rows
+    materialised in HBM - against the oracle's residual build per slot on the DEVICE's map blob (valid mask exact up to a named
+    rounding-level gate flip, rows 1e-9), and against the host entry lk_residuals on the same points (identical bits: the same tile code)."""
+    scene, o_big, _, t0 = big
+    S, U, n_pts = 12, 4, 100000
+    g = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    g.map_import(o_big.map_export())
+    g.init_process_cov_q()
+    o = oracle_lib.Oracle(scene.cfg(), imu_mode_only=True)
+    o.init_process_cov_q()
+    o.map_import(g.map_export())
+    rng = np.random.default_rng(2202)
+    tbs = [t0 + 0.7 + 0.21 * u for u in range(U)]
+    scans = [synth.dense_scan(scene.world, scenes.Frozen(scene.traj, tbs[u]), tbs[u], scene.P, n=n_pts, n_buckets=1, seed_scan=2302 + u) for u in range(U)]
+    tile = np.arange(S) % U
+    xs = np.stack([synth.initial_state(scene.traj, tbs[tile[s]], scene.P, rng, 0.02, 0.5) for s in range(S)])
+    Ps = np.tile((1e-4 * np.eye(30)).reshape(1, 900), (S, 1))
+    allpts = np.concatenate([scans[u] for u in tile])
+    N = S * n_pts
+    d_pts = g.device_malloc(allpts.nbytes)
+    d_h6, d_z, d_R, d_v = g.device_malloc(N * 48), g.device_malloc(N * 8), g.device_malloc(N * 8), g.device_malloc(N)
+    g.h2d(d_pts, allpts)
+    g.batch_set_priors(xs, Ps)
+    g.batch_residuals_dev(d_pts, S, n_pts, d_h6, d_z, d_R, d_v)
+    g.synchronize()
+    h6, z, R, v = np.zeros((N, 6)), np.zeros(N), np.zeros(N), np.zeros(N, dtype=np.uint8)
+    for dst, src in ((h6, d_h6), (z, d_z), (R, d_R), (v, d_v)):
+        g.d2h(dst, src)
+    n_flips = 0
+    for s in range(S):
+        a, b = s * n_pts, (s + 1) * n_pts
+        xb = scenes.xyz_of(scans[tile[s]])
+        o.set_state(xs[s], Ps[s].reshape(30, 30))
+        ho, zo, Ro, vo = o.residuals(xb)
+        assert vo.sum() > 20000
+        flips = np.flatnonzero(vo != v[a:b])
+        for i in flips:
+            _, marg = o.residual_margins(xb[i])
+            print(f"config2 batch flip: slot {s} point {int(i)} oracle valid {int(vo[i])} hip valid {int(v[a + i])} margins range/sigma/key {marg}")
+            assert min(marg[0], marg[1]) < 1e-9 or marg[2] < 1e-9, (s, int(i), marg)
+        n_flips += len(flips)
+        scenes.rows_close(h6[a:b], z[a:b], R[a:b], ho, zo, Ro, (vo & v[a:b]).astype(np.uint8), rtol=1e-9)
+        unm = v[a:b] == 0
+        assert not h6[a:b][unm].any() and not z[a:b][unm].any() and not R[a:b][unm].any()   # rows of unmatched points are zero
+        if s < 2:   # the host entry on slot 0's state: same tile code, same bits
+            g.set_state(xs[s], Ps[s].reshape(30, 30), slot=0)
+            hh, zh, Rh, vh = g.residuals(xb)
+            assert np.array_equal(vh, v[a:b]) and np.array_equal(hh, h6[a:b]) and np.array_equal(zh, z[a:b]) and np.array_equal(Rh, R[a:b])
+            g.batch_set_priors(xs, Ps)
+    assert n_flips <= 2, n_flips
+    for d in (d_pts, d_h6, d_z, d_R, d_v):
+        g.device_free(d)
+    g.close()
+    o.close()
+
+
 # ----------------------------------------------------------------------------- batch replay (config 5, reduced)
 def test_batch_sort_by_voxel(scene, oracle_lib, hip_lib):
     """lk_batch_sort_by_voxel_dev: every time bucket of every scan of a device-resident batch put into root-voxel order under the slots' prior
