@@ -725,14 +725,12 @@ def main():
     if S2 > 0:
         try:
             N2 = S2 * N_PTS
-            d_h6 = torch.empty((N2, 6), dtype=torch.float64, device=dev)
-            d_z = torch.empty(N2, dtype=torch.float64, device=dev)
-            d_R = torch.empty(N2, dtype=torch.float64, device=dev)
+            d_rows = torch.empty((N2, 8), dtype=torch.float64, device=dev)   # per point: h (1 x 6), z, R
             d_v = torch.empty(N2, dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
 
             def run_c2():
-                g.batch_residuals_dev(d_batch.data_ptr(), S2, N_PTS, d_h6.data_ptr(), d_z.data_ptr(), d_R.data_ptr(), d_v.data_ptr())
+                g.batch_residuals_dev(d_batch.data_ptr(), S2, N_PTS, d_rows.data_ptr(), d_v.data_ptr())
 
             g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S2)
             for _ in range(3):
@@ -752,9 +750,10 @@ def main():
             n_ev, ms_ev = g.profile_get("residual_rows")
             ev_ms = ms_ev / max(n_ev, 1)
             n_chk2 = min(args.config2_check, S2)
-            c2 = (d_h6[:n_chk2 * N_PTS].cpu().numpy(), d_z[:n_chk2 * N_PTS].cpu().numpy(), d_R[:n_chk2 * N_PTS].cpu().numpy(), d_v[:n_chk2 * N_PTS].cpu().numpy())
+            r8 = d_rows[:n_chk2 * N_PTS].cpu().numpy()
+            c2 = (np.ascontiguousarray(r8[:, :6]), np.ascontiguousarray(r8[:, 6]), np.ascontiguousarray(r8[:, 7]), d_v[:n_chk2 * N_PTS].cpu().numpy())
             matched = float(d_v.to(torch.float32).mean().item())
-            del d_h6, d_z, d_R, d_v
+            del d_rows, d_v, r8
             c2pmc = None
             if os.path.exists(C2_PMC_FILE):
                 c2pmc = json.load(open(C2_PMC_FILE))

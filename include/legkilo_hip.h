@@ -310,11 +310,11 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                         const uint32_t* bucket_off, const double* bucket_dt, size_t n_buckets, lk_pose* out);
 /* Config 2 ("voxel kNN + point-to-plane residuals only") for a device-resident batch: the residual build of KILO.cc:122-210 for
  * n_scans x n_pts points in one launch, scan s (layout of lk_batch_replay_dev) under the CURRENT state of filter slot s (lk_batch_set_priors(_dev);
- * no predict, no update, no insert), with the rows MATERIALISED in HBM exactly as lk_residuals returns them: d_h6 [n_scans * n_pts][6]
- * row-major, d_z, d_R, d_valid (0 / 1) - rows of unmatched points are zero.  16 B read + 65 B written per point.  Asynchronous on the
- * handle's stream (lk_synchronize). */
-int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_h6, double* d_z, double* d_R,
-                           uint8_t* d_valid);
+ * no predict, no update, no insert), with the rows MATERIALISED in HBM: d_rows8 [n_scans * n_pts][8] = one 64-byte record per point holding what
+ * lk_residuals returns in three arrays - h (1 x 6, KILO.cc:195-197), z (KILO.cc:199), R (KILO.cc:208-209) - and d_valid (0 / 1, the point
+ * matched a plane).  Records of unmatched points are zero.  16 B read + 65 B written per point.  d_rows8 must be 16-byte aligned.
+ * Asynchronous on the handle's stream (lk_synchronize). */
+int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_rows8, uint8_t* d_valid);
 /* Bulk read-out of the filters a batch replay left in slots [first_slot, first_slot + n): state (n x 36: rot 9, pos, vel, ba, bw,
  * grav, imu_a, imu_w, bv, contact) and covariance (n x 900, row-major) - what ESKF::state() / cov() and getRotCov / getPosCov /
  * getVelCov (blocks (0,0), (3,3), (6,6) of P, eskf.h:46-109) give per filter, for all of them with ONE gather kernel instead of one

@@ -335,11 +335,10 @@ class LegKiloHip:
                                              C.c_double(t_begin), _p(off), _p(dt), C.c_size_t(len(dt)), poses))
         return poses
 
-    def batch_residuals_dev(self, d_pts, n_scans, n_pts, d_h6, d_z, d_R, d_valid):
+    def batch_residuals_dev(self, d_pts, n_scans, n_pts, d_rows8, d_valid):
         """Config 2 for a device-resident batch (lk_batch_residuals_dev): residual rows of n_scans x n_pts points, scan s under the current state of
-        slot s, written to the device buffers d_h6 [n][6], d_z, d_R (float64) and d_valid (uint8).  Asynchronous on the handle's stream."""
-        self._chk(self.L.lk_batch_residuals_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts), C.c_void_p(d_h6), C.c_void_p(d_z),
-                                                C.c_void_p(d_R), C.c_void_p(d_valid)))
+        slot s, written to the device buffers d_rows8 [n][8] float64 = (h0..h5, z, R) per point and d_valid (uint8).  Asynchronous on the handle's stream."""
+        self._chk(self.L.lk_batch_residuals_dev(self.h, C.c_void_p(d_pts), C.c_size_t(n_scans), C.c_size_t(n_pts), C.c_void_p(d_rows8), C.c_void_p(d_valid)))
 
     def batch_sort_by_voxel_dev(self, d_in, d_out, n_scans, n_pts, bucket_off):
         """Every bucket of every scan of a device-resident batch into root-voxel order under the slots' prior poses (lk_batch_sort_by_voxel_dev):

@@ -1806,6 +1806,18 @@ static ResidualKernelFn batch_residual_kernel(const lk_handle* h, const LkMap& f
     return (h->pr.ext_identity && xid_enable) ? lk_residual_kernel<false, 1, true> : lk_residual_kernel<false, 1, false>;
 }
 
+// Grid of a batch residual launch over `sn` slots x `nblk` tiles: plain 2-D grid (tile, slot); LEGKILO_XCDMAP=1: the XCD-aware 1-D grid of ResidualOut::xmap_slots (A/B)
+static dim3 batch_residual_grid(int nblk, int sn, ResidualOut* ro) {
+    static const bool xmap = getenv("LEGKILO_XCDMAP") != nullptr && atoi(getenv("LEGKILO_XCDMAP")) != 0;   // measured slower (EXPERIMENTS.md, round 6): off unless asked for
+    const unsigned long long wg = 8ull * (unsigned long long)((nblk + 7) / 8) * (unsigned long long)sn;
+    if (!xmap || sn < 2 || nblk < 16 || wg >= (1ull << 31)) {
+        ro->xmap_slots = 0;
+        return dim3(nblk, sn);
+    }
+    ro->xmap_slots = sn;
+    return dim3((unsigned int)wg);
+}
+
 __global__ void lk_zero_scan_counters_kernel(LkFilter* filters, unsigned int n_slots) {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
@@ -3215,7 +3227,8 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                     else
                         LAUNCH(h, "predict", hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t));
                 }
-                LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, sn), dim3(LK_RB), 0, st, fmap, h->pr, fl,
+                const dim3 rgrid = batch_residual_grid(nblk, sn, &ro);
+                LAUNCH(h, "residual", hipLaunchKernelGGL(res_kernel, rgrid, dim3(LK_RB), 0, st, fmap, h->pr, fl,
                                                          pts, n_pts, nb, parts, h->part_stride, ro, (size_t)0));
                 if (h->wave_update)
                     LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts,
@@ -3230,7 +3243,8 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
                     else
                         hipLaunchKernelGGL(lk_predict_kernel, dim3(sn), dim3(LK_FB), 0, st, fl, h->d_Q, t);
                 }
-                hipLaunchKernelGGL(res_kernel, dim3(nblk, sn), dim3(LK_RB), 0, st, fmap, h->pr, fl, pts, n_pts, nb, parts,
+                const dim3 rgrid = batch_residual_grid(nblk, sn, &ro);
+                hipLaunchKernelGGL(res_kernel, rgrid, dim3(LK_RB), 0, st, fmap, h->pr, fl, pts, n_pts, nb, parts,
                                    h->part_stride, ro, (size_t)0);
                 if (h->wave_update)
                     hipLaunchKernelGGL(lk_update_wave_kernel, dim3(sn), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE),
@@ -3259,11 +3273,12 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
 
 // Config 2 at bandwidth size: the residual build of KILO.cc:122-210 - transform, covariance terms, voxel lookup, plane match with the one
 // neighbour retry, observation row - for n_scans x n_pts points in ONE launch, scan s under the CURRENT state of filter slot s (no predict,
-// no update, no insert), rows MATERIALISED in HBM the way lk_residuals hands them to the host: h6 (n x 6 row-major), z, R, valid.
+// no update, no insert), rows MATERIALISED in HBM: one 64-B record [h(6) z R] per point + the valid byte lk_residuals returns.
 // 16 B in + 65 B out per point; the map side is the frozen-map grid of the batch replay (L2 / Infinity-Cache resident).
-int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_h6, double* d_z, double* d_R, uint8_t* d_valid) {
+int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double* d_rows8, uint8_t* d_valid) {
     CHECK_H(h);
-    if (!d_pts || !d_h6 || !d_z || !d_R || !d_valid) return fail(h, LK_ERR_INVALID, "null argument");
+    if (!d_pts || !d_rows8 || !d_valid) return fail(h, LK_ERR_INVALID, "null argument");
+    if (((uintptr_t)d_rows8 & 15u) != 0) return fail(h, LK_ERR_INVALID, "d_rows8 must be 16-byte aligned");
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (n_pts == 0) return fail(h, LK_ERR_INVALID, "empty scans");
     if (n_pts > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "n_pts exceeds max_scan_points");
@@ -3277,9 +3292,10 @@ int lk_batch_residuals_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, 
                                              : ((h->pr.ext_identity && xid_enable) ? lk_residual_kernel<true, 1, true> : lk_residual_kernel<true, 1, false>);
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
-    ro.h6 = d_h6, ro.z = d_z, ro.R = d_R, ro.valid = d_valid;
+    ro.rows8 = d_rows8, ro.valid = d_valid;
     const int nblk = (int)((n_pts + LK_RB - 1) / LK_RB);
-    LAUNCH(h, "residual_rows", hipLaunchKernelGGL(k, dim3(nblk, (unsigned int)n_scans), dim3(LK_RB), 0, h->stream, fmap, h->pr, h->d_filters, d_pts, n_pts, (int)n_pts,
+    const dim3 rgrid = batch_residual_grid(nblk, (int)n_scans, &ro);
+    LAUNCH(h, "residual_rows", hipLaunchKernelGGL(k, rgrid, dim3(LK_RB), 0, h->stream, fmap, h->pr, h->d_filters, d_pts, n_pts, (int)n_pts,
                                                   h->d_partials, h->part_stride, ro, n_pts));
     HIPCHK(h, hipGetLastError());
     return LK_OK;
@@ -3648,7 +3664,8 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
         }
         first = false;
         const auto res_kernel = batch_residual_kernel(h, fmap);
-        hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts + bucket_off[b], n_pts, nb, parts,
+        const dim3 rgrid = batch_residual_grid(nblk, S, &ro);
+        hipLaunchKernelGGL(res_kernel, rgrid, dim3(LK_RB), 0, st, fmap, h->pr, fl, d_pts + bucket_off[b], n_pts, nb, parts,
                            h->part_stride, ro, (size_t)0);
         if (h->wave_update)
             hipLaunchKernelGGL(lk_update_wave_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t,

@@ -16,6 +16,17 @@
 #include "lk_device.h"
 
 #define LK_PB 256
+#ifndef LK_PTS_NT
+#define LK_PTS_NT 1    // the 16-B scan point with a non-temporal load (round 6: 1.560 -> 1.537 ms per step, same bits; A/B: -DLK_PTS_NT=0)
+#endif
+#ifndef LK_ROWS_NT
+#define LK_ROWS_NT 1   // config 2's materialised rows leave with non-temporal stores (A/B: -DLK_ROWS_NT=0)
+#endif
+#if LK_ROWS_NT
+#define LK_ROWS_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define LK_ROWS_STORE(v, p) (*(p) = (v))
+#endif
 #ifndef LK_ROWS_AT_TAKE
 #define LK_ROWS_AT_TAKE 1   // a matched lane writes its final LDS row [h z | h/R | R 1] when it takes its plane: no LDS read-back before K3
                             // (0 = park the raw row and finish it after the matching; A/B: 1.798 -> 1.775 ms per step, same bits)
@@ -315,12 +326,19 @@ __device__ __forceinline__ void neighbour_key(const LkParams& pr, const float* l
 
 struct ResidualOut {       // optional per-point outputs (config 2 / lk_residuals); any may be null
     double* h6;            // n x 6 row-major
+    double* rows8 = nullptr;   // instead of h6 / z / R: n packed records [h(6) z R] of 64 B (lk_batch_residuals_dev)
     double* z;
     double* R;
     unsigned char* valid;
     float* world;          // n x 4 (x y z intensity), cloud_down_world
     int2* ids;             // SPEC instantiations only: per point {home, neighbour} root code of the lookups (spec_code)
     int2* ids_lane = nullptr;   // SPEC: if set, THIS lane's codes go here (a register of the caller) instead of ids[] - a one-tile bucket's checker is the same wave
+    // lk_residual_kernel only.  > 0: XCD-aware launch of a BATCH - a 1-D grid of 8 x ceil(tiles / 8) x xmap_slots workgroups.  Workgroups go to the
+    // eight XCDs round robin by their linear id (MI355X_MICROARCH.md), so workgroup L runs on XCD L % 8 and is the (L / 8)-th workgroup there: it takes
+    // tile (L % 8) * c + (L / 8) % c of scan (L / 8) / c, c = ceil(tiles / 8).  Every XCD then sees the SAME eighth of every scan's bucket - and a
+    // bucket comes in voxel order (pcl::VoxelGrid's output order, or lk_batch_sort_by_voxel_dev's), so that eighth is one slab of the map: the
+    // plane records an XCD's 4 MB L2 has to hold are an eighth of the map's instead of all of them.  0: the plain 2-D grid (tile, slot).
+    int xmap_slots = 0;
 };
 // What a speculative residual pass (the pipelined stream path) remembers of a point's two root lookups, so that the verify pass
 // can tell whether an insert that ran beside it may have changed the point's result: a root id (>= 0), or - the lookup found no
@@ -362,7 +380,12 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         PointLite g;
         int root = -1, nroot = -1;
         if (i < n) {
+#if LK_PTS_NT
+            typedef float lk_f4v __attribute__((ext_vector_type(4)));
+            const lk_f4v p = __builtin_nontemporal_load(reinterpret_cast<const lk_f4v*>(spts) + i);   // read once: keep it from displacing plane records in L2
+#else
             const float4 p = spts[i];
+#endif
             g = point_lite<XID>(p.x, p.y, p.z, bc, pr);
             if (out.world) {
                 float4 w = make_float4((float)g.p_w.x, (float)g.p_w.y, (float)g.p_w.z, 0.f);
@@ -412,13 +435,7 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
         }
         ok = success;
 #if LK_ROWS_AT_TAKE
-        if (EMIT_ROWS && ok) {
-            const double* r = best.row;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) h[a] = r[a];
-            z = r[6];
-            R = r[13];
-        }
+        // (EMIT_ROWS: the rows go to HBM from the wave's LDS region behind the wave barrier below - whole 16-B pieces, consecutive lanes)
 #else
         if (ok) {  // KILO.cc:195-209: h (1x6), z, R for the matched point, from the parked row
             const double* r = best.row;
@@ -428,14 +445,6 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
             R = pr.lidar_ratio * r[13];  // (R ext_R) body_cov (R ext_R)^T only, no state covariance (KILO.cc:205-206)
         }
 #endif
-        if (EMIT_ROWS && i < n) {
-            size_t o = out_base + i;
-            out.valid[o] = ok ? 1 : 0;
-            out.z[o] = z;
-            out.R[o] = R;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) out.h6[o * 6 + a] = h[a];
-        }
     }
     // K3, per wave and without any block barrier.  Every lane stores its row [h(6) z | h(6)/R | R valid] (zeros when
     // it did not match) in the wave's LDS region; lane (q = lane & 31, half = lane >> 5) then accumulates component q
@@ -464,6 +473,49 @@ __device__ __forceinline__ double residual_tile(const LkMap& map, const LkParams
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (EMIT_ROWS) {
+        // config 2: the tile's 64 observation rows to HBM; rows of unmatched points are zero.  Whole 16-B pieces, consecutive lanes: every
+        // store instruction of the wave covers 1 024 contiguous bytes (8 whole cache lines) instead of 64 eight-byte words a row apart
+        // (2.4 -> 0.5 L2 write requests per point).  Non-temporal: the rows stream out and are never read again by this launch - kept out of
+        // the L2's way they do not evict the plane records every other wave is matching against (HBM reads 38.6 -> 27.7 B per point).
+        typedef double lk_d2v __attribute__((ext_vector_type(2)));
+        const int tile0 = i - lane;                                   // wave-uniform
+        const int nv = n - tile0 < 64 ? n - tile0 : 64;               // points of this tile (<= 0: a tile behind the scan's end)
+        const size_t o0 = out_base + (size_t)tile0;
+        if (out.rows8) {
+            // packed records [h(6) z R] of 64 B (lk_batch_residuals_dev): the tile is ONE contiguous 4 096-B block, lane l stores pieces l, 64 + l, ...
+            lk_d2v* dst = reinterpret_cast<lk_d2v*>(out.rows8 + o0 * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = k * 64 + lane, row = e >> 2, c = (e & 3) * 2;
+                if (row < nv) {
+                    const double* r = rows + row * LK_ROW2;
+                    lk_d2v v;
+                    v.x = r[c], v.y = c == 6 ? r[13] : r[c + 1];   // doubles 0..6 of the LDS row are h, z; R sits at 13
+                    LK_ROWS_STORE(v, dst + e);
+                }
+            }
+        } else {
+            // lk_residuals' separate arrays: the tile's h6 block is 64 x 48 B = 192 contiguous pieces
+            lk_d2v* dst = reinterpret_cast<lk_d2v*>(out.h6 + o0 * 6);   // (o0 * 48) B: 16-B aligned with the buffer
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = k * 64 + lane, row = e / 3, c = (e - row * 3) * 2;
+                if (row < nv) {
+                    lk_d2v v;
+                    v.x = rows[row * LK_ROW2 + c], v.y = rows[row * LK_ROW2 + c + 1];
+                    LK_ROWS_STORE(v, dst + e);
+                }
+            }
+            if (lane < nv) {
+                const double* r = rows + lane * LK_ROW2;
+                LK_ROWS_STORE(r[6], out.z + o0 + lane);
+                LK_ROWS_STORE(r[13], out.R + o0 + lane);
+            }
+        }
+        if (lane < nv) LK_ROWS_STORE((unsigned char)(rows[lane * LK_ROW2 + 14] != 0.0 ? 1 : 0), out.valid + o0 + lane);
+        return 0.0;   // config 2 ends here ("residuals only"): no caller of a row-emitting launch reads the tile's sums A, b (K3)
+    }
     if (LK_X_NORED) return (lane == 28) ? (ok ? 1.0 : 0.0) : 0.0;
 #if LK_MFMA_RED
     // K3 on the matrix cores: G = X^T Y over the tile's 64 rows with X = [h/R (6), R, valid] (row doubles 7..14) and
@@ -532,15 +584,23 @@ __global__ void LK_RES_BOUNDS
                        ResidualOut out, size_t out_slot_stride) {
     // per-wave LDS region holding the wave's 64 observation rows
     __shared__ double stage[LK_RB / LK_WAVE][64 * LK_ROW2];
-    const int slot = blockIdx.y;
+    int slot = blockIdx.y, bx = blockIdx.x;
+    if (out.xmap_slots > 0) {   // XCD-aware batch launch (ResidualOut::xmap_slots); uniform per workgroup
+        const unsigned int T = (unsigned int)((n + LK_RB - 1) / LK_RB), c = (T + 7u) >> 3;
+        const unsigned int x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned int t = x * c + j % c;
+        slot = (int)(j / c);
+        if (t >= T || slot >= out.xmap_slots) return;
+        bx = (int)t;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
     const double acc = residual_tile<EMIT_ROWS, GRID, XID, false, SPEC>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
-                                                blockIdx.x * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
-    if (lane < LK_NPART) {
-        const size_t wave_id = (size_t)blockIdx.x * (LK_RB / LK_WAVE) + wv;
+                                                bx * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
+    if (!EMIT_ROWS && lane < LK_NPART) {
+        const size_t wave_id = (size_t)bx * (LK_RB / LK_WAVE) + wv;
         partials[(size_t)slot * part_slot_stride + wave_id * LK_NPART + lane] = (lane < 29) ? acc : 0.0;
     }
 }

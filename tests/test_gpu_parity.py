@@ -871,14 +871,15 @@ def test_config2_batch_rows_resident(big, oracle_lib, hip_lib):
     allpts = np.concatenate([scans[u] for u in tile])
     N = S * n_pts
     d_pts = g.device_malloc(allpts.nbytes)
-    d_h6, d_z, d_R, d_v = g.device_malloc(N * 48), g.device_malloc(N * 8), g.device_malloc(N * 8), g.device_malloc(N)
+    d_rows, d_v = g.device_malloc(N * 64), g.device_malloc(N)
     g.h2d(d_pts, allpts)
     g.batch_set_priors(xs, Ps)
-    g.batch_residuals_dev(d_pts, S, n_pts, d_h6, d_z, d_R, d_v)
+    g.batch_residuals_dev(d_pts, S, n_pts, d_rows, d_v)
     g.synchronize()
-    h6, z, R, v = np.zeros((N, 6)), np.zeros(N), np.zeros(N), np.zeros(N, dtype=np.uint8)
-    for dst, src in ((h6, d_h6), (z, d_z), (R, d_R), (v, d_v)):
-        g.d2h(dst, src)
+    rows8, v = np.zeros((N, 8)), np.zeros(N, dtype=np.uint8)
+    g.d2h(rows8, d_rows)
+    g.d2h(v, d_v)
+    h6, z, R = np.ascontiguousarray(rows8[:, :6]), np.ascontiguousarray(rows8[:, 6]), np.ascontiguousarray(rows8[:, 7])
     n_flips = 0
     for s in range(S):
         a, b = s * n_pts, (s + 1) * n_pts
@@ -901,7 +902,7 @@ def test_config2_batch_rows_resident(big, oracle_lib, hip_lib):
             assert np.array_equal(vh, v[a:b]) and np.array_equal(hh, h6[a:b]) and np.array_equal(zh, z[a:b]) and np.array_equal(Rh, R[a:b])
             g.batch_set_priors(xs, Ps)
     assert n_flips <= 2, n_flips
-    for d in (d_pts, d_h6, d_z, d_R, d_v):
+    for d in (d_pts, d_rows, d_v):
         g.device_free(d)
     g.close()
     o.close()

@@ -7,9 +7,9 @@ in $LK_PROFILES_DIR (default profiles/).   usage: collect_config2_pmc.py <tag> <
 
 HBM bytes: FETCH_SIZE / WRITE_SIZE are KiB counters.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes of wide
 coalesced reads (doubled here), "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count".  The workload therefore
-runs a fill (N x 48 B written) and a device-to-device copy (N x 48 B read and written) in the same profiled process; their counter readings against
-the known byte counts are stored as `calibration`, and the rows kernel's own write count has a known value too (it writes 65 B of rows and 4 B of
-partial sums per point unconditionally)."""
+runs a fill (N x 48 B written) and an elementwise multiply (N x 48 B read and written) in the same profiled process; their counter readings against
+the known byte counts are stored as `calibration`, and the rows kernel's own write count has a known value too (it writes a 64-B row record and the valid
+byte per point unconditionally)."""
 import collections
 import csv
 import glob
@@ -40,8 +40,8 @@ def main():
             return "rows"
         if "FillFunctor" in name:
             return "fill"
-        if "copy" in name.lower() and "at::native" in name:
-            return "copy"
+        if "MulFunctor" in name or "mul" in name.lower() and "at::native" in name:
+            return "mul"
         return None
 
     for f in glob.glob("/tmp/c2p_*/**/*counter_collection.csv", recursive=True):
@@ -49,7 +49,7 @@ def main():
             c = cls(short(r["Kernel_Name"]))
             if c is None:
                 continue
-            if c in ("fill", "copy") and int(float(r.get("Grid_Size") or 0)) < N // 8:   # only the big calibration launches (the map build etc. also fill small buffers)
+            if c in ("fill", "mul") and int(float(r.get("Grid_Size") or 0)) < N // 8:   # only the big calibration launches (the map build etc. also fill small buffers)
                 continue
             acc[c][r["Counter_Name"]] += float(r["Counter_Value"])
             ndisp[c][r["Counter_Name"]].add((f, r["Dispatch_Id"]))
@@ -59,7 +59,7 @@ def main():
             c = cls(short(r["Kernel_Name"]))
             if c is None:
                 continue
-            if c in ("fill", "copy") and int(float(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)) < N // 8:
+            if c in ("fill", "mul") and int(float(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)) < N // 8:
                 continue
             dur[c].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
     for f in glob.glob("/tmp/c2p_stats/**/*kernel_stats.csv", recursive=True):
@@ -77,14 +77,14 @@ def main():
     cal = {}
     if "fill" in per and per["fill"].get("WRITE_SIZE"):
         cal["fill_WRITE_SIZE_bytes_over_known"] = per["fill"]["WRITE_SIZE"] * 1024.0 / (N * 48)
-    if "copy" in per:
-        if per["copy"].get("WRITE_SIZE"):
-            cal["copy_WRITE_SIZE_bytes_over_known"] = per["copy"]["WRITE_SIZE"] * 1024.0 / (N * 48)
-        if per["copy"].get("FETCH_SIZE"):
-            cal["copy_FETCH_SIZE_bytes_over_known"] = per["copy"]["FETCH_SIZE"] * 1024.0 / (N * 48)
-    known_written = 69.0   # 65 B of rows + 4 B of the wave's partial record, per point, unconditional
+    if "mul" in per:
+        if per["mul"].get("WRITE_SIZE"):
+            cal["mul_WRITE_SIZE_bytes_over_known"] = per["mul"]["WRITE_SIZE"] * 1024.0 / (N * 48)
+        if per["mul"].get("FETCH_SIZE"):
+            cal["mul_FETCH_SIZE_bytes_over_known"] = per["mul"]["FETCH_SIZE"] * 1024.0 / (N * 48)   # the guide: 0.5 for wide coalesced reads
+    known_written = 65.0   # 64 B row record + the valid byte, per point, unconditional
     if write_KiB:
-        cal["rows_WRITE_SIZE_bytes_over_known_69B_per_point"] = write_KiB * 1024.0 / (N * known_written)
+        cal["rows_WRITE_SIZE_bytes_over_known_65B_per_point"] = write_KiB * 1024.0 / (N * known_written)
     latest = {"tag": tag, "commit": os.environ.get("LK_PROF_COMMIT", "unknown"), "kernel": "lk_residual_kernel<true> (lk_batch_residuals_dev)", "slots": slots,
               "points_per_launch": N, "launches_profiled": launches, "kernel_sources_sha16": bench.kernel_sources_sha16(),
               "FETCH_SIZE_KiB": fetch_KiB, "WRITE_SIZE_KiB": write_KiB, "calibration": cal}

@@ -2,7 +2,7 @@
 """BASELINE config 2 at bandwidth size (lk_batch_residuals_dev) as a stand-alone workload for the profiler: the bench's scene and map, the
 FIRST S scans of the bench batch (same generator jobs, same cache keys as bench.py --cache-dir), every scan under its prior, residual rows
 materialised in HBM, R launches.  Two calibration launches of KNOWN byte counts run in the same process (a torch fill and a torch
-device-to-device copy of the h6 buffer: WRITE_SIZE / FETCH_SIZE are uncalibrated on gfx950 - MI355X_MICROARCH.md, HBM section).
+elementwise multiply over the h6 buffer: WRITE_SIZE / FETCH_SIZE are uncalibrated on gfx950 - MI355X_MICROARCH.md, HBM section).
 Prints one JSON line.
 
     python tools/config2_workload.py --slots 256 --reps 5 [--cache-dir /tmp/lkcache]
@@ -60,15 +60,14 @@ def main():
     bench.build_map(g, traj, P, first, warm, warm_t)
     N = S * bench.N_PTS
     d_pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(scans)).view(np.uint8)).to(dev)
-    d_h6 = torch.empty((N, 6), dtype=torch.float64, device=dev)
-    d_z = torch.empty(N, dtype=torch.float64, device=dev)
-    d_R = torch.empty(N, dtype=torch.float64, device=dev)
+    d_rows = torch.empty((N, 8), dtype=torch.float64, device=dev)
+    d_h6 = d_rows.view(-1)[: N * 6].view(N, 6)     # calibration source below: N x 48 B
     d_v = torch.empty(N, dtype=torch.uint8, device=dev)
     g.batch_set_priors(xs, Ps)
     torch.cuda.synchronize()
 
     def run():
-        g.batch_residuals_dev(d_pts.data_ptr(), S, bench.N_PTS, d_h6.data_ptr(), d_z.data_ptr(), d_R.data_ptr(), d_v.data_ptr())
+        g.batch_residuals_dev(d_pts.data_ptr(), S, bench.N_PTS, d_rows.data_ptr(), d_v.data_ptr())
 
     run()
     g.synchronize()
@@ -87,9 +86,9 @@ def main():
         for _ in range(3):
             cal.fill_(1.5)
         for _ in range(3):
-            cal.copy_(d_h6)
+            torch.mul(d_h6, 2.0, out=cal)     # an elementwise kernel: N x 48 B read (16 B per lane, coalesced), N x 48 B written
         torch.cuda.synchronize()
-        out["calibration"] = {"fill_bytes_written": N * 48, "copy_bytes_read": N * 48, "copy_bytes_written": N * 48, "fills": 3, "copies": 3}
+        out["calibration"] = {"fill_bytes_written": N * 48, "mul_bytes_read": N * 48, "mul_bytes_written": N * 48, "fills": 3, "muls": 3}
     print(json.dumps(out))
     g.close()
 
