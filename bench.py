@@ -62,6 +62,10 @@ C2_BYTES_PER_POINT = 81    # config 2 with the rows materialised: 16 B scan poin
 OV_KERNELS = ("ov_reset", "predict", "ov_residual", "update", "ov_begin", "ov_reproject", "ov_materialise", "ov_point_geom", "ov_root_lane", "ov_insert_root", "ov_fit_eig", "ov_fit_lane",
               "ov_insert_apply", "ov_insert_fallback")
 OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
+# config 4's sensor message: the fields of an Ouster PointCloud2 point that LidarProcessing::ousterHander reads (lidar_processing.cc:54-80)
+OUSTER_MSG_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<u4")])
+OUSTER_MSG_LAYOUT = dict(point_step=16, off_x=0, off_y=4, off_z=8, off_time=12, lidar_type=2)
+T0_CONFIG4 = 3.0
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
 
 
@@ -181,6 +185,12 @@ def _gen(job):
         raw = synth.vlp16_scan(_W, _T, tb, P, seed_noise=s_noise)
         pre = synth.preprocess_velodyne(raw, P["filter_num"], P["blind"])
         return synth.sort_by_time(synth.voxel_grid_centroid(pre, P["voxel_grid_resolution"]))
+    if kind == "ouster":   # config 4: an OS1-64-like message of the diter configuration (x, y, z f32 + the point's `t` in ns)
+        tb, s_noise, static = a
+        pts, t_ns = synth.ouster_scan(_W, Frozen(_T, tb) if static else _T, tb, config.DITER, seed_noise=s_noise)
+        raw = np.zeros(len(pts), dtype=OUSTER_MSG_DTYPE)
+        raw["x"], raw["y"], raw["z"], raw["t"] = pts["x"], pts["y"], pts["z"], t_ns
+        return raw
     raise ValueError(kind)
 
 
@@ -238,6 +248,8 @@ def main():
     ap.add_argument("--shuffle-main", action="store_true", help="profiling aid: the MAIN timed loop runs on the batch with a random permutation inside every bucket "
                     "(tools/gpu_prof_shuffled.sh collects the residual kernel's counters for that order -> profiles/latest_shuffled_pmc.json); the line says so")
     ap.add_argument("--overlay-scans", type=int, default=1024, help="scans of the batch replayed WITH the map insert (per-scan overlay, extra.overlay_*; 0 = skip)")
+    ap.add_argument("--config4-scans", type=int, default=100, help="extra.config4_*: consecutive Ouster-shaped scans (diter.yaml, 64 x 1024 rays, 500 Hz kinematic + IMU messages, leg "
+                    "fusion) through decode -> voxel grid + time sort -> the live path with insert (BASELINE config 4; 0 = skip)")
     ap.add_argument("--config2-scans", type=int, default=256, help="extra.config2_*: scans of the batch whose residual ROWS are materialised in HBM in one launch (BASELINE config 2 "
                     "at bandwidth size: lk_batch_residuals_dev; 0 = skip)")
     ap.add_argument("--config2-check", type=int, default=4, help="of those, scans whose rows the oracle's residual build checks (valid mask, h / z / R)")
@@ -298,6 +310,10 @@ def main():
     jobs += [("dense", (t_after + 0.1 * k, N_BUCKETS, 8008 + k, 8108 + k)) for k in range(ns)]
     jobs += [("dense", (t_after + 0.1 * (ns + k), 51, 8208 + k, 8308 + k)) for k in range(n51)]
     jobs += [("vlp", (t_after + 0.1 * k, 7007 + k)) for k in range(U1)]
+    U4 = args.config4_scans if (rank == 0 and world_size == 1) else 0
+    if U4:
+        jobs.append(("ouster", (T0_CONFIG4, 3999, True)))
+        jobs += [("ouster", (T0_CONFIG4 + 0.1 * k, 4000 + k, False)) for k in range(U4)]
     # optional per-job cache (profiling passes of one session re-run this command many times)
     def cpath(j):
         return os.path.join(args.cache_dir, "lk_" + j[0] + "_" + "_".join(repr(v) for v in j[1]) + ".npy")
@@ -319,6 +335,8 @@ def main():
     sscans = [next(it) for _ in range(ns)]
     s51 = [next(it) for _ in range(n51)]
     c1_scans = [next(it) for _ in range(U1)]
+    c4_static = next(it) if U4 else None
+    c4_msgs = [next(it) for _ in range(U4)]
     gen_s = time.time() - t_gen0
     off, dt = synth.buckets_of(scans[0])
     assert all(len(sc) == N_PTS for sc in scans)
@@ -906,6 +924,63 @@ def main():
             tl.append(time.perf_counter() - tc)
         extra["config1_live_stream_ms_per_scan"] = round(float(np.median(tl[1:])) * 1e3, 3)
         del d_c1, d_x1, d_P1
+    # ---- extra: BASELINE config 4 ("Diter++ Go2 sequence replay, IMU-as-observation + leg-kinematic factors, 1 MI355X"): no bag exists here, so
+    # SURVEY 8(d)'s synthetic stand-in - diter.yaml, an Ouster-like 64 x 1024 message every 0.1 s, 500 Hz kinematic + IMU messages (trot
+    # gait), only_imu_use: false - as a LIVE run on its own handle: per scan lk_decode_scan (lidar_processing.cc:54-80) -> lk_preprocess_scan
+    # (pcl::VoxelGrid + time sort, KILO.cc:356-370) -> lk_process_scan (bucket loop with predictUpdateKinImu between the buckets, insert after
+    # every bucket, KILO.cc:367-396), each timed on its own.  The CPU port and the reference's own build replay the same scans below.
+    c4 = None
+    if U4:
+        try:
+            P4 = config.DITER
+            cfg4 = config.make_config(P4, device_id=local_rank, n_slots=1, max_roots=1 << 15, max_nodes=1 << 16, max_point_blocks=1 << 15, max_scan_points=1 << 17)
+            g4 = binding.LegKiloHip(cfg4)
+            x04 = synth.initial_state(traj, T0_CONFIG4, P4)
+            g4.set_state(x04, 1e-6 * np.eye(30))
+            g4.init_process_cov_q()
+            g4.set_acc_norm(9.81)
+            g4.set_times(T0_CONFIG4, T0_CONFIG4)
+            dec0, _, _ = g4.decode_scan(c4_static.tobytes(), len(c4_static), OUSTER_MSG_LAYOUT, P4["time_scale"], P4["filter_num"], P4["blind"], header_stamp=T0_CONFIG4)
+            xb4 = xyz_of(dec0)
+            xw4 = world_of(x04, xb4, P4)
+            g4.map_build(xw4, xb4)
+            kins4 = [synth.kin_stream(traj, T0_CONFIG4 + 0.1 * k, T0_CONFIG4 + 0.1 * (k + 1), P4, seed=5000 + k) for k in range(U4)]
+            t_dec, t_pre, t_path, ds4, tb4, poses4 = [], [], [], [], [], []
+            for k in range(U4):
+                msg = c4_msgs[k].tobytes()
+                tb = T0_CONFIG4 + 0.1 * k
+                tc = time.perf_counter()
+                dec, b_, _ = g4.decode_scan(msg, len(c4_msgs[k]), OUSTER_MSG_LAYOUT, P4["time_scale"], P4["filter_num"], P4["blind"], header_stamp=tb)
+                t1_ = time.perf_counter()
+                ds = g4.preprocess_scan(dec, P4["voxel_grid_resolution"])
+                t2_ = time.perf_counter()
+                pose, _ = g4.process_scan(ds, b_, kins=kins4[k])
+                t3_ = time.perf_counter()
+                t_dec.append(t1_ - tc), t_pre.append(t2_ - t1_), t_path.append(t3_ - t2_)
+                ds4.append(ds), tb4.append(b_)
+                poses4.append((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect), np.array(pose.pos), np.array(pose.rot)))
+            rs4 = g4.stream_resident_stats()
+            sk = slice(1, None)   # the first scan pays one-off allocations
+            extra["config4_scans"] = U4
+            extra["config4_points_per_message"] = round(float(np.mean([len(m) for m in c4_msgs])), 1)
+            extra["config4_points_per_scan_after_voxel_grid"] = round(float(np.mean([len(d) for d in ds4])), 1)
+            extra["config4_buckets_per_scan"] = round(float(np.mean([p_[0] for p_ in poses4])), 1)
+            extra["config4_kin_imu_messages_per_scan"] = round(float(np.mean([len(k_) for k_ in kins4])), 1)
+            extra["config4_mean_n_effect"] = round(float(np.mean([p_[2] for p_ in poses4])), 1)
+            extra["config4_decode_ms_per_scan"] = round(float(np.median(t_dec[sk])) * 1e3, 3)
+            extra["config4_preprocess_ms_per_scan"] = round(float(np.median(t_pre[sk])) * 1e3, 3)
+            extra["config4_path_ms_per_scan"] = round(float(np.median(t_path[sk])) * 1e3, 3)
+            extra["config4_path_scans_per_s"] = round(1.0 / float(np.median(t_path[sk])), 1)
+            extra["config4_path_us_per_bucket"] = round(float(np.median(t_path[sk])) * 1e6 / max(1.0, extra["config4_buckets_per_scan"]), 2)
+            extra["config4_all_three_ms_per_scan"] = round(float(np.median(np.array(t_dec[sk]) + np.array(t_pre[sk]) + np.array(t_path[sk]))) * 1e3, 3)
+            extra["config4_resident_kernel_relaunches"] = int(rs4[1])
+            extra["config4_note"] = ("host buffers in, pose out: every stage includes its PCIe copies and its synchronisation; `path` = the reference's timed lambda "
+                                     "(KILO.cc:367-396: bucket loop with kinematic + IMU updates between the buckets and the map insert after every bucket)")
+            c4 = (cfg4, x04, xw4, xb4, ds4, tb4, kins4, poses4)
+            g4.close()
+        except Exception as e:  # noqa: BLE001
+            extra["config4_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+            warnings.append("config-4 live run failed: " + extra["config4_error"])
     cpu_baseline = None
     parity = None
     if rank == 0 and ns >= 2:
@@ -1041,6 +1116,37 @@ def main():
                 parity["config1_overlay_ragged"] = {"n": n_o, "counts_equal": o_eq, "max_pos_delta_m": o_dpos, "tolerance_m": 1e-7}
                 parity["ok"] = bool(parity["ok"] and o_dpos <= 1e-7 and o_eq >= n_o - 1)
                 extra["config1_overlay_cpu_port_scans_per_s"] = round(1.0 / float(np.median(t1o)), 1)
+        if c4 is not None:   # config 4: the same run on the CPU port (kinematic + IMU mode, insert on) and on the reference's own build
+            cfg4, x04, xw4, xb4, ds4, tb4, kins4, poses4 = c4
+            runs4 = [("port", lambda: ob.Oracle(cfg4, imu_mode_only=False))]
+            if ob.build_ref() is not None:
+                import tempfile
+
+                yml4 = os.path.join(tempfile.mkdtemp(prefix="lkc4"), "c4.yaml")
+                runs4.append(("reference", lambda: ob.ReferenceKilo(config.DITER, False, yml4)))
+            c4par = {}
+            for name, mk in runs4:
+                r4 = mk()
+                r4.set_state(x04, 1e-6 * np.eye(30))
+                r4.init_process_cov_q()
+                r4.set_acc_norm(9.81)
+                r4.set_times(T0_CONFIG4, T0_CONFIG4)
+                r4.map_build(xw4, xb4)
+                t4s, eq4, dpos4 = [], 0, 0.0
+                for k in range(len(ds4)):
+                    tc = time.perf_counter()
+                    pose, _ = r4.process_scan(ds4[k], tb4[k], kins=kins4[k], with_sort=True)
+                    t4s.append(time.perf_counter() - tc)
+                    nb_, nu_, ne_, pos_, _ = poses4[k]
+                    eq4 += int(int(pose.n_effect) == ne_ and (name != "port" or (int(pose.n_buckets), int(pose.n_updates)) == (nb_, nu_)))
+                    dpos4 = max(dpos4, float(np.abs(np.array(pose.pos) - pos_).max()))
+                r4.close()
+                c4par[name] = {"n": len(ds4), "counts_equal": eq4, "max_pos_delta_m": dpos4}
+                extra[f"config4_cpu_{name}_ms_per_scan"] = round(float(np.median(t4s[1:])) * 1e3, 3)
+                extra[f"config4_path_speedup_vs_cpu_{name}"] = round(float(np.median(t4s[1:])) * 1e3 / extra["config4_path_ms_per_scan"], 2)
+            # closed loop with insert over 100 scans: counts are exact, positions agree to the closed-loop sensitivity of DESIGN section 7 (1e-6 m)
+            parity["config4_live"] = dict(c4par, tolerance_m=1e-6, checker="oracle / oracle/_ref KILO::process, leg fusion, insert on, same messages and scans")
+            parity["ok"] = bool(parity["ok"] and all(v["counts_equal"] == v["n"] and v["max_pos_delta_m"] <= 1e-6 for v in c4par.values()))
         if shuf is not None:   # the shuffled batch's own parity sample: same oracle, same map, the scans as the device got them (the sort is stable)
             sh_host, sh_last = shuf
             sh_eq, sh_dpos = 0, 0.0

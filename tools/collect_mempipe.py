@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 N_CU = 256
+FULL_GRID = 313 * 64 * 1024   # threads of one batch residual launch: 313 tiles x 1024 scans
 
 
 def main():
@@ -37,12 +38,14 @@ def main():
                     k = r["Kernel_Name"]
                     if "lk_residual_kernel<false, 1" not in k and "lk_residual_kernel<(bool)0, 1" not in k:
                         continue
+                    if int(float(r.get("Grid_Size") or 0)) != FULL_GRID:   # the 1024-scan launches of the timed loop only (the shard128 extra launches the same kernel over 128 scans)
+                        continue
                     acc[r["Counter_Name"]] += float(r["Counter_Value"])
                     cnt[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
             for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
-                    if "lk_residual_kernel<false, 1" in k or "lk_residual_kernel<(bool)0, 1" in k:
+                    if ("lk_residual_kernel<false, 1" in k or "lk_residual_kernel<(bool)0, 1" in k) and int(float(r.get("Grid_Size") or 0)) == FULL_GRID:
                         durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
         if not acc:
             continue
@@ -73,6 +76,11 @@ def main():
             d["tcp_accesses_per_point"] = g("TCP_TOTAL_ACCESSES_sum") / pts
             d["tcp_ta_data_stall_cycles_per_access"] = g("TCP_TCP_TA_DATA_STALL_CYCLES_sum", 0.0) / g("TCP_TOTAL_ACCESSES_sum")
             d["tcp_read_tagconflict_stall_cycles_per_access"] = g("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0) / g("TCP_TOTAL_ACCESSES_sum")
+        if g("TCP_TOTAL_ACCESSES_sum") and g("TCP_TCP_TA_ADDR_STALL_CYCLES_sum") is not None:
+            pass
+        for k in ("TCP_TCP_TA_ADDR_STALL_CYCLES_sum", "TCP_LFIFO_STALL_CYCLES_sum", "TCP_RFIFO_STALL_CYCLES_sum", "TCP_TCR_RDRET_STALL_sum"):
+            if g(k) is not None and g("GRBM_GUI_ACTIVE"):
+                d[k.lower().replace("_sum", "") + "_frac_per_cu"] = g(k) / (N_CU * g("GRBM_GUI_ACTIVE"))
         if g("TCP_GATE_EN1_sum"):
             d["tcp_busy_frac_of_clocked"] = g("TCP_GATE_EN2_sum", 0.0) / g("TCP_GATE_EN1_sum")
             d["tcp_tcr_stall_frac_of_clocked"] = g("TCP_TCR_TCP_STALL_CYCLES_sum", 0.0) / g("TCP_GATE_EN1_sum")
