@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lk_prim.h"   // rocPRIM's sorts and scans, instantiated in lk_prim.hip
@@ -97,6 +98,8 @@ struct lk_handle {
     LkMap fmap = {};           // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
     size_t grid_cap = 0;       // grid cells allocated behind the max_nodes match records of map.match
     bool grid_valid = false;   // the grid describes the current map
+    uint64_t map_gen = 0;      // counts the map snapshots batch replays have frozen: frozen_map() bumps it whenever the map had changed since the last one
+    uint64_t ov_gen = 0;       // the snapshot the last overlay replay ran against (lk_overlay_export reads base blocks / planes of THAT map)
     bool grid_enable = true;   // LEGKILO_GRID=0 keeps batch replay on the hash table (A/B)
     int* d_grid_mm = nullptr;
     // grow-only scratch of lk_preprocess_scan
@@ -116,6 +119,24 @@ struct lk_handle {
     LkFilter* d_ov_priors = nullptr;                      // the batch's priors, kept for the retry after a pool overflow
     size_t ov_priors_cap = 0;
     unsigned int* d_ov_status = nullptr;
+    // input order of device-resident batches (lk_batch_order): the batches the frozen-map batch entries have seen, with the library's voxel-ordered copy
+    struct OrdEntry {
+        const lk_point* src = nullptr;     // the caller's buffer and the shape it was seen with
+        size_t n_scans = 0, n_pts = 0, n_buckets = 0;
+        uint64_t off_hash = 0;
+        bool as_given = false;             // the batch already was in voxel order: replayed where it lies, no copy, no stamp
+        lk_point* copy = nullptr;          // voxel-ordered copy (every bucket of every scan sorted by root-voxel key under the priors of the first sight)
+        size_t copy_bytes = 0;
+        unsigned long long* d_ref = nullptr;   // device: [0] content stamp of src at the replay before, [1] 1 = this replay reads the copy
+        bool have_copy = false;            // the copy holds the buffer's content as of the last sort (as far as the host knows: h_seen says what the device found)
+        unsigned int* h_seen = nullptr;    // host-mapped, written by the device: replays in a row that found the same content stamp; LK_ORD_SORTED while the copy is current
+        unsigned int* d_seen = nullptr;
+        uint64_t tick = 0;
+    };
+    OrdEntry ord[2];
+    uint64_t ord_tick = 0, ord_examined = 0, ord_sorted = 0, ord_stale = 0;
+    int batch_order_mode = 1;              // LK_BATCH_ORDER_AUTO; LEGKILO_BATCH_ORDER=0 / lk_batch_order(h, 0): replay every batch as given
+    int batch_order_after = 2;             // a batch is sorted once this many replays in a row have found the same content in its buffer (the sort pays for itself after ~10)
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfEntry> prof;
@@ -293,6 +314,7 @@ static int create_pools(lk_handle* h, const lk_config* cfg) {
     }
     if (const char* e = getenv("LEGKILO_UPDATE_CLASSIC")) h->wave_update = atoi(e) == 0;
     if (const char* e = getenv("LEGKILO_GRID")) h->grid_enable = atoi(e) != 0;
+    if (const char* e = getenv("LEGKILO_BATCH_ORDER")) h->batch_order_mode = atoi(e) != 0;
     HIPCHK(h, hipMalloc(&h->d_grid_mm, 8 * sizeof(int)));
     if (const char* e = getenv("LEGKILO_REPLAY_GROUPS")) h->replay_groups = std::min(std::max(atoi(e), 1), (int)lk_handle::kMaxGroups);
     HIPCHK(h, hipEventCreate(&h->ev0));
@@ -408,6 +430,11 @@ void lk_destroy(lk_handle* h) {
     if (h->h_rag) hipHostFree(h->h_rag);
     if (h->h_result) hipHostFree(h->h_result);
     ov_free(h);
+    for (auto& e : h->ord) {
+        if (e.copy) hipFree(e.copy);
+        if (e.d_ref) hipFree(e.d_ref);
+        if (e.h_seen) hipHostFree(e.h_seen);
+    }
     if (h->d_ov_status) hipFree(h->d_ov_status);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1789,6 +1816,7 @@ static int frozen_map(lk_handle* h, LkMap* out) {
         }
         h->fmap = fm;
         h->grid_valid = true;
+        ++h->map_gen;
     }
     *out = h->fmap;
     return LK_OK;
@@ -1897,7 +1925,11 @@ static int finish_scan(lk_handle* h, lk_pose* pose, const void* d_resume = nullp
                 break;
             }
             if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
@@ -2197,6 +2229,11 @@ int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
     CHECK_H(h);
     if (!h->ov.counters || !h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
     if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
+    // an overlay is not self-contained: split leaves keep their first points in the BASE map's blocks, lazily copied voxels their plane in the base
+    // map's plane records.  Once the handle's map has changed (lk_process_scan, lk_map_update, lk_map_slide, lk_map_import, ...) those ids may
+    // name other voxels: refuse instead of exporting them
+    if (!h->grid_valid || h->ov_gen != h->map_gen)
+        return fail(h, LK_ERR_STATE, "the handle's map has changed since the overlay replay: its overlays can no longer be exported (export before the map is updated, slid or imported, or replay again)");
     const LkOverlay& ov = h->ov;
     // leaves the fast root pass left split (old points still in the handle's blocks) are made whole first
     hipLaunchKernelGGL(lk_ov_merge_split_kernel, dim3(64), dim3(LK_MB), 0, h->stream, h->map, ov, slot);
@@ -3090,11 +3127,15 @@ __global__ void __launch_bounds__(256) lk_sort_gather_kernel(const lk_point* __r
 // instead of sixty (1.8 -> 0.6 L2 requests per point on the bench batch, 2.25 -> 1.6 ms per step).  Points keep their bucket; the order inside
 // a bucket is one of the legal outcomes of KILO.cc:369's sort (equal curvature).  Stable segmented radix sort (rocPRIM) of (key, index) pairs +
 // one gather; priors from lk_batch_set_priors(_dev).  Once per loaded batch, not per replay; in and out must not overlap.
+static int sort_by_voxel(lk_handle* h, const lk_point* d_in, lk_point* d_out, uint32_t first_slot, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets);
 int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_out, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets) {
     CHECK_H(h);
+    return sort_by_voxel(h, d_in, d_out, 0, n_scans, n_pts, bucket_off, n_buckets);
+}
+static int sort_by_voxel(lk_handle* h, const lk_point* d_in, lk_point* d_out, uint32_t first_slot, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets) {
     if (!d_in || !d_out || !bucket_off) return fail(h, LK_ERR_INVALID, "null argument");
     if (n_scans == 0 || n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty batch");
-    if (n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans exceeds n_slots");
+    if ((size_t)first_slot + n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans exceeds n_slots");
     if (bucket_off[0] != 0 || bucket_off[n_buckets] != n_pts) return fail(h, LK_ERR_INVALID, "bucket_off must cover the scan: bucket_off[0] == 0, bucket_off[n_buckets] == n_pts");
     for (size_t b = 0; b < n_buckets; ++b)
         if (bucket_off[b + 1] < bucket_off[b]) return fail(h, LK_ERR_INVALID, "bucket_off must be non-decreasing");
@@ -3114,7 +3155,7 @@ int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_o
     HIPCHK(h, tmp.alloc(&v1, sizeof(unsigned int) * total));
     HIPCHK(h, tmp.alloc(&d_off, sizeof(unsigned int) * (nseg + 1)));
     HIPCHK(h, hipMemcpyAsync(d_off, offs.data(), sizeof(unsigned int) * (nseg + 1), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(lk_sort_keys_kernel, dim3((unsigned int)((n_pts + 255) / 256), (unsigned int)n_scans), dim3(256), 0, h->stream, h->pr, h->d_filters, d_in, n_pts, k0, v0);
+    hipLaunchKernelGGL(lk_sort_keys_kernel, dim3((unsigned int)((n_pts + 255) / 256), (unsigned int)n_scans), dim3(256), 0, h->stream, h->pr, h->d_filters + first_slot, d_in, n_pts, k0, v0);
     HIPCHK(h, hipGetLastError());
     size_t tmp_bytes = 0;
     HIPCHK(h, lk_prim_segmented_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (unsigned int)total, (unsigned int)nseg, d_off, d_off + 1, 0, 30, h->stream));
@@ -3123,6 +3164,156 @@ int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_o
     hipLaunchKernelGGL(lk_sort_gather_kernel, dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, h->stream, d_in, d_out, v1, total);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // offs and the temporaries go out of scope
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ input order of device-resident batches (lk_batch_order)
+// The batch residual kernel is 1.4 x slower on a batch whose buckets come in a random order than on one in voxel order (1.80 against 0.63 L2
+// requests per point).  So that this is not the caller's problem, the frozen-map batch entries keep track of the batches they are given - (device
+// pointer, shape, bucket bounds) + a stamp of 4 096 sampled points, taken ON THE DEVICE by a one-workgroup kernel ahead of the residual launches
+// (no host round trip) - and once a batch has come back unchanged twice they sort it, unless every bucket already is in voxel order, ONCE into a
+// library-owned copy (sort_by_voxel: 5.6 ms per 1 024 x 100 000 points) which its later replays read.  Any order inside a bucket is a legal outcome
+// of the reference's sort of equal time stamps (KILO.cc:369), so the copy is a batch of the same scans.  A batch that is replayed once or twice - new
+// scans streamed through one staging buffer - is never sorted; new content in a sorted batch's buffer is noticed by the same kernel, which tells the
+// residual kernel to read the caller's buffer (ResidualOut::alt_use) and starts the count again.  (An in-place edit that changes none of the sampled
+// points is not noticed: lk_batch_changed.)
+__global__ void __launch_bounds__(256) lk_sort_check_kernel(LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts, size_t n_pts,
+                                                            unsigned int* __restrict__ unsorted) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 || i >= n_pts) return;
+    BucketConst bc;
+    load_bucket_const<false>(&filters[blockIdx.y], pr, bc);
+    const float4* p4 = reinterpret_cast<const float4*>(pts) + (size_t)blockIdx.y * n_pts;
+    const float4 a = p4[i - 1], b = p4[i];
+    if (a.w != b.w) return;   // a bucket boundary (runs of equal curvature, KILO.cc:375-378)
+    int ka[3], kb[3];
+    key_floor(point_world(a.x, a.y, a.z, bc, pr), pr.voxel_size_f, ka);
+    key_floor(point_world(b.x, b.y, b.z, bc, pr), pr.voxel_size_f, kb);
+    const unsigned int sa = (((unsigned int)ka[2] & 1023u) << 20) | (((unsigned int)ka[1] & 1023u) << 10) | ((unsigned int)ka[0] & 1023u);
+    const unsigned int sb = (((unsigned int)kb[2] & 1023u) << 20) | (((unsigned int)kb[1] & 1023u) << 10) | ((unsigned int)kb[0] & 1023u);
+    if (sb < sa) atomicAdd(unsorted, 1u);
+}
+// Stamp of 4 096 points spread over the batch, compared on the device with the stamp of the replay before (ref[0]); ref[1] = which buffer THIS replay's
+// residual launches read (1: the library's copy); *seen (host-mapped) = how many replays in a row have found the same stamp (LK_ORD_SORTED once a copy
+// of this very content exists).  mode LK_ORD_SET: the copy has just been made from the buffer.
+#define LK_ORD_PROBE 0     // no copy (yet): count how often the content repeats
+#define LK_ORD_CHECK 1     // a copy exists: use it if the buffer still holds what it was made from
+#define LK_ORD_SET 2
+#define LK_ORD_SORTED 1000000u
+__global__ void __launch_bounds__(256) lk_batch_stamp_kernel(const lk_point* __restrict__ pts, size_t total, unsigned long long* __restrict__ ref,
+                                                             unsigned int* __restrict__ seen, int mode) {
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0ull;
+    __syncthreads();
+    const size_t stride = total / 4096 ? total / 4096 : 1;
+    unsigned long long hsh = 0ull;
+    for (int k = 0; k < 16; ++k) {
+        const size_t idx = ((size_t)threadIdx.x * 16 + k) * stride;
+        if (idx >= total) break;
+        const uint4 v = reinterpret_cast<const uint4*>(pts)[idx];
+        unsigned long long m = ((unsigned long long)v.x | ((unsigned long long)v.y << 32)) ^ (0x9E3779B97F4A7C15ull * (idx + 1));
+        m = (m ^ (m >> 31)) * 0xBF58476D1CE4E5B9ull;
+        m ^= ((unsigned long long)v.z | ((unsigned long long)v.w << 32)) * 0x94D049BB133111EBull;
+        m = (m ^ (m >> 29)) * 0xC2B2AE3D27D4EB4Full;
+        hsh += m ^ (m >> 32);   // a sum: the order the threads arrive in does not matter
+    }
+    atomicAdd(&acc, hsh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long st = acc | 1ull;   // never 0: ref[0] == 0 means "no stamp yet"
+        if (mode == LK_ORD_SET) {
+            ref[0] = st, ref[1] = 1ull, *seen = LK_ORD_SORTED;
+        } else if (st == ref[0]) {
+            ref[1] = mode == LK_ORD_CHECK ? 1ull : 0ull;
+            if (mode == LK_ORD_PROBE) *seen = *seen + 1u;
+        } else {   // other content than last time: this replay reads the caller's buffer, and the count starts again
+            ref[0] = st, ref[1] = 0ull, *seen = 1u;
+        }
+    }
+}
+static uint64_t hash_offsets(const uint32_t* off, size_t n) {
+    uint64_t x = 1469598103934665603ull;
+    for (size_t i = 0; i <= n; ++i) x = (x ^ off[i]) * 1099511628211ull;
+    return x;
+}
+// Which buffer the residual launches of a frozen-map batch replay read.  `st`: the stream the slots' priors were armed on and the batch will run on.
+// Fills ro->alt_pts / alt_use (null: the caller's buffer as given).  One small launch per call; the call that makes the copy synchronises.
+static int batch_ordered(lk_handle* h, const lk_point* d_pts, uint32_t first_slot, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets,
+                         hipStream_t st, ResidualOut* ro) {
+    ro->alt_pts = nullptr, ro->alt_use = nullptr;
+    if (h->batch_order_mode == 0 || n_scans * n_pts < 4096 || n_scans * n_pts >= ((size_t)1 << 32)) return LK_OK;
+    const uint64_t oh = hash_offsets(bucket_off, n_buckets);
+    lk_handle::OrdEntry* e = nullptr;
+    for (auto& c : h->ord)
+        if (c.src == d_pts && c.n_scans == n_scans && c.n_pts == n_pts && c.n_buckets == n_buckets && c.off_hash == oh) e = &c;
+    if (!e) {   // a batch not seen before (or forgotten): the least recently used entry goes; nothing is examined yet, only its stamp is taken
+        e = h->ord[0].tick <= h->ord[1].tick ? &h->ord[0] : &h->ord[1];
+        if (!e->d_ref) {
+            HIPCHK(h, hipMalloc(&e->d_ref, 2 * sizeof(unsigned long long)));
+            HIPCHK(h, hipHostMalloc(&e->h_seen, sizeof(unsigned int), hipHostMallocMapped));
+            HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_seen), e->h_seen, 0));
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // replays of the entry's former batch may still be using its stamp words
+            for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
+                if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));
+        }
+        *reinterpret_cast<volatile unsigned int*>(e->h_seen) = 0u;
+        HIPCHK(h, hipMemsetAsync(e->d_ref, 0, 2 * sizeof(unsigned long long), st));
+        e->src = d_pts, e->n_scans = n_scans, e->n_pts = n_pts, e->n_buckets = n_buckets, e->off_hash = oh;
+        e->as_given = false, e->have_copy = false;
+    }
+    e->tick = ++h->ord_tick;
+    if (e->as_given) return LK_OK;
+    const unsigned int seen = *reinterpret_cast<volatile unsigned int*>(e->h_seen);   // written by the device; may lag behind the replays still in flight
+    if (e->have_copy && seen < LK_ORD_SORTED) {   // a replay found other content in the caller's buffer: the copy is of no use any more
+        e->have_copy = false;
+        ++h->ord_stale;
+    }
+    if (!e->have_copy && seen >= (unsigned int)h->batch_order_after && seen < LK_ORD_SORTED) {
+        // the same content has been replayed often enough to be worth 5.6 ms: examine it, and unless it already is in voxel order, sort it into the copy
+        ++h->ord_examined;
+        HIPCHK(h, hipStreamSynchronize(st));   // the priors are armed
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)   // (replays in flight on the other streams write the entry's stamp words)
+            if (h->side[i]) HIPCHK(h, hipStreamSynchronize(h->side[i]));
+        unsigned int* d_uns = reinterpret_cast<unsigned int*>(e->d_ref + 1);   // (borrowed: ref[1] is written again by the stamp kernel below)
+        HIPCHK(h, hipMemsetAsync(d_uns, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(lk_sort_check_kernel, dim3((unsigned int)((n_pts + 255) / 256), (unsigned int)n_scans), dim3(256), 0, st, h->pr, h->d_filters + first_slot, d_pts, n_pts, d_uns);
+        HIPCHK(h, hipGetLastError());
+        unsigned int uns = 0;
+        HIPCHK(h, hipMemcpyAsync(&uns, d_uns, sizeof(uns), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipMemsetAsync(d_uns, 0, sizeof(unsigned long long), st));
+        bool sort_it = uns != 0;
+        if (sort_it) {
+            const size_t bytes = sizeof(lk_point) * n_scans * n_pts;
+            if (e->copy_bytes < bytes) {
+                if (e->copy) hipFree(e->copy), e->copy = nullptr, e->copy_bytes = 0;
+                if (hipMalloc(&e->copy, bytes) != hipSuccess) {   // no room for a copy: this batch is replayed as given
+                    (void)hipGetLastError();
+                    e->copy = nullptr;
+                    sort_it = false;
+                } else {
+                    e->copy_bytes = bytes;
+                }
+            }
+        }
+        if (!sort_it) {
+            e->as_given = true;   // in voxel order already (or no memory): replayed where it lies from now on, no stamps
+            return LK_OK;
+        }
+        const int rc = sort_by_voxel(h, d_pts, e->copy, first_slot, n_scans, n_pts, bucket_off, n_buckets);   // on h->stream, synchronous
+        if (rc) return rc;
+        ++h->ord_sorted;
+        e->have_copy = true;
+        hipLaunchKernelGGL(lk_batch_stamp_kernel, dim3(1), dim3(256), 0, st, d_pts, n_scans * n_pts, e->d_ref, e->d_seen, LK_ORD_SET);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(st));
+    } else {
+        hipLaunchKernelGGL(lk_batch_stamp_kernel, dim3(1), dim3(256), 0, st, d_pts, n_scans * n_pts, e->d_ref, e->d_seen, e->have_copy ? LK_ORD_CHECK : LK_ORD_PROBE);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (e->have_copy) ro->alt_pts = e->copy, ro->alt_use = e->d_ref;
     return LK_OK;
 }
 
@@ -3139,6 +3330,23 @@ static int join_side_streams(lk_handle* h) {   // the asynchronous batch entry m
             HIPCHK(h, hipEventRecord(h->ev_join[i], h->side[i]));
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
         }
+    return LK_OK;
+}
+int lk_batch_order(lk_handle* h, int mode) {
+    CHECK_H(h);
+    if (mode != 0 && mode != 1) return fail(h, LK_ERR_INVALID, "mode must be LK_BATCH_ORDER_AS_GIVEN (0) or LK_BATCH_ORDER_AUTO (1)");
+    h->batch_order_mode = mode;
+    return LK_OK;
+}
+int lk_batch_changed(lk_handle* h) {
+    CHECK_H(h);
+    for (auto& e : h->ord) e.src = nullptr;   // every batch is a first sight again (the copies' memory is kept for the next one)
+    return LK_OK;
+}
+int lk_batch_order_stats(lk_handle* h, uint64_t* out3) {
+    CHECK_H(h);
+    if (!out3) return fail(h, LK_ERR_INVALID, "null argument");
+    out3[0] = h->ord_examined, out3[1] = h->ord_sorted, out3[2] = h->ord_stale;
     return LK_OK;
 }
 int lk_batch_get_states_dev(lk_handle* h, uint32_t first_slot, size_t n, double* d_x36, double* d_P900) {
@@ -3188,6 +3396,9 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
     HIPCHK(h, hipGetLastError());
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
+    rc = batch_ordered(h, d_pts, 0, n_scans, n_pts, bucket_off, n_buckets, h->stream, &ro);   // the caller's buffer, or the library's voxel-ordered copy of it
+    if (rc) return rc;
+    const lk_point* const alt_base = ro.alt_pts;
     // non-empty buckets; update(k) and predict(k+1) share one launch (the map is frozen: nothing reads the state in between)
     std::vector<size_t> live;
     for (size_t b = 0; b < n_buckets; ++b) {
@@ -3219,6 +3430,7 @@ int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, siz
             LkFilter* fl = h->d_filters + s0;
             double* parts = h->d_partials + (size_t)s0 * h->part_stride;
             const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
+            ro.alt_pts = alt_base ? alt_base + (size_t)s0 * n_pts + bucket_off[b] : nullptr;
             if (ngroups == 1) {
                 if (k == 0) {
                     if (h->wave_update)
@@ -3647,10 +3859,16 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
     hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, S, t_begin);
     ResidualOut ro;
     memset(&ro, 0, sizeof(ro));
+    {
+        const int rc = batch_ordered(h, d_pts, first_slot, n_scans, n_pts, bucket_off, n_buckets, st, &ro);   // first sight of a batch synchronises; afterwards one small launch
+        if (rc) return rc;
+    }
+    const lk_point* const alt_base = ro.alt_pts;
     bool first = true;
     for (size_t b = 0; b < n_buckets; ++b) {
         if (bucket_off[b + 1] <= bucket_off[b]) continue;
         const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
+        ro.alt_pts = alt_base ? alt_base + bucket_off[b] : nullptr;
         size_t nx = b + 1;
         while (nx < n_buckets && bucket_off[nx + 1] <= bucket_off[nx]) ++nx;
         const bool has_next = nx < n_buckets;
@@ -3981,7 +4199,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         (void)hipStreamSynchronize(h->stream);
         return rc;
     }
-    h->ov_last_slots = (uint32_t)S;
+    h->ov_last_slots = (uint32_t)S, h->ov_gen = h->map_gen;
     const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
     HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
@@ -4004,6 +4222,12 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         memcpy(out, tmp.data(), sizeof(lk_pose) * n_scans);
     } else {
         HIPCHK(h, hipStreamSynchronize(st));
+    }
+    if (stt[0] & LK_E_KEY_RANGE) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "overlay replay: a point of slot %u lies in a voxel whose key is outside the +-2^20 range of the private root tables' packed keys (%.0f km from the origin at this voxel size)",
+                 stt[4], 1048576.0 * h->cfg.max_voxel_size / 1000.0);
+        return fail(h, LK_ERR_INVALID, buf);
     }
     if (stt[0]) {
         char buf[256];
@@ -4083,7 +4307,7 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
             LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min((int)S, ov_fb_wg_r ? ov_fb_wg_r : 128)), dim3(LK_MB), 0, st, ov, h->pr, fl, src, (int)S));
         }
         HIPCHK(h, hipGetLastError());
-        h->ov_last_slots = (uint32_t)S;
+        h->ov_last_slots = (uint32_t)S, h->ov_gen = h->map_gen;
         const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
         HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
@@ -4102,6 +4326,12 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
         rc = fetch_poses(h, tmp.data(), S);
         if (rc) return rc;
         memcpy(out, tmp.data(), sizeof(lk_pose) * (size_t)S);
+    }
+    if (stt[0] & LK_E_KEY_RANGE) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "overlay replay: a point of slot %u lies in a voxel whose key is outside the +-2^20 range of the private root tables' packed keys (%.0f km from the origin at this voxel size)",
+                 stt[4], 1048576.0 * h->cfg.max_voxel_size / 1000.0);
+        return fail(h, LK_ERR_INVALID, buf);
     }
     if (stt[0]) {
         const LkOverlay& ov = h->ov;

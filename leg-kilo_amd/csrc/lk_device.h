@@ -35,6 +35,7 @@
 #define LK_E_BLOCKS_FULL 4u
 #define LK_E_SCRATCH_FULL 8u
 #define LK_E_BAD_BLOB 16u
+#define LK_E_KEY_RANGE 64u      // overlay replay: a point's voxel key does not fit the packed 3 x 21-bit key of the private root tables (not a capacity problem: no pool growth helps)
 #define LK_E_SPEC_TIMEOUT 32u   // a verify wave of the pipelined stream path gave up waiting for the insert stream (bounded spin)
 
 enum { LK_CTR_NODES = 0, LK_CTR_BLOCKS = 1, LK_CTR_ROOTS = 2, LK_CTR_ERR = 3, LK_CTR_TOUCHED = 4, LK_CTR_SCRATCH = 5,

@@ -305,7 +305,7 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
     key_floor(pw, pr.voxel_size_f, key);
     unsigned long long pk;
     if (!ov_pack_key(key[0], key[1], key[2], &pk)) {
-        atomicOr(&pm.counters[LK_CTR_ERR], LK_E_HASH_FULL);
+        atomicOr(&pm.counters[LK_CTR_ERR], LK_E_KEY_RANGE);
         return -1;
     }
     unsigned int cell = 0;

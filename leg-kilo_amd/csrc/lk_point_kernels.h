@@ -339,6 +339,10 @@ struct ResidualOut {       // optional per-point outputs (config 2 / lk_residual
     // bucket comes in voxel order (pcl::VoxelGrid's output order, or lk_batch_sort_by_voxel_dev's), so that eighth is one slab of the map: the
     // plane records an XCD's 4 MB L2 has to hold are an eighth of the map's instead of all of them.  0: the plain 2-D grid (tile, slot).
     int xmap_slots = 0;
+    // lk_residual_kernel only: the library's voxel-ordered copy of the caller's batch (lk_batch_order, legkilo_hip.hip).  alt_use[1] != 0 - decided on the
+    // device by lk_batch_stamp_kernel just ahead of this launch: the caller's buffer still holds what the copy was made from - reads the copy.
+    const lk_point* alt_pts = nullptr;
+    const unsigned long long* alt_use = nullptr;
 };
 // What a speculative residual pass (the pipelined stream path) remembers of a point's two root lookups, so that the verify pass
 // can tell whether an insert that ran beside it may have changed the point's result: a root id (>= 0), or - the lookup found no
@@ -597,6 +601,7 @@ __global__ void LK_RES_BOUNDS
     const int lane = tid & 63, wv = tid >> 6;
     BucketConst bc;
     load_bucket_const<false>(&filters[slot], pr, bc);
+    if (out.alt_use && out.alt_use[1] != 0ull) pts = out.alt_pts;   // wave-uniform (scalar load): the voxel-ordered copy of the same scans
     const double acc = residual_tile<EMIT_ROWS, GRID, XID, false, SPEC>(map, pr, bc, reinterpret_cast<const float4*>(pts + (size_t)slot * pts_slot_stride),
                                                 bx * LK_RB + tid, n, &stage[wv][0], lane, out, (size_t)slot * out_slot_stride);
     if (!EMIT_ROWS && lane < LK_NPART) {

@@ -975,6 +975,55 @@ def test_batch_sort_by_voxel(scene, oracle_lib, hip_lib):
         xg, _ = g.get_state(slot=s)
         assert (po.n_buckets, po.n_updates, po.n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
         assert np.allclose(xo, xg, rtol=1e-8, atol=1e-9), (s, np.abs(xo - xg).max())
+    # ---- the implicit path (lk_batch_order, default LK_BATCH_ORDER_AUTO): the batch entries themselves keep a voxel-ordered copy of a batch that comes back
+    def replays(buf, x_, P_, n):
+        out = []
+        for _ in range(n):
+            g.batch_set_priors(x_, P_)
+            p_ = g.batch_replay_dev(buf, S, n_pts, 0.0, off, dt)
+            X_, _ = g.batch_get_states(0, S)
+            out.append((p_, X_))
+        return out
+
+    X_sorted, _ = g.batch_get_states(0, S)
+    xa, Pa = np.array(xs), np.array(Ps)
+    assert g.batch_order_stats() == (0, 0, 0)          # one replay of d_out so far: only its stamp was taken
+    for p_, X_ in replays(d_out, xa, Pa, 3):             # replayed unchanged twice -> examined at the third: already in voxel order, no copy
+        assert np.array_equal(X_, X_sorted)
+    assert g.batch_order_stats() == (1, 0, 0), g.batch_order_stats()
+    r_in = replays(d_in, xa, Pa, 4)                      # the RANDOM-order buffer: as given twice, then sorted once into the library's copy ...
+    assert g.batch_order_stats() == (2, 1, 0), g.batch_order_stats()
+    assert np.array_equal(r_in[0][1], r_in[1][1]) and not np.array_equal(r_in[0][1], X_sorted)
+    for p_, X_ in r_in[2:]:   # ... which is the order the explicit call produced (same keys, same priors, stable sort): the same bits
+        assert np.array_equal(X_, X_sorted), np.abs(X_ - X_sorted).max()
+        for s in range(S):
+            assert (p_[s].n_buckets, p_[s].n_updates, p_[s].n_effect) == (poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect), s
+    assert np.abs(r_in[0][1] - X_sorted).max() < 1e-9     # the same scans in another legal order: equal up to the order of sums
+    chk = np.empty_like(allpts)
+    g.d2h(chk, d_in)
+    assert np.array_equal(chk.view(np.uint8), allpts.view(np.uint8))     # the caller's buffer is never written
+    # new CONTENT in the sorted batch's buffer (the scans in reverse slot order): noticed on the device - that replay reads the buffer as given, correct at
+    # once -, counted again, sorted again at the third replay
+    rev = np.ascontiguousarray(np.concatenate(scans[::-1]))
+    g.h2d(d_in, rev)
+    xr, Pr = np.array(xs[::-1]), np.array(Ps[::-1])
+    want = []
+    for s in range(S):
+        o.set_state(xr[s], Pr[s])
+        o.set_times(0.0, 0.0)
+        po, _ = o.process_scan(rev[s * n_pts:(s + 1) * n_pts], 0.0)
+        want.append(((po.n_buckets, po.n_updates, po.n_effect), o.get_state()[0]))
+    for rnd, (p_, X_) in enumerate(replays(d_in, xr, Pr, 4)):
+        for s in range(S):
+            assert want[s][0] == (p_[s].n_buckets, p_[s].n_updates, p_[s].n_effect), (rnd, s)
+            assert np.allclose(want[s][1], X_[s], rtol=1e-8, atol=1e-9), (rnd, s, np.abs(want[s][1] - X_[s]).max())
+    assert g.batch_order_stats() == (3, 2, 1), g.batch_order_stats()
+    # LK_BATCH_ORDER_AS_GIVEN: nothing is looked at
+    g.batch_order(0)
+    replays(d_in, xr, Pr, 1)
+    g.batch_changed()
+    assert g.batch_order_stats() == (3, 2, 1)
+    g.batch_order(1)
     g.device_free(d_in)
     g.device_free(d_out)
     with pytest.raises(hip_lib.LegKiloError):   # buckets must cover the scan
@@ -1048,6 +1097,7 @@ def test_batch_replay_frozen_map(scene, oracle_lib, hip_lib, S):
         g2 = hip_lib.LegKiloHip(scene.cfg(n_slots=2 * S))
         g2.map_import(blob)
         g2.init_process_cov_q()
+        g2.batch_order(0)   # bit for bit against the synchronous replay above, which read the buffer as given (a batch that keeps coming back is otherwise replayed from its voxel-ordered copy)
         hx, hP = np.ascontiguousarray(np.array(xs)), np.ascontiguousarray(np.array(Ps).reshape(S, 900))
         d_x, d_P, d_pts2 = g2.device_malloc(hx.nbytes), g2.device_malloc(hP.nbytes), g2.device_malloc(allpts.nbytes)
         g2.h2d(d_x, hx)
@@ -1172,6 +1222,7 @@ def test_batch_replay_overlay_follows_the_map(scene, oracle_lib, hip_lib):
         return counts
 
     first = replay_and_check("young map")
+    assert len(g.overlay_export(0)) > 0   # an overlay refers to the map of its replay: exportable while that map stands ...
     # the handle's own map moves on: dense scans with insert through the stream path (and through the oracle, only to keep its filter in step)
     for k in range(3):
         tb = t0 + 0.1 * (k + 1)
@@ -1179,7 +1230,11 @@ def test_batch_replay_overlay_follows_the_map(scene, oracle_lib, hip_lib):
         g.set_state(synth.initial_state(scene.traj, tb, scene.P), 1e-6 * np.eye(30))
         g.set_times(tb, tb)
         g.process_scan(pts, tb)
+        if k == 0:   # ... and refused (LK_ERR_STATE), not served from recycled base blocks, once the map has changed under it
+            with pytest.raises(RuntimeError, match="map has changed since the overlay replay"):
+                g.overlay_export(0)
     second = replay_and_check("after three more scans")
+    assert len(g.overlay_export(0)) > 0
     assert first != second, (first, second)
     print(f"overlay follows the map: n_effect {first} on the young map, {second} after three more scans with insert")
     g.device_free(d_pts)
@@ -1624,7 +1679,9 @@ def test_batch_replay_ragged(scene, oracle_lib, hip_lib, monkeypatch):
     d_pts = g.device_malloc(allpts.nbytes)
     g.h2d(d_pts, allpts)
     g.batch_set_priors(np.array(xs[:3]), np.array(Ps[:3]))
+    g.batch_order(0)   # both entries on the buffer AS GIVEN (the uniform entry would otherwise replay its voxel-ordered copy: same scans, another order of sums)
     g.batch_replay_dev(d_pts, 3, 4000, 0.0, off, dt)
+    g.batch_order(1)
     ref = [g.get_state(slot=s) for s in range(3)]
     g.batch_set_priors(np.array(xs[:3]), np.array(Ps[:3]))
     g.batch_replay_ragged_dev(d_pts, g.ragged_tables([0, 4000, 8000, 12000], [off] * 3, [dt] * 3, [0.0] * 3))
