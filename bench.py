@@ -423,6 +423,14 @@ def main():
     d_x = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
     d_P = torch.from_numpy(np.ascontiguousarray(Ps)).to(dev)
     torch.cuda.synchronize()
+    # once per loaded batch, like the upload above: the library puts every bucket of the batch into root-voxel order in a copy of its own
+    # (lk_batch_prepare_dev; a caller who does not ask gets the same at the batch's third replay - lk_batch_order).  The order INSIDE a time bucket is
+    # left open by the reference (KILO.cc:369); with this step `value` no longer depends on the order the generator happens to emit.
+    g.batch_set_priors_dev(d_x.data_ptr(), d_P.data_ptr(), S)
+    g.synchronize()
+    tpz = time.perf_counter()
+    g.batch_prepare_dev(d_batch.data_ptr(), S, N_PTS, off)
+    batch_prepare_ms = (time.perf_counter() - tpz) * 1e3
 
     # Batches are enqueued back to back (lk_batch_replay_async_dev), alternating between two sets of filter slots and two
     # streams so that the update kernels of one batch overlap the residual launches of the next: every step still delivers
@@ -504,9 +512,10 @@ def main():
     # 128-scan batches (three in flight, rotating over three slot ranges / streams) - what a GPU of the 8-GPU run executes per step.
     if S >= 128:
         S8 = 128
+        ring8 = max(1, min(3, (max(2, args.in_flight) * S_max) // S8))   # slot ranges the 128-scan batches rotate over (a 128-scan rank has 256 slots: two)
 
         def step8(k):
-            g.batch_replay_async_dev(d_batch.data_ptr(), (k % 3) * S8, S8, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(), d_P900=d_P.data_ptr(),
+            g.batch_replay_async_dev(d_batch.data_ptr(), (k % ring8) * S8, S8, N_PTS, 0.0, off, dt, d_x36=d_x.data_ptr(), d_P900=d_P.data_ptr(),
                                      host_out_ptr=ring[k % ring_rows].data_ptr())
         n8 = 8 * max(args.steps, 10)
         for k in range(max(args.warmup, 6)):
@@ -541,10 +550,12 @@ def main():
     # bucket, in voxel-grid cell order (synth.dense_scan(layout="cell"): the order pcl::VoxelGrid leaves its output in, KILO.cc:356-360), which
     # puts neighbouring lanes into neighbouring voxels; a recorded scan that was not voxel-filtered has no such order.
     shuf = None
+    shuf_auto = None
     resorted = None
     if rank == 0 and world_size == 1 and args.shuffle_check > 0 and not args.shuffle_main:
         d_shuf = shuffled_in_bucket(d_batch, 4242)
         torch.cuda.synchronize()
+        g.batch_order(0)   # LK_BATCH_ORDER_AS_GIVEN: what the random order costs when the library is told to leave the batch alone
         for k in range(max(args.warmup, 3)):
             step(k, d_shuf.data_ptr())
         finish(min(max(args.warmup, 3), ring_rows))
@@ -573,6 +584,30 @@ def main():
             except Exception as e:  # noqa: BLE001
                 warnings.append(f"profiles/latest_shuffled_pmc.json unreadable: {e}")
         shuf = (sh_host, sh_last)
+        g.batch_order(1)
+        # ... and the SAME buffer under the library's default (LK_BATCH_ORDER_AUTO), nothing prepared by the caller: the first replays run as given, the
+        # third makes the voxel-ordered copy (inside the warm-up steps), the timed steps read it
+        try:
+            g.batch_changed()
+            n_warm_auto = max(args.warmup, 8)
+            for k in range(n_warm_auto):
+                step(k, d_shuf.data_ptr())
+            finish(min(n_warm_auto, ring_rows))
+            sync_all()
+            ts = time.perf_counter()
+            for k in range(args.steps):
+                step(k, d_shuf.data_ptr())
+            finish(args.steps)
+            sync_all()
+            el_au = time.perf_counter() - ts
+            au_last = ring[(args.steps - 1) % ring_rows][: S * pose_sz].numpy().view(_abi.pose_dtype()).copy()
+            extra["shuffled_auto_ms_per_step"] = round(el_au / args.steps * 1e3, 3)
+            extra["shuffled_auto_over_headline"] = round((el_au / args.steps) / (elapsed / args.steps), 3)
+            extra["shuffled_auto_order_stats"] = dict(zip(("examined", "sorted", "stale"), g.batch_order_stats()))
+            shuf_auto = (sh_host, au_last)
+        except Exception as e:  # noqa: BLE001
+            extra["shuffled_auto_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+            warnings.append("auto-ordered replay of the shuffled batch failed: " + extra["shuffled_auto_error"])
         # ... and what it costs to put such a batch back into voxel order on the device (lk_batch_sort_by_voxel_dev: root-voxel key under the slot's
         # PRIOR pose, stable segmented radix sort of every bucket, one gather; once per loaded batch, not per replay), and the step on it
         try:
@@ -807,9 +842,15 @@ def main():
             warnings.append("config-2 rows launch failed: " + extra["config2_error"])
 
     extra["ramp_steps_before_warmup"] = args.ramp_steps
+    extra["batch_prepare_ms_once"] = round(batch_prepare_ms, 2)
+    extra["batch_order_stats"] = dict(zip(("examined", "sorted", "stale"), g.batch_order_stats()))
     extra.update({"map_bytes": int(map_bytes), "map_roots": n_roots, "map_nodes": n_nodes, "map_build_s": round(map_build_s, 2),
-                  "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok, "rccl_map_broadcast_ms": bcast_ms,
-                  "rccl_map_scatter_allgather_ms": bcast2_ms})
+                  "generate_s": round(gen_s, 1), "gen_workers": workers, "mean_n_effect": n_eff, "pose_gather_ok": gather_ok,
+                  # the transport the two timings belong to: "nccl" = RCCL over xGMI (one GPU per rank - the driver's multi-GPU runs); "gloo" = the
+                  # single-box self-test hook (LEGKILO_BENCH_BACKEND=gloo: several ranks share one GPU, the collectives go through host memory)
+                  "collective_backend": None if dist is None else str(dist.get_backend()),
+                  "map_broadcast_ms": bcast_ms, "map_scatter_allgather_ms": bcast2_ms,
+                  "ranks_sharing_one_gpu": bool(os.environ.get("LEGKILO_BENCH_SHARE_GPU") == "1") if dist is not None else None})
     # ---- extra: the same batch step when the scans start in (pinned) host memory: upload of batch k+1 on a copy stream under
     # the replay of batch k (the boundary also takes host buffers; this rate is never `value`)
     if rank == 0 and world_size == 1 and not args.no_pcie:
@@ -1159,6 +1200,18 @@ def main():
                 sh_dpos = max(sh_dpos, float(np.abs(np.array(pose.pos) - sl_["pos"]).max()))
             parity["shuffled_in_bucket"] = {"n": len(sh_host), "counts_equal": sh_eq, "max_pos_delta_m": sh_dpos, "tolerance_m": 1e-7}
             parity["ok"] = bool(parity["ok"] and sh_dpos <= 1e-7 and sh_eq >= len(sh_host) - max(1, len(sh_host) // 50))
+        if shuf_auto is not None:   # the shuffled buffer replayed from the library's own voxel-ordered copy: the oracle on the scans as the CALLER gave them
+            sh_host, au_last = shuf_auto
+            au_eq, au_dpos = 0, 0.0
+            for s_ in range(min(len(sh_host), 8)):
+                o.set_state(xs[s_], Ps[s_])
+                o.set_times(0.0, 0.0)
+                pose, _ = o.process_scan(sh_host[s_], 0.0, with_sort=True)
+                sl_ = au_last[s_]
+                au_eq += int((int(pose.n_buckets), int(pose.n_updates), int(pose.n_effect)) == (int(sl_["n_buckets"]), int(sl_["n_updates"]), int(sl_["n_effect"])))
+                au_dpos = max(au_dpos, float(np.abs(np.array(pose.pos) - sl_["pos"]).max()))
+            parity["shuffled_auto"] = {"n": min(len(sh_host), 8), "counts_equal": au_eq, "max_pos_delta_m": au_dpos, "tolerance_m": 1e-7}
+            parity["ok"] = bool(parity["ok"] and au_dpos <= 1e-7 and au_eq >= min(len(sh_host), 8) - 1)
         if resorted is not None:   # the device-sorted batch: the oracle replays the scans as lk_batch_sort_by_voxel_dev left them
             rs_host, rs_last = resorted
             rs_eq, rs_dpos = 0, 0.0

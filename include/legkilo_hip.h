@@ -324,6 +324,9 @@ int lk_batch_sort_by_voxel_dev(lk_handle* h, const lk_point* d_in, lk_point* d_o
 #define LK_BATCH_ORDER_AUTO 1
 int lk_batch_order(lk_handle* h, int mode);
 int lk_batch_changed(lk_handle* h);
+/* For a caller who KNOWS a batch will be replayed many times: examine it and make the voxel-ordered copy now, under the priors of slots [0, n_scans)
+ * (lk_batch_set_priors(_dev) first), instead of at its third replay.  Synchronous; once per loaded batch (works in either mode). */
+int lk_batch_prepare_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets);
 /* out3 = { batches examined (replayed unchanged often enough), of those sorted into a copy, sorted batches whose buffer later held other content } since lk_create */
 int lk_batch_order_stats(lk_handle* h, uint64_t* out3);
 int lk_batch_replay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin,

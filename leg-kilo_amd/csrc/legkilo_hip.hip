@@ -3239,9 +3239,11 @@ static uint64_t hash_offsets(const uint32_t* off, size_t n) {
 // Which buffer the residual launches of a frozen-map batch replay read.  `st`: the stream the slots' priors were armed on and the batch will run on.
 // Fills ro->alt_pts / alt_use (null: the caller's buffer as given).  One small launch per call; the call that makes the copy synchronises.
 static int batch_ordered(lk_handle* h, const lk_point* d_pts, uint32_t first_slot, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets,
-                         hipStream_t st, ResidualOut* ro) {
+                         hipStream_t st, ResidualOut* ro, bool now = false) {
+    ResidualOut none;
+    if (!ro) ro = &none;
     ro->alt_pts = nullptr, ro->alt_use = nullptr;
-    if (h->batch_order_mode == 0 || n_scans * n_pts < 4096 || n_scans * n_pts >= ((size_t)1 << 32)) return LK_OK;
+    if ((h->batch_order_mode == 0 && !now) || n_scans * n_pts < 4096 || n_scans * n_pts >= ((size_t)1 << 32)) return LK_OK;
     const uint64_t oh = hash_offsets(bucket_off, n_buckets);
     lk_handle::OrdEntry* e = nullptr;
     for (auto& c : h->ord)
@@ -3269,7 +3271,7 @@ static int batch_ordered(lk_handle* h, const lk_point* d_pts, uint32_t first_slo
         e->have_copy = false;
         ++h->ord_stale;
     }
-    if (!e->have_copy && seen >= (unsigned int)h->batch_order_after && seen < LK_ORD_SORTED) {
+    if (!e->have_copy && (now || seen >= (unsigned int)h->batch_order_after) && seen < LK_ORD_SORTED) {
         // the same content has been replayed often enough to be worth 5.6 ms: examine it, and unless it already is in voxel order, sort it into the copy
         ++h->ord_examined;
         HIPCHK(h, hipStreamSynchronize(st));   // the priors are armed
@@ -3336,6 +3338,18 @@ int lk_batch_order(lk_handle* h, int mode) {
     CHECK_H(h);
     if (mode != 0 && mode != 1) return fail(h, LK_ERR_INVALID, "mode must be LK_BATCH_ORDER_AS_GIVEN (0) or LK_BATCH_ORDER_AUTO (1)");
     h->batch_order_mode = mode;
+    return LK_OK;
+}
+int lk_batch_prepare_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, const uint32_t* bucket_off, size_t n_buckets) {
+    CHECK_H(h);
+    if (!d_pts || !bucket_off) return fail(h, LK_ERR_INVALID, "null argument");
+    if (n_scans == 0 || n_scans > h->cfg.n_slots || n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty batch, or n_scans exceeds n_slots");
+    if (bucket_off[0] != 0 || bucket_off[n_buckets] != n_pts) return fail(h, LK_ERR_INVALID, "bucket_off must cover the scan: bucket_off[0] == 0, bucket_off[n_buckets] == n_pts");
+    int rc = join_side_streams(h);
+    if (rc) return rc;
+    rc = batch_ordered(h, d_pts, 0, n_scans, n_pts, bucket_off, n_buckets, h->stream, nullptr, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return LK_OK;
 }
 int lk_batch_changed(lk_handle* h) {
