@@ -7,7 +7,7 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05b}
 COMMIT=${2:-unknown}
-BASE="--cpu-sample 0 --config1-scans 0 --no-pcie --sustained-s 0 --overlay-scans 0 --shuffle-check 0 --cache-dir /tmp/lkcache"
+BASE="--cpu-sample 0 --config1-scans 0 --config2-scans 0 --config4-scans 0 --no-pcie --sustained-s 0 --overlay-scans 0 --shuffle-check 0 --cache-dir /tmp/lkcache"
 cd $REPO
 COMMON="$BASE" bash tools/gpu_prof_r03.sh $TAG "stats fetch write sq1 sq2 sq3 tcc" $COMMIT
 cp gpurun_out/profiles_$TAG/latest_pmc.json gpurun_out/latest_pmc_$TAG.json 2>/dev/null
