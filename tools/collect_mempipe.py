@@ -45,7 +45,9 @@ def main():
             for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r["Kernel_Name"]
-                    if ("lk_residual_kernel<false, 1" in k or "lk_residual_kernel<(bool)0, 1" in k) and int(float(r.get("Grid_Size") or 0)) == FULL_GRID:
+                    gx, gy = int(float(r.get("Grid_Size_X") or 0)), int(float(r.get("Grid_Size_Y") or 0))   # the kernel trace lists the grid per dimension
+                    full = (gx * max(gy, 1) == FULL_GRID) if gx else (int(float(r.get("Grid_Size") or 0)) == FULL_GRID)
+                    if ("lk_residual_kernel<false, 1" in k or "lk_residual_kernel<(bool)0, 1" in k) and full:
                         durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
         if not acc:
             continue
