@@ -129,7 +129,7 @@ __device__ __forceinline__ void eval_plane(const lk_match_rec* __restrict__ mr, 
 #if LK_ROWS_AT_TAKE
         // the row in its final form [h z | h/R | R 1] right here: nothing is read back from LDS before the reduction
         const double Rv = pr.lidar_ratio * sig_r;   // KILO.cc:205-206
-        const double ri = lk_inv(Rv);
+        const double ri = lk_inv_nodecision(Rv);   // scales the row for the sums A = sum h h^T / R, b = sum h z / R: no gate reads it
         r[7] = t.w.x * ri, r[8] = t.w.y * ri, r[9] = t.w.z * ri;
         r[10] = n.x * ri, r[11] = n.y * ri, r[12] = n.z * ri;
         r[13] = Rv;
