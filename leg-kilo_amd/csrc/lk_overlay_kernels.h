@@ -729,6 +729,121 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
     }
 }
 
+// Round 6: the same fit by a GROUP of eight lanes.  One lane per fit walks the leaf's <= 50 points one after the other - 34 of the 129 us of GPU
+// time a bucket index of the recorded-run batch costs (1 024 slots x one or two fits: a latency chain), and in the uniform batch the lanes of a wave
+// each read their own 72-B records (2.6 of 17.9 ms).  Here a wave first finds the real jobs among its 64 job slots (most are empty: a slot per touched
+// root and inline group), then takes them eight at a time: lane `sub` of a group handles points sub, sub + 8, ... - eight consecutive 72-B records per
+// step, 576 contiguous bytes -, the fifteen running sums are combined over the group with three exchange steps, and the group's first lane commits.
+// Another order of the same sums than the one-lane loop (as that one already was against the 21-sum form): the same value to rounding.
+#ifndef LK_FIT_GROUP
+#define LK_FIT_GROUP 8
+#endif
+__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_group_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    __shared__ int owner[LK_WAVE * 5];
+    const unsigned int slot = blockIdx.y;
+    const LkMap pm = ov_slot_map(ov, slot);
+    if (pm.counters[LK_CTR_ERR]) return;
+    const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
+    const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;   // entry [g][t]: inline leaf group g of touched root t
+    const int lane = threadIdx.x, sub = lane & (LK_FIT_GROUP - 1), grp = lane / LK_FIT_GROUP;
+    const int total = n_touched * LK_INLINE_GROUPS;
+    for (int i0 = blockIdx.x * LK_WAVE; i0 < total; i0 += gridDim.x * LK_WAVE) {   // wave-uniform
+        const int i = i0 + lane;
+        int4 hd = make_int4(0, 0, 0, 0);
+        int2 bs = make_int2(0, 0);
+        if (i < total) {
+            const int g = i / n_touched, t = i - g * n_touched;
+            const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
+            hd = *reinterpret_cast<const int4*>(job);
+            if (hd.z > 0 && hd.w != 0) bs = make_int2(job->base_block, job->n_base);
+        }
+        const bool has = hd.z > 0 && hd.w != 0;   // ("not a plane" events ended in lk_ov_fit_eig_kernel)
+        const unsigned long long m = __ballot(has);
+        const int njobs = __popcll(m);
+        if (has) {   // the real jobs of this round, in slot order: {leaf, block, points, base block, points in it}
+            const int rk = __popcll(m & ((1ull << lane) - 1ull));
+            owner[rk * 5 + 0] = hd.x, owner[rk * 5 + 1] = hd.y, owner[rk * 5 + 2] = hd.z, owner[rk * 5 + 3] = bs.x, owner[rk * 5 + 4] = bs.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r0 = 0; r0 < njobs; r0 += LK_WAVE / LK_FIT_GROUP) {   // wave-uniform
+            const int k = r0 + grp;
+            const bool act = k < njobs;
+            const int* jr = &owner[(act ? k : 0) * 5];
+            const int root = jr[0], block = jr[1], cnt = act ? jr[2] : 0, base_block = jr[3], n_base = jr[4];
+            PlaneFit fit;
+            {
+                const lk_plane_rec* pl = &pm.planes[root];   // (an idle group reads its slot's first job's record: valid memory, never used)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fit.c[c] = pl->center[c], fit.vmin[c] = pl->normal[c], fit.vmid[c] = pl->plane_var[c], fit.vmax[c] = pl->plane_var[3 + c];
+                fit.emin = pl->plane_var[6], fit.emid = pl->plane_var[7], fit.emax = pl->plane_var[8];
+            }
+            fit.is_plane = true;
+            const int cn = cnt > 0 ? cnt : 1;
+            const double invA = 1.0 / (cn * (fit.emin - fit.emid)), invB = 1.0 / (cn * (fit.emin - fit.emax));
+            const double invn = 1.0 / cn;
+            const lk_pt_rec* __restrict__ bp = pm.blocks[block].pts;
+            const lk_pt_rec* __restrict__ bb = n_base > 0 ? base.blocks[base_block].pts : bp;
+            double sm[15];   // sa (3), sb (3), saa, sab, sbb, sV (6)
+#pragma unroll
+            for (int q = 0; q < 15; ++q) sm[q] = 0.0;
+#pragma unroll 1
+            for (int j = sub; j < cnt; j += LK_FIT_GROUP) {
+                double pw[3], var[6];
+                const lk_pt_rec* __restrict__ pj = (j < n_base ? bb : bp) + j;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pw[c] = pj->pw[c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) var[c] = pj->var[c];
+                const double q0 = pw[0] - fit.c[0], q1 = pw[1] - fit.c[1], q2 = pw[2] - fit.c[2];
+                const double dmin = q0 * fit.vmin[0] + q1 * fit.vmin[1] + q2 * fit.vmin[2];
+                const double dmid = (q0 * fit.vmid[0] + q1 * fit.vmid[1] + q2 * fit.vmid[2]) * invA;
+                const double dmax = (q0 * fit.vmax[0] + q1 * fit.vmax[1] + q2 * fit.vmax[2]) * invB;
+                const double dmA = dmin * invA, dmB = dmin * invB;
+                double FA[3], FB[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) FA[c] = dmid * fit.vmin[c] + dmA * fit.vmid[c], FB[c] = dmax * fit.vmin[c] + dmB * fit.vmax[c];
+                const double a0 = var[0] * FA[0] + var[1] * FA[1] + var[2] * FA[2], a1 = var[1] * FA[0] + var[3] * FA[1] + var[4] * FA[2],
+                             a2 = var[2] * FA[0] + var[4] * FA[1] + var[5] * FA[2];
+                const double b0 = var[0] * FB[0] + var[1] * FB[1] + var[2] * FB[2], b1 = var[1] * FB[0] + var[3] * FB[1] + var[4] * FB[2],
+                             b2 = var[2] * FB[0] + var[4] * FB[1] + var[5] * FB[2];
+                sm[0] += a0, sm[1] += a1, sm[2] += a2, sm[3] += b0, sm[4] += b1, sm[5] += b2;
+                sm[6] += FA[0] * a0 + FA[1] * a1 + FA[2] * a2;
+                sm[7] += FA[0] * b0 + FA[1] * b1 + FA[2] * b2;
+                sm[8] += FB[0] * b0 + FB[1] * b1 + FB[2] * b2;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) sm[9 + c] += var[c];
+            }
+            // the group's eight partial sums, in a fixed order (xor 1, 2, 4): every lane of the group ends with the total
+#pragma unroll
+            for (int q = 0; q < 15; ++q) {
+#pragma unroll
+                for (int w = 1; w < LK_FIT_GROUP; w <<= 1) sm[q] += __shfl_xor(sm[q], w, LK_WAVE);
+            }
+            if (act && sub == 0) {
+                double acc21[21];
+                int kk = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int cc = r; cc < 3; ++cc)
+                        acc21[kk++] = fit.vmid[r] * fit.vmid[cc] * sm[6] + (fit.vmid[r] * fit.vmax[cc] + fit.vmax[r] * fit.vmid[cc]) * sm[7] + fit.vmax[r] * fit.vmax[cc] * sm[8];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) acc21[kk++] = (fit.vmid[r] * sm[cc] + fit.vmax[r] * sm[3 + cc]) * invn;
+                }
+                const double invn2 = invn * invn;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc21[15 + c] = sm[9 + c] * invn2;
+                plane_commit<true>(&pm.planes[root], &pm.match[root], fit, acc21, cnt);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // owner[] is rewritten by the next round
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ---------------------------------------------------------------- the root pass of the batch replay, FAST PATH (round 5)
 // Nearly every touched root of a batch bucket is a leaf that takes its few new points (in input order), maybe passes a refit event or
 // two, maybe freezes.  The generic pass (dev_insert_root<.., OV>) spends its time - 168 VGPRs, three waves per SIMD, 5.5 GB per launch -
