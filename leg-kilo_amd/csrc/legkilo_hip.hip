@@ -928,6 +928,109 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
     if (lane == 0) f->last_update_t = t_upd, f->last_predict_t = t_pred;
 }
 
+// Round 6: the FRONT of a bucket index of the ragged batch with insert as ONE launch when every bucket holds <= LK_SCAN_WAVE_MAX points (a recorded
+// scan's 2 ms bins): lk_rag_advance_kernel (messages + predict), lk_ov_residual_kernel, lk_update_wave_ragged_kernel, lk_ov_begin_kernel and
+// lk_ov_reproject_kernel were five one-wave-per-scan launches, each paying a launch boundary (~5 us for 1 024 one-wave workgroups whatever they do) and
+// its own load / store of the filter's 7.6 KB.  Here one wave per scan runs the five bodies back to back - the one-wave filter cores and the tile code
+// of dev_scan_wave, the overlay lookup of lk_ov_residual_kernel - with state and covariance in LDS from the first message to the update.  Same device
+// functions, same order of sums (tile totals in tile order, as lk_update_wave_kernel adds up to eight of them): bit-identical to the five launches
+// (test_batch_replay_overlay_ragged compares both against the oracle; LEGKILO_RAG_FUSE=0 is the A/B).
+extern "C++" {
+template <bool XID>
+__global__ void __launch_bounds__(LK_WAVE, 2)
+    lk_rag_ov_front_kernel(LkMap base, LkOverlay ov, LkParams pr, LkFilter* filters, const double* __restrict__ Q, LkRagged rg, const lk_point* __restrict__ d_pts,
+                           int b, int msg_kind) {
+    __shared__ WaveSmem sm;
+    __shared__ double rows[64 * LK_ROW2];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const LkMap pm = ov_slot_map(ov, (unsigned int)slot);
+    if (b >= rag_nb(rg, slot)) {   // this scan has run out of buckets: the passes behind this one must find its work lists empty (lk_ov_begin_kernel ran for every slot)
+        dev_bucket_begin_wave(pm);
+        return;
+    }
+    LkFilter* f = &filters[slot];
+    const double* T = rag_t(rg, slot);
+    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
+    if (lane < 36) sm.x[lane] = f->x[lane];
+    double t_upd = f->last_update_t, t_pred = f->last_predict_t;
+    __syncthreads();
+    const double tb = T[b];
+    if (msg_kind) {   // lk_rag_advance_kernel: the scan's messages stamped before this bucket that no earlier bucket has consumed (KILO.cc:379-390)
+        const size_t mstride = msg_kind == 2 ? 33 : 7;
+        const unsigned int q0 = rg.imu_off[slot], q1 = rg.imu_off[slot + 1];
+        for (unsigned int q = q0; q < q1; ++q) {
+            const double* m = rg.imu + mstride * (size_t)q;
+            const double tm = m[0];
+            if (!(tm < tb)) break;
+            if (b > 0 && tm < T[b - 1]) continue;
+            wave_predict_core(sm, Q, tm - t_upd, tm - t_pred, lane, rg.q_diag != 0);
+            t_pred = tm;
+            if (msg_kind == 2) wave_kin_update_core(sm, rows, m, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
+            else wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
+            t_upd = tm;
+        }
+    }
+    wave_predict_core(sm, Q, tb - t_upd, tb - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115
+    t_pred = tb;
+    // lk_ov_residual_kernel: the bucket's tiles against base map + the scan's overlay, under the predicted state in LDS
+    const unsigned long long* po = rag_pt_off(rg, slot);
+    const lk_point* pts = d_pts + po[b];
+    const int n = (int)(po[b + 1] - po[b]);
+    BucketConst bc;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bc.R[i] = sm.x[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc.p[i] = sm.x[9 + i];
+    {
+        const double* P = sm.P;
+        bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
+        bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
+    }
+    LkOvView ovv;
+    ovv.keys = ov.keys + (size_t)slot * ov.hash_cap;
+    ovv.hash_mask = ov.hash_cap - 1;
+    ovv.match = ov.match + (size_t)slot * ov.nodes_cap;
+    ovv.nodes = ov.nodes + (size_t)slot * ov.nodes_cap;
+    ovv.bits = ov.bits + (size_t)slot * ov.bit_words;
+    ResidualOut ro;
+    ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = nullptr, ro.ids = nullptr;
+    double totv = 0.0;   // tot[j] in lanes 0..31
+    for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
+        __builtin_amdgcn_wave_barrier();   // the previous tile's reads of the rows are complete
+        const double a = residual_tile<false, 3, XID, true, false>(base, pr, bc, reinterpret_cast<const float4*>(pts), i0 + lane, n, rows, lane, ro, (size_t)0, &ovv);
+        totv += (lane < 29) ? a : 0.0;
+    }
+    // lk_update_wave_ragged_kernel (update_only): the posterior the insert reads
+    const int N = (int)(lane_bcast<28>(totv) + 0.5);
+    if (lane == 0) {
+        f->last_predict_t = t_pred;
+        f->n_buckets += 1;
+        f->last_N = N;
+        f->updated = N > 0;
+        if (N > 0) {
+            f->n_updates += 1;
+            f->n_effect += (unsigned long long)N;
+        }
+        f->last_update_t = N > 0 ? tb : t_upd;   // KILO.cc:212
+    }
+    if (N > 0) wave_update_core(sm, totv, N, lane);
+    __syncthreads();
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+    if (lane < 36) f->x[lane] = sm.x[lane];
+    // the re-projection below reads the posterior through the filter record, like every other kernel of the insert - written by THIS wave: its stores
+    // have to be acknowledged before its loads go out (workgroup scope = s_waitcnt; an agent-scope fence here is an L2 write-back + invalidate per
+    // wave, 1 024 of them per launch: the first version of this kernel was 6 ms SLOWER than the five launches for it)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    // lk_ov_begin_kernel, lk_ov_reproject_kernel
+    dev_bucket_begin_wave(pm);
+    for (int i = lane; i < n; i += LK_WAVE) {
+        const int r = ov_reproject_point(base, ov, pr, filters, pts, i, (unsigned int)slot);
+        ov.ptroot[(size_t)slot * ov.scan_cap + i] = r;   // for lk_ov_point_geom_kernel
+    }
+}
+}   // extern "C++"
+
 __global__ void __launch_bounds__(LK_WAVE, 2)
     lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
                         const double* __restrict__ Q) {
@@ -4308,11 +4411,17 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
             const int nb = std::max(1, max_n ? max_n[b] : biggest);
             const int nblk = (nb + LK_RB - 1) / LK_RB;
             const LkPtSrc src = {d_pts, 0, 0, rg.pt_off, rg.nb, rg.ldb, (int)b};
-            LAUNCH(h, "rag_advance", hipLaunchKernelGGL(lk_rag_advance_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_Q, rg, (int)b, msg_kind));
-            LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, h->d_partials, h->part_stride));
-            LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, (int)b, 1));
-            LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
-            LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
+            static const bool rag_fuse = getenv("LEGKILO_RAG_FUSE") == nullptr || atoi(getenv("LEGKILO_RAG_FUSE")) != 0;   // 0: the five launches (A/B, and the bit-identity reference)
+            if (rag_fuse && biggest <= LK_SCAN_WAVE_MAX) {
+                const auto front = (h->pr.ext_identity && xid_enable) ? lk_rag_ov_front_kernel<true> : lk_rag_ov_front_kernel<false>;
+                LAUNCH(h, "rag_ov_front", hipLaunchKernelGGL(front, dim3(S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, h->d_Q, rg, d_pts, (int)b, msg_kind));
+            } else {
+                LAUNCH(h, "rag_advance", hipLaunchKernelGGL(lk_rag_advance_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_Q, rg, (int)b, msg_kind));
+                LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, h->d_partials, h->part_stride));
+                LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, (int)b, 1));
+                LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
+                LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
+            }
             const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
             LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel<true>, dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
             LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, S), dim3(256), 0, st, ov, h->pr, fl, src));
