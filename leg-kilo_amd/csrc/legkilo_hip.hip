@@ -4423,9 +4423,13 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
                 LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
             }
             const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
-            LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel<true>, dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
-            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, S), dim3(256), 0, st, ov, h->pr, fl, src));
-            LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(std::max(1, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+            if (rag_fuse && biggest <= LK_SCAN_WAVE_MAX) {
+                LAUNCH(h, "ov_mid", hipLaunchKernelGGL(lk_ov_mid_kernel<true>, dim3(S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
+            } else {
+                LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel<true>, dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
+                LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, S), dim3(256), 0, st, ov, h->pr, fl, src));
+                LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(std::max(1, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
+            }
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL((lk_ov_insert_root_kernel<3, true>), dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
             LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, ov, h->pr));
             static const bool fit_group_r = getenv("LEGKILO_OV_FIT_GROUP") == nullptr || atoi(getenv("LEGKILO_OV_FIT_GROUP")) != 0;

@@ -452,14 +452,14 @@ __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base,
 // pass keeps matching the base grid cell (the bit is set by the root pass when it refits the leaf or hands the root to the generic pass, which
 // also gets the match record made first); the sums are read from the base map's (LK_PAD_SUMSRC).  35 -> 15 memory requests per new root.
 template <bool LEAN>
-__global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, LkOverlay ov, LkParams pr) {
-    const unsigned int slot = blockIdx.y;
+__device__ __forceinline__ void ov_materialise_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot_, const int bx_, const int gx_, const int tid_) {
+    const unsigned int slot = slot_;
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
     const unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
     unsigned int* bits = ov.bits + (size_t)slot * ov.bit_words;
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * LK_MB) >> 6);
+    const int lane = tid_ & 63;
+    const int wave = (int)((bx_ * LK_MB + tid_) >> 6), nwaves = (int)((gx_ * LK_MB) >> 6);
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     for (int t0 = wave * LK_WAVE; t0 < n_touched; t0 += nwaves * LK_WAVE) {
         const int tt = t0 + lane;
@@ -593,6 +593,10 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
         const int n_new = __popcll(__ballot(need));
         if (lane == 0 && n_new) atomicAdd(&pm.counters[LK_CTR_ROOTS], (unsigned int)n_new);
     }
+}
+template <bool LEAN>
+__global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    ov_materialise_body<LEAN>(base, ov, pr, blockIdx.y, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------- the plane fits of the root pass, ONE LANE PER FIT
@@ -942,9 +946,9 @@ __global__ void __launch_bounds__(256) lk_ov_base_sums_kernel(LkMap base, unsign
 //                            counters, refit events decided from prefix sums, freeze, the fit job, the sums.  Whatever is not a root leaf
 //                            that appends / refits / freezes goes to the generic wave-per-root pass as it was found (map.heavy).
 // Per root the second kernel issues ~40 small memory requests and a few hundred lane-instructions: 64 roots per wave instead of one.
-__global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const unsigned int slot = blockIdx.y;
+__device__ __forceinline__ void ov_point_geom_body(const LkOverlay& ov, const LkParams& pr, const LkFilter* __restrict__ filters, const LkPtSrc& src, const unsigned int slot_, const int bx_, const int tid_) {
+    const int i = bx_ * 256 + tid_;
+    const unsigned int slot = slot_;
     const lk_point* pts;
     const int n = ov_pt_src(src, slot, &pts);
     if (i >= n) return;
@@ -969,8 +973,11 @@ __global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkP
     d->var[0] = gm.var.xx, d->var[1] = gm.var.xy, d->var[2] = gm.var.xz;
     d->var[3] = gm.var.yy, d->var[4] = gm.var.yz, d->var[5] = gm.var.zz;
 }
-__global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
-    const unsigned int slot = blockIdx.y;
+__global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
+    ov_point_geom_body(ov, pr, filters, src, blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+}
+__device__ __forceinline__ void ov_root_lane_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot_, const int bx_, const int gx_, const int tid_) {
+    const unsigned int slot = slot_;
     const LkMap map = ov_slot_map(ov, slot);
     if (map.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
@@ -978,7 +985,7 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
     const size_t job_stride = ov.hash_cap;
     LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
     const int thr = pr.layer_init_num[0];
-    for (int t = blockIdx.x * LK_WAVE + threadIdx.x; t < n_touched; t += gridDim.x * LK_WAVE) {
+    for (int t = bx_ * LK_WAVE + tid_; t < n_touched; t += gx_ * LK_WAVE) {
         const int root = map.touched[t];
         lk_node_rec* nd = &map.nodes[root];
         const int4 cnt = reinterpret_cast<const int4*>(nd)[4];   // npts, new_points, state, block
@@ -1090,6 +1097,30 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
             jb->cnt = 0;
         }
     }
+}
+__global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    ov_root_lane_body(base, ov, pr, blockIdx.y, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
+}
+// Round 6, small buckets (the recorded-run batch: lk_batch_replay_overlay_ragged_dev with every bucket <= LK_SCAN_WAVE_MAX points): copy-on-write, point
+// geometry and the lane-per-root pass of ONE slot as one workgroup of one launch - three launches of ~5 us each whatever they do, for a dozen points
+// per slot.  What a phase writes the next one reads through the same CU's L1 (workgroup-scope fences; no L2 write-back).
+template <bool LEAN>
+__global__ void __launch_bounds__(LK_MB) lk_ov_mid_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
+    const unsigned int slot = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    ov_materialise_body<LEAN>(base, ov, pr, slot, 0, 1, tid);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {
+        const lk_point* pts;
+        const int n = ov_pt_src(src, slot, &pts);
+        for (int bx = 0; bx * 256 < n; ++bx) ov_point_geom_body(ov, pr, filters, src, slot, bx, tid);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (tid < LK_WAVE) ov_root_lane_body(base, ov, pr, slot, 0, 1, tid);
 }
 
 // ---------------------------------------------------------------- the ordered insert, slot = blockIdx.y
