@@ -20,7 +20,7 @@ import bench  # noqa: E402
 
 KEYS = {"ov_reset": "lk_ov_reset_kernel", "ov_residual": "lk_ov_residual_kernel", "ov_begin": "lk_ov_begin_kernel", "ov_reproject": "lk_ov_reproject_kernel",
         "ov_materialise": "lk_ov_materialise_kernel", "ov_point_geom": "lk_ov_point_geom_kernel", "ov_root_lane": "lk_ov_root_lane_kernel",
-        "ov_insert_root": "lk_ov_insert_root_kernel", "ov_fit_eig": "lk_ov_fit_eig_kernel", "ov_fit_lane": "lk_ov_fit_lane_kernel",
+        "ov_insert_root": "lk_ov_insert_root_kernel", "ov_fit_eig": "lk_ov_fit_eig_kernel", "ov_fit_lane": "lk_ov_fit_group_kernel",   # round 6: the fit pass by groups of eight lanes (bench.py keeps the profile key "ov_fit_lane")
         "ov_insert_apply": "lk_ov_insert_apply_kernel", "ov_insert_fallback": "lk_ov_insert_fallback_kernel", "ov_base_sums": "lk_ov_base_sums_kernel"}
 
 
@@ -62,7 +62,9 @@ def main():
     # registers / scratch / waves per SIMD as the COMPILER reports them (profiles/r05_resource_usage.txt, `make resource-usage`): the profiler's
     # VGPR_Count column is an allocation granule count on gfx950, not the kernel's VGPRs
     table = {}
-    rt = os.path.join(ROOT, "profiles", "r05_resource_usage.txt")
+    rt = os.path.join(ROOT, "profiles", "r06_resource_usage.txt")
+    if not os.path.exists(rt):
+        rt = os.path.join(ROOT, "profiles", "r05_resource_usage.txt")
     if os.path.exists(rt):
         for line in open(rt).read().splitlines()[1:]:
             f = line.split()
