@@ -4290,7 +4290,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
         } else {
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
         }
-        LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, ov, h->pr));
+        LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
         static const bool fit_group = getenv("LEGKILO_OV_FIT_GROUP") == nullptr || atoi(getenv("LEGKILO_OV_FIT_GROUP")) != 0;   // 0: round 5's one lane per fit (A/B)
         if (fit_group)
             LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_group_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
@@ -4431,7 +4431,7 @@ static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_,
                 LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(std::max(1, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
             }
             LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL((lk_ov_insert_root_kernel<3, true>), dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
-            LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, ov, h->pr));
+            LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
             static const bool fit_group_r = getenv("LEGKILO_OV_FIT_GROUP") == nullptr || atoi(getenv("LEGKILO_OV_FIT_GROUP")) != 0;
             if (fit_group_r)
                 LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_group_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));

@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 // private plane record (centre, normal = v_min; v_mid, v_max and the eigenvalues in the first nine plane_var words) for lk_ov_fit_lane_kernel,
 // which overwrites them with the finished plane.  Two kernels because the closed-form eigen-solver (acos, two cos) and the loop over the leaf's
 // points each fit 128 registers and together do not: the single kernel ran at two waves per SIMD.
-__global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkOverlay ov, LkParams pr) {
+__global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
@@ -634,6 +634,19 @@ __global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkOverlay ov,
         if (cnt <= 0) continue;
         lk_plane_rec* pl = &pm.planes[root];
         if (hd.w == 0) {   // plane_commit's "not a plane" branch
+            // init_plane's else-branch keeps the previous fit's centre, normal and plane_var (voxel_map.cc:112-115).  A lazily copied root
+            // (lk_ov_materialise_kernel<LEAN>) has them in the BASE map's record only: make them private before the marker that says so goes
+            // (lk_overlay_export would otherwise emit whatever the pool held)
+            if (pl->points_size == LK_PLANE_LAZY) {
+                const int bnode = (int)pm.nodes[root].pad_[LK_PAD_BASE] - 1;
+                if (bnode >= 0) {
+                    const uint4* bp4 = reinterpret_cast<const uint4*>(&base.planes[bnode]);
+                    uint4* pp4 = reinterpret_cast<uint4*>(pl);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (q != 3) pp4[q] = bp4[q];   // piece 3 = d, radius, flags, points_size: d / radius / flags are private already
+                }
+            }
             pl->points_size = cnt;
             const unsigned int fl = pl->flags & ~LK_PLANE_IS_PLANE;
             pl->flags = fl;
