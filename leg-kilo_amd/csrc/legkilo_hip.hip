@@ -1,269 +1,10 @@
-// legkilo_hip.hip — implementation of the C-ABI in include/legkilo_hip.h for gfx950.
-// Host side of the shim: owns HBM pools, the HIP stream, and the launch sequences that
-// replace KILO::predictUpdatePoint (KILO.cc:108-233) and the bucket loop (KILO.cc:367-396).
-// There is no CPU fallback: without a gfx950 device lk_create fails with LK_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
+// legkilo_hip.hip - the main translation unit of liblegkilo_hip.so (see lk_internal.h)
+#define LK_TU_MAIN 1
+#include "lk_internal.h"
 
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <climits>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "lk_prim.h"   // rocPRIM's sorts and scans, instantiated in lk_prim.hip
-
-#include "lk_device.h"
-#include "lk_filter_kernels.h"
-#include "lk_point_kernels.h"
-#include "lk_map_kernels.h"
-#include "lk_pre_kernels.h"
-#include "lk_overlay_kernels.h"
-
-static_assert(sizeof(lk_plane_rec) == 256, "plane record must be 256 B");
-static_assert(sizeof(lk_node_rec) == 128, "node record must be 128 B");
-static_assert(sizeof(lk_pt_rec) == 72, "point record must be 72 B");
-static_assert(sizeof(lk_point) == 16, "scan point must be 16 B");
-
-struct ProfEntry {
-    uint64_t launches = 0;
-    double total_ms = 0.0;
-};
-
-struct lk_handle {
-    lk_config cfg = {};
-    LkParams pr = {};
-    LkMap map = {};
-    hipStream_t stream = nullptr;
-    static constexpr int kMaxGroups = 4;
-    hipStream_t side[kMaxGroups - 1] = {};  // extra queues of the slot-group batch replay
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
-    int replay_groups = 3;
-    size_t async_n = 0;           // n_scans of the asynchronous batches that may be in flight (0: none since the last lk_synchronize)
-    bool wave_update = true;  // batch replay: single-wave update kernel (LEGKILO_UPDATE_CLASSIC=1 selects the 256-thread one)
-    double last_slide_position[3] = {0.0, 0.0, 0.0};  // voxel_map.h:201
-    unsigned int hash_cap = 0;
-    LkFilter* d_filters = nullptr;
-    double* d_Q = nullptr;
-    double* d_partials = nullptr;
-    size_t part_stride = 0;  // doubles per slot
-    lk_point* d_scan = nullptr;
-    float* d_world = nullptr;
-    double* d_rows = nullptr;  // h6 (6n) | z (n) | R (n)
-    unsigned char* d_valid = nullptr;
-    double* d_tmp = nullptr;   // small scratch for class-surface calls (>= 18*32 doubles + 900*2)
-    lk_pose* d_poses = nullptr;
-    void* d_ragdev = nullptr;     // lk_batch_replay_scans_dev: flags, ranks, CSR tables, messages (grow-only)
-    size_t ragdev_cap = 0;
-    void* d_ragtmp = nullptr;     // rocPRIM scan scratch
-    size_t ragtmp_cap = 0;
-    void* d_rag = nullptr;        // tables of lk_batch_replay_ragged_dev (device copy, pinned staging copy)
-    void* h_rag = nullptr;
-    size_t rag_cap = 0;
-    // pipelined stream path ("spec"): the insert of bucket k on its own stream beside predict + residual of bucket k+1 (enqueue_bucket)
-    hipStream_t ins = nullptr;
-    hipEvent_t ev_U[2] = {}, ev_D[2] = {}, ev_I = nullptr;
-    unsigned int epoch = 16;      // bucket sequence number: stamps of LkMap::dirty / newroot, value of spec[LK_SPEC_DONE]
-    unsigned int spec_base = 16;  // first epoch of the open window (stamps below it belong to inserts that were joined)
-    bool spec_open = false;       // inserts may still be running on `ins`
-    int gridscan_mode = 1;        // scans of large buckets as one grid-resident launch (lk_scan_grid_kernel): 0 never, 1 when every bucket holds
-                                  // 513 .. LK_GRIDSCAN_AUTO_MAX points (where it measures faster than the launches), 2 whenever it applies; LEGKILO_GRIDSCAN / lk_stream_grid
-    bool resident_enable = true;  // scans of small buckets as one resident launch (lk_scan_stream_kernel); LEGKILO_RESIDENT=0 / lk_stream_resident(h, 0): per-bucket launches
-    bool spec_enable = false;     // LEGKILO_SPEC=1 / lk_stream_pipeline(h, 1); measured slower than the sequential order: off by default
-    LkFilter* d_snap = nullptr;   // 2 posterior snapshots (dev_snapshot_posterior)
-    struct ScanResult {            // what a stream-path scan hands back: written by ONE kernel into host-mapped pinned memory (no copies, one sync)
-        lk_pose pose;
-        unsigned int ctr[LK_CTR_COUNT];
-        int resume[4];               // scan-resident kernel: LkResume's bf, bi, fb_bucket (where the launch stopped), 0
-        unsigned int seq, pad_;      // written last: the host may poll it instead of blocking in hipStreamSynchronize
-    };
-    uint64_t resident_scans = 0, resident_relaunches = 0, grid_scans = 0, grid_relaunches = 0;   // lk_stream_resident_stats
-    unsigned int test_stall_ms = 0;   // lk_test_stall: the next resident launches run with this bound and an injected stall (error-path test)
-    unsigned int result_seq = 0;
-    ScanResult* h_result = nullptr;   // hipHostMalloc(mapped)
-    ScanResult* d_result = nullptr;   // its device-side address
-    LkFilter* d_fbackup = nullptr;   // filters[0] as it was when the running scan started: what an LK_ERR_TIMEOUT puts back (grid-resident and pipelined paths)
-    bool fbackup_valid = false;
-    int2* d_ids = nullptr;        // [max_scan] root codes of the speculative residual pass
-    uint64_t spec_buckets = 0, spec_tiles = 0, spec_redo_total = 0, res_redo_total = 0;
-    unsigned int spec_redo_seen = 0, res_redo_seen = 0;
-    double acc_norm = 1.0;
-    bool q_diag = true;        // d_Q holds a diagonal matrix (zero-initialised; lk_set_Q re-checks)
-    // frozen-map grid of batch replay (LkMap::grid): valid until the map changes
-    LkMap fmap = {};           // h->map + the grid fields; h->map itself always has grid_on = 0 (the streaming path mutates the map)
-    size_t grid_cap = 0;       // grid cells allocated behind the max_nodes match records of map.match
-    bool grid_valid = false;   // the grid describes the current map
-    uint64_t map_gen = 0;      // counts the map snapshots batch replays have frozen: frozen_map() bumps it whenever the map had changed since the last one
-    uint64_t ov_gen = 0;       // the snapshot the last overlay replay ran against (lk_overlay_export reads base blocks / planes of THAT map)
-    bool grid_enable = true;   // LEGKILO_GRID=0 keeps batch replay on the hash table (A/B)
-    int* d_grid_mm = nullptr;
-    // grow-only scratch of lk_preprocess_scan
-    size_t pre_cap = 0, pre_tmp_bytes = 0;
-    lk_point *pre_raw = nullptr, *pre_cells = nullptr, *pre_out = nullptr;
-    unsigned int *pre_k0 = nullptr, *pre_k1 = nullptr, *pre_flags = nullptr, *pre_pos = nullptr, *pre_misc = nullptr;
-    int *pre_v0 = nullptr, *pre_v1 = nullptr, *pre_starts = nullptr;
-    void* pre_tmp = nullptr;
-    // batch replay with a per-scan insert overlay (lk_overlay_kernels.h): the pools of all slots, grow-only
-    LkOverlay ov = {};
-    uint32_t ov_slots = 0;                                // slots the pools were allocated for
-    uint32_t ov_want_roots = 0, ov_want_nodes = 0, ov_want_blocks = 0;   // lk_overlay_reserve (0: derived from the scan size)
-    uint32_t ov_last_slots = 0;                           // slots of the last overlay replay (lk_overlay_export / lk_overlay_stats)
-    uint32_t ov_hw_roots = 0, ov_hw_nodes = 0, ov_hw_blocks = 0;   // high-water marks of the last replay (any slot): the next replay's pools are sized from them
-    size_t ov_hw_npts = 0;                                // ... which belong to scans of this size
-    size_t ov_pool_bytes = 0;                             // bytes the overlay pools hold (lk_overlay_pool_bytes)
-    LkFilter* d_ov_priors = nullptr;                      // the batch's priors, kept for the retry after a pool overflow
-    size_t ov_priors_cap = 0;
-    unsigned int* d_ov_status = nullptr;
-    // input order of device-resident batches (lk_batch_order): the batches the frozen-map batch entries have seen, with the library's voxel-ordered copy
-    struct OrdEntry {
-        const lk_point* src = nullptr;     // the caller's buffer and the shape it was seen with
-        size_t n_scans = 0, n_pts = 0, n_buckets = 0;
-        uint64_t off_hash = 0;
-        bool as_given = false;             // the batch already was in voxel order: replayed where it lies, no copy, no stamp
-        lk_point* copy = nullptr;          // voxel-ordered copy (every bucket of every scan sorted by root-voxel key under the priors of the first sight)
-        size_t copy_bytes = 0;
-        unsigned long long* d_ref = nullptr;   // device: [0] content stamp of src at the replay before, [1] 1 = this replay reads the copy
-        bool have_copy = false;            // the copy holds the buffer's content as of the last sort (as far as the host knows: h_seen says what the device found)
-        unsigned int* h_seen = nullptr;    // host-mapped, written by the device: replays in a row that found the same content stamp; LK_ORD_SORTED while the copy is current
-        unsigned int* d_seen = nullptr;
-        uint64_t tick = 0;
-    };
-    OrdEntry ord[2];
-    uint64_t ord_tick = 0, ord_examined = 0, ord_sorted = 0, ord_stale = 0;
-    int batch_order_mode = 1;              // LK_BATCH_ORDER_AUTO; LEGKILO_BATCH_ORDER=0 / lk_batch_order(h, 0): replay every batch as given
-    int batch_order_after = 2;             // a batch is sorted once this many replays in a row have found the same content in its buffer (the sort pays for itself after ~10)
-    bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::map<std::string, ProfEntry> prof;
-    std::string err;
-};
-
-static thread_local std::string g_err;
-
-static int fail(lk_handle* h, int code, const std::string& msg) {
-    g_err = msg;
-    if (h) h->err = msg;
-    return code;
-}
-#define HIPCHK(h, call)                                                                               \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess)                                                                         \
-            return fail(h, LK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
-    } while (0)
-
-template <typename F>
-static int launch(lk_handle* h, const char* name, F&& f) {
-    if (h->profiling) {
-        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-        f();
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-        HIPCHK(h, hipEventSynchronize(h->ev1));
-        float ms = 0.f;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        ProfEntry& p = h->prof[name];
-        p.launches += 1;
-        p.total_ms += ms;
-    } else {
-        // LEGKILO_TRACE_LAUNCH=<prefix> (debug aid): every launch whose name starts with the prefix is announced on stderr and waited for -
-        // the last name printed before a "Memory access fault by GPU" is the kernel that made it
-        static const char* trace = getenv("LEGKILO_TRACE_LAUNCH");
-        const bool tr = trace && strncmp(name, trace, strlen(trace)) == 0;
-        if (tr) fprintf(stderr, "[launch] %s\n", name), fflush(stderr);
-        f();
-        if (tr) HIPCHK(h, hipDeviceSynchronize());
-    }
-    HIPCHK(h, hipGetLastError());
-    return LK_OK;
-}
-#define LAUNCH(h, name, ...)                                   \
-    do {                                                       \
-        int rc_ = launch(h, name, [&]() { __VA_ARGS__; });     \
-        if (rc_ != LK_OK) return rc_;                          \
-    } while (0)
-
-// Every device allocation of this library.  LEGKILO_POISON_POOLS=1 (test aid): the fresh memory is filled with 0x5a bytes instead of whatever the
-// allocator hands out - in a young process zeros, in a long-lived one somebody's old data - so that a kernel which trusts memory nobody has
-// written meets garbage in EVERY run (the whole GPU suite is run that way once per round: tools/gpu_poison_suite.sh)
-static hipError_t lk_hip_malloc(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    static const bool poison = getenv("LEGKILO_POISON_POOLS") != nullptr;
-    if (e == hipSuccess && (poison || getenv("LEGKILO_POISON_POOLS")) && bytes) {
-        e = hipMemset(*p, 0x5a, bytes);
-        if (e == hipSuccess) e = hipDeviceSynchronize();   // (the fill runs on the null stream, the library's streams do not wait for that one)
-    }
-    return e;
-}
-template <typename T>
-static hipError_t lk_hip_malloc(T** p, size_t bytes) {
-    return lk_hip_malloc(reinterpret_cast<void**>(p), bytes);
-}
-#define hipMalloc(p, n) lk_hip_malloc((p), (n))
-
-// device temporaries of one call: freed on every return path
-struct DevTemps {
-    std::vector<void*> ptrs;
-    ~DevTemps() {
-        for (void* p : ptrs)
-            if (p) hipFree(p);
-    }
-    template <typename T>
-    hipError_t alloc(T** out, size_t bytes) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = (T*)p;
-        return e;
-    }
-};
-
-static unsigned int next_pow2(unsigned int v) {
-    unsigned int p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-static int check_map_errors(lk_handle* h, const unsigned int* fetched = nullptr) {
-    unsigned int ctr[LK_CTR_COUNT];
-    if (fetched) {
-        memcpy(ctr, fetched, sizeof(ctr));
-    } else {
-        HIPCHK(h, hipMemcpyAsync(ctr, h->map.counters, sizeof(ctr), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    if (ctr[LK_CTR_ERR] & LK_E_SPEC_TIMEOUT) {
-        // not sticky: the word is cleared, so the handle stays usable once its map has been restored
-        const unsigned int rest = ctr[LK_CTR_ERR] & ~LK_E_SPEC_TIMEOUT;
-        HIPCHK(h, hipMemcpyAsync(h->map.counters + LK_CTR_ERR, &rest, sizeof(rest), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        // the filter keeps its PRE-SCAN state on every path: the resident kernels' and the pipelined launches' scans start with a copy of
-        // filters[0] that is put back here (a scan-resident launch given up returns before its write-back, but a scan picked up again after
-        // fallback items has written the filter once)
-        if (h->fbackup_valid) {
-            HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_fbackup, sizeof(LkFilter), hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-        }
-        h->fbackup_valid = false;
-        return fail(h, LK_ERR_TIMEOUT, "a bounded device-side wait of the stream path timed out (device fault, or a pre-empted / debugged GPU; "
-                                       "LEGKILO_RESIDENT_TIMEOUT_MS raises the bound): the filter keeps its state from before the scan, the map may hold a partial "
-                                       "insert - restore it (lk_map_import) and replay the scan");
-    }
-    h->fbackup_valid = false;
-    if (ctr[LK_CTR_ERR]) {
-        char buf[160];
-        snprintf(buf, sizeof(buf), "device pool overflow (bits 0x%x: 1 hash, 2 nodes, 4 point blocks, 8 scratch, 16 bad blob)", ctr[LK_CTR_ERR]);
-        return fail(h, LK_ERR_CAPACITY, buf);
-    }
-    return LK_OK;
-}
+thread_local std::string g_err;
 
 static int create_pools(lk_handle* h, const lk_config* cfg);
-static void ov_free(lk_handle* h);
 
 extern "C" {
 
@@ -453,20 +194,6 @@ void lk_destroy(lk_handle* h) {
     delete h;
 }
 
-static int spec_join(lk_handle* h);
-#define CHECK_H(h)                                                         \
-    do {                                                                   \
-        if (!(h)) return fail(nullptr, LK_ERR_INVALID, "null handle");     \
-        hipSetDevice((h)->cfg.device_id);                                  \
-        if ((h)->spec_open) {                                              \
-            int rcj_ = spec_join(h);                                       \
-            if (rcj_ != LK_OK) return rcj_;                                \
-        }                                                                  \
-    } while (0)
-#define CHECK_SLOT(h, s)                                                                  \
-    do {                                                                                  \
-        if ((s) >= (h)->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot out of range"); \
-    } while (0)
 
 // ------------------------------------------------------------------ ESKF surface
 int lk_set_state(lk_handle* h, uint32_t slot, const double* x36, const double* P900) {
@@ -792,7 +519,6 @@ extern "C" {
 // per-bucket launches of lk_batch_replay_ragged_dev compute; a bucket's tile totals are added in tile order, which is
 // the order lk_update_wave_kernel uses for up to 8 tiles (one per group) - the host takes this path only when every bucket
 // has <= LK_SCAN_WAVE_MAX points, so both paths give the same bits.
-#define LK_SCAN_WAVE_MAX 512
 #ifdef LK_DEBUG_PHASES
 __device__ unsigned long long lk_sw_dbg[16];   // DEBUG BUILD ONLY: s_memtime deltas per phase of dev_scan_wave, [15] = buckets
 #define SW_STAMP(k) do { const unsigned long long t1_ = wall_clock64(); ph_[k] += t1_ - t0_; t0_ = t1_; } while (0)
@@ -928,108 +654,6 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
     if (lane == 0) f->last_update_t = t_upd, f->last_predict_t = t_pred;
 }
 
-// Round 6: the FRONT of a bucket index of the ragged batch with insert as ONE launch when every bucket holds <= LK_SCAN_WAVE_MAX points (a recorded
-// scan's 2 ms bins): lk_rag_advance_kernel (messages + predict), lk_ov_residual_kernel, lk_update_wave_ragged_kernel, lk_ov_begin_kernel and
-// lk_ov_reproject_kernel were five one-wave-per-scan launches, each paying a launch boundary (~5 us for 1 024 one-wave workgroups whatever they do) and
-// its own load / store of the filter's 7.6 KB.  Here one wave per scan runs the five bodies back to back - the one-wave filter cores and the tile code
-// of dev_scan_wave, the overlay lookup of lk_ov_residual_kernel - with state and covariance in LDS from the first message to the update.  Same device
-// functions, same order of sums (tile totals in tile order, as lk_update_wave_kernel adds up to eight of them): bit-identical to the five launches
-// (test_batch_replay_overlay_ragged compares both against the oracle; LEGKILO_RAG_FUSE=0 is the A/B).
-extern "C++" {
-template <bool XID>
-__global__ void __launch_bounds__(LK_WAVE, 2)
-    lk_rag_ov_front_kernel(LkMap base, LkOverlay ov, LkParams pr, LkFilter* filters, const double* __restrict__ Q, LkRagged rg, const lk_point* __restrict__ d_pts,
-                           int b, int msg_kind) {
-    __shared__ WaveSmem sm;
-    __shared__ double rows[64 * LK_ROW2];
-    const int slot = blockIdx.x, lane = threadIdx.x;
-    const LkMap pm = ov_slot_map(ov, (unsigned int)slot);
-    if (b >= rag_nb(rg, slot)) {   // this scan has run out of buckets: the passes behind this one must find its work lists empty (lk_ov_begin_kernel ran for every slot)
-        dev_bucket_begin_wave(pm);
-        return;
-    }
-    LkFilter* f = &filters[slot];
-    const double* T = rag_t(rg, slot);
-    for (int e = lane; e < 900; e += LK_WAVE) sm.P[e] = f->P[e];
-    if (lane < 36) sm.x[lane] = f->x[lane];
-    double t_upd = f->last_update_t, t_pred = f->last_predict_t;
-    __syncthreads();
-    const double tb = T[b];
-    if (msg_kind) {   // lk_rag_advance_kernel: the scan's messages stamped before this bucket that no earlier bucket has consumed (KILO.cc:379-390)
-        const size_t mstride = msg_kind == 2 ? 33 : 7;
-        const unsigned int q0 = rg.imu_off[slot], q1 = rg.imu_off[slot + 1];
-        for (unsigned int q = q0; q < q1; ++q) {
-            const double* m = rg.imu + mstride * (size_t)q;
-            const double tm = m[0];
-            if (!(tm < tb)) break;
-            if (b > 0 && tm < T[b - 1]) continue;
-            wave_predict_core(sm, Q, tm - t_upd, tm - t_pred, lane, rg.q_diag != 0);
-            t_pred = tm;
-            if (msg_kind == 2) wave_kin_update_core(sm, rows, m, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
-            else wave_imu_update_core(sm, m + 1, m + 4, rg.acc_scale, rg.Rn, lane);
-            t_upd = tm;
-        }
-    }
-    wave_predict_core(sm, Q, tb - t_upd, tb - t_pred, lane, rg.q_diag != 0);   // KILO.cc:111-115
-    t_pred = tb;
-    // lk_ov_residual_kernel: the bucket's tiles against base map + the scan's overlay, under the predicted state in LDS
-    const unsigned long long* po = rag_pt_off(rg, slot);
-    const lk_point* pts = d_pts + po[b];
-    const int n = (int)(po[b + 1] - po[b]);
-    BucketConst bc;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) bc.R[i] = sm.x[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) bc.p[i] = sm.x[9 + i];
-    {
-        const double* P = sm.P;
-        bc.Prr = S3{P[0], P[1], P[2], P[31], P[32], P[62]};
-        bc.Ppp = S3{P[3 * 30 + 3], P[3 * 30 + 4], P[3 * 30 + 5], P[4 * 30 + 4], P[4 * 30 + 5], P[5 * 30 + 5]};
-    }
-    LkOvView ovv;
-    ovv.keys = ov.keys + (size_t)slot * ov.hash_cap;
-    ovv.hash_mask = ov.hash_cap - 1;
-    ovv.match = ov.match + (size_t)slot * ov.nodes_cap;
-    ovv.nodes = ov.nodes + (size_t)slot * ov.nodes_cap;
-    ovv.bits = ov.bits + (size_t)slot * ov.bit_words;
-    ResidualOut ro;
-    ro.h6 = nullptr, ro.z = nullptr, ro.R = nullptr, ro.valid = nullptr, ro.world = nullptr, ro.ids = nullptr;
-    double totv = 0.0;   // tot[j] in lanes 0..31
-    for (int i0 = 0; i0 < n; i0 += LK_WAVE) {
-        __builtin_amdgcn_wave_barrier();   // the previous tile's reads of the rows are complete
-        const double a = residual_tile<false, 3, XID, true, false>(base, pr, bc, reinterpret_cast<const float4*>(pts), i0 + lane, n, rows, lane, ro, (size_t)0, &ovv);
-        totv += (lane < 29) ? a : 0.0;
-    }
-    // lk_update_wave_ragged_kernel (update_only): the posterior the insert reads
-    const int N = (int)(lane_bcast<28>(totv) + 0.5);
-    if (lane == 0) {
-        f->last_predict_t = t_pred;
-        f->n_buckets += 1;
-        f->last_N = N;
-        f->updated = N > 0;
-        if (N > 0) {
-            f->n_updates += 1;
-            f->n_effect += (unsigned long long)N;
-        }
-        f->last_update_t = N > 0 ? tb : t_upd;   // KILO.cc:212
-    }
-    if (N > 0) wave_update_core(sm, totv, N, lane);
-    __syncthreads();
-    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
-    if (lane < 36) f->x[lane] = sm.x[lane];
-    // the re-projection below reads the posterior through the filter record, like every other kernel of the insert - written by THIS wave: its stores
-    // have to be acknowledged before its loads go out (workgroup scope = s_waitcnt; an agent-scope fence here is an L2 write-back + invalidate per
-    // wave, 1 024 of them per launch: the first version of this kernel was 6 ms SLOWER than the five launches for it)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-    // lk_ov_begin_kernel, lk_ov_reproject_kernel
-    dev_bucket_begin_wave(pm);
-    for (int i = lane; i < n; i += LK_WAVE) {
-        const int r = ov_reproject_point(base, ov, pr, filters, pts, i, (unsigned int)slot);
-        ov.ptroot[(size_t)slot * ov.scan_cap + i] = r;   // for lk_ov_point_geom_kernel
-    }
-}
-}   // extern "C++"
 
 __global__ void __launch_bounds__(LK_WAVE, 2)
     lk_scan_wave_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg,
@@ -1643,7 +1267,7 @@ extern "C" {
 //   ins :  begin(k+1) | [U_k] re-project(k) -> light(k) -> [D_k] group(k) -> apply(k) -> fallback(k) (+ DONE = epoch k)
 // Stamps carry the bucket's epoch; verify(e) treats stamps >= e - 2 as suspect (the residual pass of e may have overlapped the tail
 // of insert e - 2; inserts <= e - 3 had completed before it started: D_(e-2) follows them on `ins`).
-static int spec_join(lk_handle* h) {
+int spec_join(lk_handle* h) {
     if (!h->spec_open) return LK_OK;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_I, 0));   // everything enqueued on the main stream from here on follows the inserts
     h->spec_open = false;
@@ -1858,7 +1482,7 @@ static int enqueue_bucket(lk_handle* h, const lk_point* d_pts, int n, double t, 
 // from the hash table + match records and rebuilt when the map has changed since (every mutating entry clears grid_valid);
 // building it is two small kernels + a memset, synchronised once - it happens per map snapshot, not per batch.
 static constexpr size_t kGridMaxCells = (size_t)1 << 24;   // 16 Mi cells x 144 B = 2.4 GB of grid at most (record INDICES are 32-bit, addressing is 64-bit); larger boxes stay on the hash
-static int frozen_map(lk_handle* h, LkMap* out) {
+int frozen_map(lk_handle* h, LkMap* out) {
     *out = h->map;
     out->grid_on = 0;
     if (!h->grid_enable) return LK_OK;
@@ -1955,7 +1579,7 @@ __global__ void lk_zero_scan_counters_kernel(LkFilter* filters, unsigned int n_s
     LkFilter* f = &filters[s];
     f->n_effect = 0ull, f->n_updates = 0u, f->n_buckets = 0u, f->updated = 0, f->last_N = 0;
 }
-static int zero_scan_counters(lk_handle* h, uint32_t first_slot, uint32_t n_slots) {
+int zero_scan_counters(lk_handle* h, uint32_t first_slot, uint32_t n_slots) {
     // n_effect, n_updates, n_buckets, updated, last_N of every slot: ONE launch (a 24-byte-wide 2-D memset is two fill kernels)
     hipLaunchKernelGGL(lk_zero_scan_counters_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, h->stream, h->d_filters + first_slot, n_slots);
     HIPCHK(h, hipGetLastError());
@@ -1974,7 +1598,7 @@ __global__ void lk_pose_gather_kernel(const LkFilter* filters, lk_pose* out, int
     p.n_updates = f->n_updates;
     out[s] = p;
 }
-static int fetch_poses(lk_handle* h, lk_pose* out, int n) {
+int fetch_poses(lk_handle* h, lk_pose* out, int n) {
     hipLaunchKernelGGL(lk_pose_gather_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_filters, h->d_poses, n);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, h->d_poses, sizeof(lk_pose) * n, hipMemcpyDeviceToHost, h->stream));
@@ -2282,7 +1906,7 @@ static void fill_header(lk_handle* h, lk_blob_header& hd, const unsigned int* ct
 }
 
 // host blob of one LkMap (the handle's map, or one slot's overlay): header | roots (sorted by key) | nodes | planes | blocks
-static int export_map_blob(lk_handle* h, const LkMap& m, unsigned int hash_cap, void* blob, size_t* bytes) {
+int export_map_blob(lk_handle* h, const LkMap& m, unsigned int hash_cap, void* blob, size_t* bytes) {
     if (!bytes) return fail(h, LK_ERR_INVALID, "bytes is null");
     unsigned int ctr[LK_CTR_COUNT];
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2328,38 +1952,7 @@ int lk_map_export(lk_handle* h, void* blob, size_t* bytes) {
 }
 // the voxels scan `slot` of the last overlay replay holds privately (the roots its inserts touched or created), as a map blob: the
 // slot's key table is turned into the int4 form the exporter reads (entry index = root node id)
-int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
-    CHECK_H(h);
-    if (!h->ov.counters || !h->ov_last_slots) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
-    if (slot >= h->ov_last_slots) return fail(h, LK_ERR_INVALID, "slot was not part of the last overlay replay");
-    // an overlay is not self-contained: split leaves keep their first points in the BASE map's blocks, lazily copied voxels their plane in the base
-    // map's plane records.  Once the handle's map has changed (lk_process_scan, lk_map_update, lk_map_slide, lk_map_import, ...) those ids may
-    // name other voxels: refuse instead of exporting them
-    if (!h->grid_valid || h->ov_gen != h->map_gen)
-        return fail(h, LK_ERR_STATE, "the handle's map has changed since the overlay replay: its overlays can no longer be exported (export before the map is updated, slid or imported, or replay again)");
-    const LkOverlay& ov = h->ov;
-    // leaves the fast root pass left split (old points still in the handle's blocks) are made whole first
-    hipLaunchKernelGGL(lk_ov_merge_split_kernel, dim3(64), dim3(LK_MB), 0, h->stream, h->map, ov, slot);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> keys(ov.hash_cap);
-    HIPCHK(h, hipMemcpy(keys.data(), ov.keys + (size_t)slot * ov.hash_cap, sizeof(unsigned long long) * ov.hash_cap, hipMemcpyDeviceToHost));
-    std::vector<int4> table(ov.hash_cap);
-    for (unsigned int i = 0; i < ov.hash_cap; ++i) {
-        if (keys[i] == LK_OV_EMPTY) {
-            table[i] = make_int4(INT_MIN, INT_MIN, INT_MIN, LK_EMPTY);
-        } else {
-            int k3[3];
-            ov_unpack_key(keys[i], k3);
-            table[i] = make_int4(k3[0], k3[1], k3[2], (int)i);
-        }
-    }
-    LkMap m = ov_slot_map(ov, slot);
-    DevTemps tmp;
-    HIPCHK(h, tmp.alloc(&m.hash, sizeof(int4) * ov.hash_cap));
-    HIPCHK(h, hipMemcpy(m.hash, table.data(), sizeof(int4) * ov.hash_cap, hipMemcpyHostToDevice));
-    return export_map_blob(h, m, ov.hash_cap, blob, bytes);
-}
+
 
 // A blob is only usable by a handle configured like the one that wrote it: the voxel size defines the keys, max_layer
 // and max_points_num the insert state machine.
@@ -3429,7 +3022,7 @@ __global__ void __launch_bounds__(256) lk_states_gather_kernel(const LkFilter* _
     if (P900)
         for (int e = threadIdx.x; e < 900; e += 256) P900[(size_t)blockIdx.x * 900 + e] = f->P[e];
 }
-static int join_side_streams(lk_handle* h) {   // the asynchronous batch entry may still be running on a side stream
+int join_side_streams(lk_handle* h) {   // the asynchronous batch entry may still be running on a side stream
     for (int i = 0; i < lk_handle::kMaxGroups - 1; ++i)
         if (h->side[i]) {
             HIPCHK(h, hipEventRecord(h->ev_join[i], h->side[i]));
@@ -3689,11 +3282,9 @@ static int ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const Lk
 // launch per bucket INDEX over all scans (grid sized by the largest bucket of that index; scans that have run out of
 // buckets leave at once), every scan reading its own tables (LkRagged).  Same kernels' arithmetic as the uniform entry:
 // a ragged batch of equally shaped scans gives the same bits.  Synchronous; priors as for lk_batch_replay_dev.
-static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,
-                                 const int* max_n, size_t max_scan_pts, int msg_kind, lk_pose* out);
-static int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
+int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off,
                          const uint32_t* n_buckets, const uint32_t* bucket_off, const double* bucket_dt,
-                         const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out, bool with_insert = false) {
+                         const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out, bool with_insert) {
     CHECK_H(h);
     if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
     if (!d_pts || !scan_off || !n_buckets || !bucket_off || !bucket_dt || !t_begin) return fail(h, LK_ERR_INVALID, "null argument");
@@ -4015,492 +3606,6 @@ int lk_batch_replay_async_dev(lk_handle* h, const lk_point* d_pts, uint32_t firs
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(host_out, h->d_poses + first_slot, sizeof(lk_pose) * n_scans, hipMemcpyDeviceToHost, st));
     }
-    return LK_OK;
-}
-
-// ------------------------------------------------------------------ batch replay with a per-scan insert overlay
-// (lk_overlay_kernels.h) KILO::process for every scan of the batch - predict, residual, update AND map insert per bucket (KILO.cc:108-233,
-// :375-395) - each scan on its own copy-on-write overlay of the handle's map, which itself stays untouched.
-static void ov_free(lk_handle* h) {
-    LkOverlay& o = h->ov;
-    void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen, o.sums, o.base_sums, o.cplx, o.ptroot};
-    for (void* q : ptrs)
-        if (q) hipFree(q);
-    memset(&o, 0, sizeof(o));
-    h->ov_slots = 0;
-    h->ov_pool_bytes = 0;
-    h->ov_last_slots = 0;   // nothing of the last replay is left to export / count (lk_overlay_export, lk_overlay_stats)
-}
-// LEGKILO_POISON_POOLS (test aid): node records that look plausible - a few points, no children - and point at a block far outside any pool
-__global__ void __launch_bounds__(256) lk_ov_poison_nodes_kernel(lk_node_rec* nodes, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    nodes[i].npts = 3, nodes[i].new_points = 1, nodes[i].block = 0x3fffff00, nodes[i].layer = 0, nodes[i].state = LK_NODE_UPDATE_ENABLE | LK_NODE_INIT_OCTO;
-    for (int c = 0; c < 8; ++c) nodes[i].child[c] = -1;
-}
-// Per-scan capacities.  lk_overlay_reserve's numbers if given; else, when an earlier replay of scans of this size has left its
-// high-water marks, those + 25 % (pools more than twice that are released and re-made: round 4 reserved n_pts / 6 roots = 110 MB per scan,
-// 113 GB for 1 024 scans, where the bench's scans use 4 700 roots); else a first guess of n_pts / 18 roots.  `grow` (bits of the slots' error
-// word: 1 private root table, 2 nodes, 4 point blocks) doubles what overflowed - the replay is then run again (lk_batch_replay_overlay_dev).
-static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t biggest_bucket, const LkMap& fmap, unsigned int grow = 0) {
-    const bool hist = h->ov_hw_roots > 0 && h->ov_hw_npts == n_pts_scan;
-    uint32_t roots, nodes_extra, blocks;
-    if (h->ov_want_roots) {
-        roots = h->ov_want_roots;
-        nodes_extra = h->ov_want_nodes ? std::max(h->ov_want_nodes, roots + 64u) - roots : roots / 2;
-        blocks = h->ov_want_blocks ? h->ov_want_blocks : roots;
-    } else if (hist) {
-        roots = h->ov_hw_roots + h->ov_hw_roots / 4 + 64;
-        const uint32_t child = h->ov_hw_nodes > h->ov_hw_roots ? h->ov_hw_nodes - h->ov_hw_roots : 0u;
-        nodes_extra = child + child / 4 + 256;
-        blocks = h->ov_hw_blocks + h->ov_hw_blocks / 4 + 64;
-    } else {
-        roots = (uint32_t)std::min<size_t>(std::max<size_t>(2048, n_pts_scan / 18), std::max<size_t>(1024, n_pts_scan));
-        nodes_extra = roots / 2;
-        blocks = roots;
-    }
-    uint32_t hash_cap = next_pow2(roots + roots / 4);       // the roots' records ARE the table entries: node ids [0, hash_cap); load <= 0.8 (0.57 for the bench's scans)
-    LkOverlay& o = h->ov;
-    if (grow) {   // never below what is there; what overflowed is doubled
-        hash_cap = std::max(hash_cap, o.hash_cap), nodes_extra = std::max(nodes_extra, o.nodes_cap - o.hash_cap), blocks = std::max(blocks, o.blocks_cap);
-        if (grow & LK_E_HASH_FULL) hash_cap *= 2;
-        if (grow & LK_E_NODES_FULL) nodes_extra = nodes_extra * 2 + 256;
-        if (grow & LK_E_BLOCKS_FULL) blocks *= 2;
-    }
-    const uint32_t nodes_cap = hash_cap + nodes_extra;        // children from hash_cap upwards
-    const uint32_t scan_cap = (uint32_t)((biggest_bucket + 63) & ~(size_t)63);
-    const size_t cells = (size_t)fmap.gdim[0] * (size_t)fmap.gdim[1] * (size_t)fmap.gdim[2];
-    const uint32_t bit_words = (uint32_t)((cells + 31) / 32);
-    const bool fits = S <= h->ov_slots && hash_cap <= o.hash_cap && nodes_cap - hash_cap <= o.nodes_cap - o.hash_cap && blocks <= o.blocks_cap &&
-                      scan_cap <= o.scan_cap && bit_words <= o.bit_words;
-    // far too large for what the scans use (measured by an earlier replay, or asked for explicitly): released and re-made
-    const bool oversized = (hist || h->ov_want_roots) && !grow && (o.hash_cap > 2 * hash_cap || (size_t)o.blocks_cap > 2 * (size_t)blocks + 1024);
-    if (fits && !oversized) return LK_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint32_t S2 = oversized ? S : std::max(S, h->ov_slots);
-    LkOverlay n = {};
-    if (oversized) {
-        n.hash_cap = hash_cap, n.nodes_cap = nodes_cap, n.blocks_cap = blocks, n.scan_cap = scan_cap, n.bit_words = bit_words;
-    } else {
-        n.hash_cap = std::max(hash_cap, o.hash_cap);
-        n.nodes_cap = n.hash_cap + std::max(nodes_extra, o.nodes_cap > o.hash_cap ? o.nodes_cap - o.hash_cap : 0u);
-        n.blocks_cap = std::max(blocks, o.blocks_cap), n.scan_cap = std::max(scan_cap, o.scan_cap), n.bit_words = std::max(bit_words, o.bit_words);
-    }
-    ov_free(h);
-    h->ov = n;
-    const size_t s = S2;
-    size_t total = 0;
-    auto get = [&](auto** q, size_t bytes) -> hipError_t {
-        total += bytes;
-        return hipMalloc((void**)q, bytes);
-    };
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = get(&o.keys, s * n.hash_cap * sizeof(unsigned long long));
-    if (e == hipSuccess) e = get(&o.planes, s * n.nodes_cap * sizeof(lk_plane_rec));
-    if (e == hipSuccess) e = get(&o.match, s * n.nodes_cap * sizeof(lk_match_rec));
-    if (e == hipSuccess) e = get(&o.nodes, s * n.nodes_cap * sizeof(lk_node_rec));
-    if (e == hipSuccess) e = get(&o.blocks, s * n.blocks_cap * sizeof(lk_block_rec));
-    if (e == hipSuccess) e = get(&o.counters, s * LK_CTR_COUNT * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.touched, s * n.scan_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.next, s * n.scan_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.scratch, s * n.scan_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.gidx, s * n.scan_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.groups, s * n.scan_cap * 2 * sizeof(LkGroup));
-    if (e == hipSuccess) e = get(&o.slots, s * n.hash_cap * LK_SLOTS * sizeof(float4));
-    if (e == hipSuccess) e = get(&o.free_list, s * n.blocks_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.freed_next, s * n.blocks_cap * sizeof(int));
-    if (e == hipSuccess) e = get(&o.dirty, s * n.hash_cap * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.frozen, (size_t)n.bit_words * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
-    if (e == hipSuccess) e = get(&o.sums, s * n.hash_cap * sizeof(LkLeafSum));
-    if (e == hipSuccess) e = get(&o.base_sums, (size_t)h->map.max_nodes * sizeof(LkLeafSum));
-    if (e == hipSuccess) e = get(&o.cplx, s * n.scan_cap * 2 * sizeof(int));
-    if (e == hipSuccess) e = get(&o.ptroot, s * n.scan_cap * sizeof(int));
-    if (e == hipSuccess && !h->d_ov_status) e = hipMalloc(&h->d_ov_status, 8 * sizeof(unsigned int));
-    if (e == hipSuccess && getenv("LEGKILO_POISON_POOLS")) {
-        // test aid: fresh pools hold 0x5a bytes instead of whatever the allocator hands out (usually zeros) - a kernel that trusts a record
-        // nobody has written then faults HERE AND NOW, not in the one process whose allocation history leaves garbage there
-        hipLaunchKernelGGL(lk_ov_poison_nodes_kernel, dim3((unsigned int)((s * n.nodes_cap + 255) / 256)), dim3(256), 0, h->stream, o.nodes, s * n.nodes_cap);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        ov_free(h);
-        char buf[256];
-        snprintf(buf, sizeof(buf), "overlay pools for %u scans (%u root entries / %u child nodes / %u point blocks each) do not fit: %s (lk_overlay_reserve sets smaller per-scan capacities)",
-                 S2, n.hash_cap, n.nodes_cap - n.hash_cap, n.blocks_cap, hipGetErrorString(e));
-        return fail(h, LK_ERR_CAPACITY, buf);
-    }
-    h->ov_slots = S2;
-    h->ov_pool_bytes = total;
-    hipLaunchKernelGGL(lk_ov_init_kernel, dim3((n.hash_cap + 255) / 256, S2), dim3(256), 0, h->stream, h->ov);
-    HIPCHK(h, hipGetLastError());
-    return LK_OK;
-}
-
-int lk_overlay_reserve(lk_handle* h, uint32_t roots_per_scan, uint32_t nodes_per_scan, uint32_t blocks_per_scan) {
-    CHECK_H(h);
-    if ((roots_per_scan && roots_per_scan < 16) || (nodes_per_scan && nodes_per_scan < roots_per_scan) || (blocks_per_scan && blocks_per_scan < 16))
-        return fail(h, LK_ERR_INVALID, "overlay capacities too small (0 = derive from the scan size)");
-    h->ov_want_roots = roots_per_scan, h->ov_want_nodes = nodes_per_scan, h->ov_want_blocks = blocks_per_scan;
-    if (h->ov_slots) {   // pools of another shape are released; the next replay allocates what it needs
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        ov_free(h);
-    }
-    return LK_OK;
-}
-
-}  // extern "C"
-// the overlay pools as a group of slots starting at slot s0 sees them: every per-slot array advanced by s0 slots (the kernels index by blockIdx.y)
-static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
-    LkOverlay r = o;
-    r.keys += s0 * o.hash_cap;
-    r.planes += s0 * o.nodes_cap, r.match += s0 * o.nodes_cap, r.nodes += s0 * o.nodes_cap;
-    r.blocks += s0 * o.blocks_cap;
-    r.counters += s0 * LK_CTR_COUNT;
-    r.touched += s0 * o.scan_cap, r.next += s0 * o.scan_cap, r.scratch += s0 * o.scan_cap, r.gidx += s0 * o.scan_cap;
-    r.groups += s0 * o.scan_cap * 32;
-    r.slots += s0 * o.hash_cap * LK_SLOTS * 4;
-    r.free_list += s0 * o.blocks_cap, r.freed_next += s0 * o.blocks_cap;
-    r.dirty += s0 * o.hash_cap;
-    r.bits += s0 * o.bit_words;
-    r.jobs += s0 * o.hash_cap * LK_INLINE_GROUPS;
-    r.sums += s0 * o.hash_cap;
-    r.cplx += s0 * o.scan_cap * 2;
-    r.ptroot += s0 * o.scan_cap;
-    return r;   // frozen, base_sums, newroot, spec: shared by all slots
-}
-extern "C" {
-int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, size_t n_pts, double t_begin, const uint32_t* bucket_off,
-                                const double* bucket_dt, size_t n_buckets, lk_pose* out) {
-    CHECK_H(h);
-    if (n_scans == 0 || n_scans > h->cfg.n_slots) return fail(h, LK_ERR_INVALID, "n_scans must be in [1, n_slots]");
-    if (n_pts == 0 || n_buckets == 0) return fail(h, LK_ERR_INVALID, "empty scans");
-    if (!d_pts || !bucket_off || !bucket_dt) return fail(h, LK_ERR_INVALID, "null argument");
-    const int S = (int)n_scans;
-    std::vector<size_t> live;
-    size_t biggest = 0;
-    for (size_t b = 0; b < n_buckets; ++b) {
-        if (bucket_off[b + 1] < bucket_off[b] || bucket_off[b + 1] > n_pts) return fail(h, LK_ERR_INVALID, "bucket offsets must be non-decreasing and end inside the scan");
-        if (!std::isfinite(bucket_dt[b]) || (b > 0 && bucket_dt[b] < bucket_dt[b - 1])) return fail(h, LK_ERR_INVALID, "bucket times must be finite and non-decreasing");
-        if (bucket_off[b + 1] == bucket_off[b]) continue;
-        if ((size_t)(bucket_off[b + 1] - bucket_off[b]) > h->map.max_scan) return fail(h, LK_ERR_CAPACITY, "bucket exceeds max_scan_points");
-        biggest = std::max(biggest, (size_t)(bucket_off[b + 1] - bucket_off[b]));
-        live.push_back(b);
-    }
-    if (live.empty()) return fail(h, LK_ERR_INVALID, "empty scans");
-    int rc = join_side_streams(h);   // an asynchronous frozen-map batch may still be using the filter slots
-    if (rc) return rc;
-    LkMap fmap;
-    rc = frozen_map(h, &fmap);
-    if (rc) return rc;
-    if (!fmap.grid_on) return fail(h, LK_ERR_STATE, "overlay replay needs the frozen-map grid (root keys' bounding box too large, LEGKILO_GRID=0, or out of device memory)");
-    rc = ov_reserve(h, (uint32_t)S, n_pts, biggest, fmap);
-    if (rc) return rc;
-    // the batch's priors, kept for a second attempt: a scan whose overlay outgrows pools that were sized by this library (first guess, or
-    // the previous replay's high-water marks) makes the pools grow and the whole batch run again - only capacities the caller has set
-    // explicitly (lk_overlay_reserve) fail with LK_ERR_CAPACITY
-    if (h->ov_priors_cap < (size_t)S) {
-        if (h->d_ov_priors) hipFree(h->d_ov_priors), h->d_ov_priors = nullptr, h->ov_priors_cap = 0;
-        HIPCHK(h, hipMalloc(&h->d_ov_priors, sizeof(LkFilter) * (size_t)S));
-        h->ov_priors_cap = (size_t)S;
-    }
-    HIPCHK(h, hipMemcpyAsync(h->d_ov_priors, h->d_filters, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, h->stream));
-    unsigned int stt[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    for (int attempt = 0;; ++attempt) {
-    const LkOverlay ov = h->ov;
-    hipStream_t st = h->stream;
-    rc = zero_scan_counters(h, 0, (uint32_t)S);
-    if (rc) return rc;
-    hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, h->d_filters, S, t_begin);
-    HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
-    static const bool frozen_bits = getenv("LEGKILO_OV_FROZEN_BITS") == nullptr || atoi(getenv("LEGKILO_OV_FROZEN_BITS")) != 0;   // 0: every point through the probes and the walk (A/B)
-    if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
-    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
-    const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
-    // root pass: the fast path (lk_ov_point_geom_kernel + lk_ov_root_lane_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
-    // (LEGKILO_OV_FAST=0: the generic pass over every touched root, round 4's path; A/B)
-    // LEGKILO_OV_FAST: 1 (default) = the fast path - one thread per point (geometry) + one lane per root (lk_ov_point_geom_kernel,
-    // lk_ov_root_lane_kernel), the generic pass for what they leave; 0 = the generic pass over every touched root (round 4's path; A/B)
-    static const bool ov_fast = getenv("LEGKILO_OV_FAST") == nullptr || atoi(getenv("LEGKILO_OV_FAST")) != 0;
-    static const int root_waves = getenv("LEGKILO_OV_ROOT_WAVES") ? atoi(getenv("LEGKILO_OV_ROOT_WAVES")) : 3;   // generic pass without the fit: 184 VGPRs at 2 waves, 168 at 3
-    const auto root_kernel = ov_fast ? (root_waves >= 4 ? lk_ov_insert_root_kernel<4, true> : root_waves == 3 ? lk_ov_insert_root_kernel<3, true> : lk_ov_insert_root_kernel<2, true>)
-                                     : (root_waves >= 4 ? lk_ov_insert_root_kernel<4, false> : root_waves == 3 ? lk_ov_insert_root_kernel<3, false> : lk_ov_insert_root_kernel<2, false>);
-    if (ov_fast) LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
-    static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
-    static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
-    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
-    static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
-    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 3): the scans are independent, and the passes of a bucket are of two
-    // kinds - the root pass issues VALU work at 2.8 TB/s of HBM traffic, the others (re-projection, copy-on-write, plane fits) only move
-    // bytes - so one group's root pass runs beside the other group's memory passes.  A group is the same launches with every per-slot
-    // array offset to its first slot (ov_at).  Profiling mode (per-launch events + sync) and small batches stay on one stream.
-    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 3;
-    const int ngroups = (!h->profiling && S >= 64 * ov_groups_env) ? ov_groups_env : 1;
-    hipStream_t streams[lk_handle::kMaxGroups];
-    streams[0] = h->stream;
-    for (int g = 1; g < lk_handle::kMaxGroups; ++g) streams[g] = h->side[g - 1];
-    if (ngroups > 1) {
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        for (int g = 1; g < ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(streams[g], h->ev_fork, 0));
-    }
-    const LkOverlay ov_all = ov;
-    // the enqueue of every group's launches; whatever it returns, the side streams are joined below before this call returns (a failed
-    // launch must not leave them writing filters, partials and pools behind the caller's back)
-    auto enqueue_all = [&]() -> int {
-    for (int grp = 0; grp < ngroups; ++grp) {
-        const int s0 = (int)((long)S * grp / ngroups), sn = (int)((long)S * (grp + 1) / ngroups) - s0;
-        const unsigned int per = std::max(std::max(ov_all.hash_cap, ov_all.bit_words), (unsigned int)LK_CTR_COUNT);   // root records, bitmap words, counters
-        LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, sn), dim3(256), 0, streams[grp], ov_at(ov_all, (size_t)s0)));
-    }
-    for (size_t k = 0; k < live.size(); ++k)
-    for (int grp = 0; grp < ngroups; ++grp) {
-        const int s0 = (int)((long)S * grp / ngroups), Sg = (int)((long)S * (grp + 1) / ngroups) - s0;   // this group's slots
-        const LkOverlay ov = ov_at(ov_all, (size_t)s0);
-        hipStream_t st = streams[grp];
-        LkFilter* fl = h->d_filters + s0;
-        double* parts = h->d_partials + (size_t)s0 * h->part_stride;
-        const size_t b = live[k];
-        const int nb = (int)(bucket_off[b + 1] - bucket_off[b]);
-        const double t = t_begin + bucket_dt[b];
-        const int nblk = (nb + LK_RB - 1) / LK_RB;
-        const lk_point* pts = d_pts + (size_t)s0 * n_pts + bucket_off[b];
-        const LkPtSrc src = {pts, n_pts, nb, nullptr, nullptr, 0, 0};
-        if (k == 0) LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q, t, 2));
-        LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, Sg), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, parts, h->part_stride));
-        LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, nblk * (LK_RB / LK_WAVE), h->part_stride, t, h->d_Q, 0.0, 1));
-        // the bucket's insert into every slot's overlay, from the posterior (KILO.cc:216-233)
-        LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, ov));
-        LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
-        // per-root passes: enough waves per slot to cover its touched roots a few at a time, ~4096 workgroups per launch at least
-        const int per_slot = ov_waves_per_slot ? ov_waves_per_slot : std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
-        // (measured at 1024 slots x 20 000-point buckets, workgroups per slot: copy-on-write 2.8 / 6.6 / 12.2 ms per batch at 4 / 16 / 32 - a wave takes 64
-        // roots, more waves only find nothing to do; root pass 12.8 / 11.0 / 11.7 - a wave works through its roots one after the other)
-        const int mat_per_slot = ov_mat_wg ? ov_mat_wg : std::max(1, per_slot / 2), root_per_slot = ov_root_wg ? ov_root_wg : 3 * per_slot;
-        LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(ov_fast ? lk_ov_materialise_kernel<true> : lk_ov_materialise_kernel<false>, dim3(mat_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr));
-        // one WAVE per touched root (the leaf's plane fit only decided), then the fits one LANE each
-        if (ov_fast) {
-            LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, Sg), dim3(256), 0, st, ov, h->pr, fl, src));
-            static const int lane_blocks = getenv("LEGKILO_OV_LANE_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_LANE_BLOCKS"))) : 0;
-            LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(lane_blocks ? lane_blocks : std::max(4, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(std::max(1, per_slot / 2), Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
-        } else {
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL(root_kernel, dim3(root_per_slot, Sg), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
-        }
-        LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-        static const bool fit_group = getenv("LEGKILO_OV_FIT_GROUP") == nullptr || atoi(getenv("LEGKILO_OV_FIT_GROUP")) != 0;   // 0: round 5's one lane per fit (A/B)
-        if (fit_group)
-            LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_group_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-        else
-            LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(fit_blocks, Sg), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-        static const int ov_apply_wg = getenv("LEGKILO_OV_APPLY_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_APPLY_WG"))) : 0;
-        static const int ov_fb_wg = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
-        LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(ov_apply_wg ? ov_apply_wg : per_slot, Sg), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
-        LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min(Sg, ov_fb_wg ? ov_fb_wg : 128)), dim3(LK_MB), 0, st, ov, h->pr, fl, src, Sg));   // (1 024 slots, workgroups 8 / 32 / 128 / 256 / 512: 0.54 / 0.26 / 0.15 / 0.17 / 0.16 ms per batch; a workgroup or more per slot: 0.34)
-        if (k + 1 < live.size())
-            LAUNCH(h, "predict", hipLaunchKernelGGL(lk_update_wave_kernel, dim3(Sg), dim3(LK_WAVE), 0, st, fl, parts, 0, h->part_stride, 0.0, h->d_Q,
-                                                    t_begin + bucket_dt[live[k + 1]], 2));
-    }
-    HIPCHK(h, hipGetLastError());
-    return LK_OK;
-    };
-    rc = enqueue_all();
-    for (int g = 1; g < ngroups; ++g) {  // join: everything after this point on h->stream sees every group's results
-        if (rc) {
-            (void)hipStreamSynchronize(streams[g]);   // error path: nothing of this call keeps running
-            continue;
-        }
-        HIPCHK(h, hipEventRecord(h->ev_join[g - 1], streams[g]));
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[g - 1], 0));
-    }
-    if (rc) {
-        (void)hipStreamSynchronize(h->stream);
-        return rc;
-    }
-    h->ov_last_slots = (uint32_t)S, h->ov_gen = h->map_gen;
-    const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
-    HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    const bool growable = !h->ov_want_roots && !(stt[0] & ~(LK_E_HASH_FULL | LK_E_NODES_FULL | LK_E_BLOCKS_FULL)) && attempt < 4;
-    if (!stt[0] || !growable) break;
-    HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_ov_priors, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
-    rc = ov_reserve(h, (uint32_t)S, n_pts, biggest, fmap, stt[0]);
-    if (rc) return rc;
-    }   // attempts
-    const LkOverlay& ov = h->ov;
-    hipStream_t st = h->stream;
-    if (!stt[0]) h->ov_hw_roots = stt[3], h->ov_hw_nodes = stt[1], h->ov_hw_blocks = stt[2], h->ov_hw_npts = n_pts;
-    if (out) {
-        std::vector<lk_pose> tmp(n_scans);
-        rc = fetch_poses(h, tmp.data(), S);   // synchronises
-        if (rc) return rc;
-        memcpy(out, tmp.data(), sizeof(lk_pose) * n_scans);
-    } else {
-        HIPCHK(h, hipStreamSynchronize(st));
-    }
-    if (stt[0] & LK_E_KEY_RANGE) {
-        char buf[200];
-        snprintf(buf, sizeof(buf), "overlay replay: a point of slot %u lies in a voxel whose key is outside the +-2^20 range of the private root tables' packed keys (%.0f km from the origin at this voxel size)",
-                 stt[4], 1048576.0 * h->cfg.max_voxel_size / 1000.0);
-        return fail(h, LK_ERR_INVALID, buf);
-    }
-    if (stt[0]) {
-        char buf[256];
-        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots; per-scan pools: %u root entries, %u child nodes, %u blocks (lk_overlay_reserve)",
-                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.hash_cap, ov.nodes_cap - ov.hash_cap, ov.blocks_cap);
-        return fail(h, LK_ERR_CAPACITY, buf);
-    }
-    return LK_OK;
-}
-
-int lk_batch_replay_overlay_ragged_dev(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uint64_t* scan_off, const uint32_t* n_buckets,
-                                       const uint32_t* bucket_off, const double* bucket_dt, const double* t_begin, const uint32_t* n_msg, const void* msgs,
-                                       int msg_kind, lk_pose* out) {
-    CHECK_H(h);
-    if (msg_kind < 0 || msg_kind > 2) return fail(h, LK_ERR_INVALID, "msg_kind must be 0 (no messages), 1 (lk_imu) or 2 (lk_kin_imu)");
-    if (msg_kind && !n_msg) return fail(h, LK_ERR_INVALID, "null argument");
-    return ragged_replay(h, d_pts, n_scans, scan_off, n_buckets, bucket_off, bucket_dt, t_begin, msg_kind ? n_msg : nullptr, msgs,
-                         msg_kind == 2 ? sizeof(lk_kin_imu) : sizeof(lk_imu), out, true);
-}
-}  // extern "C"
-// The ragged batch WITH insert, bucket INDEX after bucket index over all scans (one launch of every pass per index, grids sized by that
-// index's longest bucket; a scan that has run out of buckets leaves every launch at once): per index b - the scan's messages up to the
-// bucket's time + predict (lk_rag_advance_kernel), residual with the overlay lookup, update, then the insert passes of
-// lk_batch_replay_overlay_dev on each scan's own bucket (LkPtSrc).  One stream: a recorded run's buckets are small, the launches are what it costs.
-static int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb,
-                                 const int* max_n, size_t max_scan_pts, int msg_kind, lk_pose* out) {
-    const int S = (int)S_;
-    int rc = join_side_streams(h);
-    if (rc) return rc;
-    LkMap fmap;
-    rc = frozen_map(h, &fmap);
-    if (rc) return rc;
-    if (!fmap.grid_on) return fail(h, LK_ERR_STATE, "overlay replay needs the frozen-map grid (root keys' bounding box too large, LEGKILO_GRID=0, or out of device memory)");
-    rc = ov_reserve(h, (uint32_t)S, max_scan_pts, (size_t)biggest, fmap);
-    if (rc) return rc;
-    if (h->ov_priors_cap < (size_t)S) {
-        if (h->d_ov_priors) hipFree(h->d_ov_priors), h->d_ov_priors = nullptr, h->ov_priors_cap = 0;
-        HIPCHK(h, hipMalloc(&h->d_ov_priors, sizeof(LkFilter) * (size_t)S));
-        h->ov_priors_cap = (size_t)S;
-    }
-    hipStream_t st = h->stream;
-    HIPCHK(h, hipMemcpyAsync(h->d_ov_priors, h->d_filters, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
-    static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
-    const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
-    unsigned int stt[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    for (int attempt = 0;; ++attempt) {
-        const LkOverlay ov = h->ov;
-        LkFilter* fl = h->d_filters;
-        rc = zero_scan_counters(h, 0, (uint32_t)S);
-        if (rc) return rc;
-        hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, S, d_tbegin);
-        HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
-        LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
-        LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
-        {
-            const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);
-            LAUNCH(h, "ov_reset", hipLaunchKernelGGL(lk_ov_reset_kernel, dim3((per + 255) / 256, S), dim3(256), 0, st, ov));
-        }
-        for (size_t b = 0; b < ldb; ++b) {
-            const int nb = std::max(1, max_n ? max_n[b] : biggest);
-            const int nblk = (nb + LK_RB - 1) / LK_RB;
-            const LkPtSrc src = {d_pts, 0, 0, rg.pt_off, rg.nb, rg.ldb, (int)b};
-            static const bool rag_fuse = getenv("LEGKILO_RAG_FUSE") == nullptr || atoi(getenv("LEGKILO_RAG_FUSE")) != 0;   // 0: the five launches (A/B, and the bit-identity reference)
-            if (rag_fuse && biggest <= LK_SCAN_WAVE_MAX) {
-                const auto front = (h->pr.ext_identity && xid_enable) ? lk_rag_ov_front_kernel<true> : lk_rag_ov_front_kernel<false>;
-                LAUNCH(h, "rag_ov_front", hipLaunchKernelGGL(front, dim3(S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, h->d_Q, rg, d_pts, (int)b, msg_kind));
-            } else {
-                LAUNCH(h, "rag_advance", hipLaunchKernelGGL(lk_rag_advance_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_Q, rg, (int)b, msg_kind));
-                LAUNCH(h, "ov_residual", hipLaunchKernelGGL(res_kernel, dim3(nblk, S), dim3(LK_RB), 0, st, fmap, ov, h->pr, fl, src, h->d_partials, h->part_stride));
-                LAUNCH(h, "update", hipLaunchKernelGGL(lk_update_wave_ragged_kernel, dim3(S), dim3(LK_WAVE), 0, st, fl, h->d_partials, h->part_stride, h->d_Q, rg, (int)b, 1));
-                LAUNCH(h, "ov_begin", hipLaunchKernelGGL(lk_ov_begin_kernel, dim3(S), dim3(LK_WAVE), 0, st, ov));
-                LAUNCH(h, "ov_reproject", hipLaunchKernelGGL(lk_ov_reproject_kernel, dim3((nb + LK_WAVE - 1) / LK_WAVE, S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr, fl, src));
-            }
-            const int per_slot = std::max(1, std::min((nb + 255) / 256, std::max(2, (4096 + S - 1) / S)));
-            if (rag_fuse && biggest <= LK_SCAN_WAVE_MAX) {
-                LAUNCH(h, "ov_mid", hipLaunchKernelGGL(lk_ov_mid_kernel<true>, dim3(S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
-            } else {
-                LAUNCH(h, "ov_materialise", hipLaunchKernelGGL(lk_ov_materialise_kernel<true>, dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr));
-                LAUNCH(h, "ov_point_geom", hipLaunchKernelGGL(lk_ov_point_geom_kernel, dim3((nb + 255) / 256, S), dim3(256), 0, st, ov, h->pr, fl, src));
-                LAUNCH(h, "ov_root_lane", hipLaunchKernelGGL(lk_ov_root_lane_kernel, dim3(std::max(1, (nb + 16 * LK_WAVE - 1) / (16 * LK_WAVE)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            }
-            LAUNCH(h, "ov_insert_root", hipLaunchKernelGGL((lk_ov_insert_root_kernel<3, true>), dim3(std::max(1, per_slot / 2), S), dim3(LK_MB), 0, st, fmap, ov, h->pr, fl, src));
-            LAUNCH(h, "ov_fit_eig", hipLaunchKernelGGL(lk_ov_fit_eig_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            static const bool fit_group_r = getenv("LEGKILO_OV_FIT_GROUP") == nullptr || atoi(getenv("LEGKILO_OV_FIT_GROUP")) != 0;
-            if (fit_group_r)
-                LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_group_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            else
-                LAUNCH(h, "ov_fit_lane", hipLaunchKernelGGL(lk_ov_fit_lane_kernel, dim3(std::max(1, std::min(8, (nb + 63) / 64)), S), dim3(LK_WAVE), 0, st, fmap, ov, h->pr));
-            LAUNCH(h, "ov_insert_apply", hipLaunchKernelGGL(lk_ov_insert_apply_kernel, dim3(per_slot, S), dim3(LK_MB), 0, st, ov, h->pr, fl, src));
-            static const int ov_fb_wg_r = getenv("LEGKILO_OV_FB_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_FB_WG"))) : 0;
-            LAUNCH(h, "ov_insert_fallback", hipLaunchKernelGGL(lk_ov_insert_fallback_kernel, dim3(std::min((int)S, ov_fb_wg_r ? ov_fb_wg_r : 128)), dim3(LK_MB), 0, st, ov, h->pr, fl, src, (int)S));
-        }
-        HIPCHK(h, hipGetLastError());
-        h->ov_last_slots = (uint32_t)S, h->ov_gen = h->map_gen;
-        const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
-        HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((S + 255) / 256, 64)), dim3(256), 0, st, ov, (unsigned int)S, h->d_ov_status);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        const bool growable = !h->ov_want_roots && !(stt[0] & ~(LK_E_HASH_FULL | LK_E_NODES_FULL | LK_E_BLOCKS_FULL)) && attempt < 4;
-        if (!stt[0] || !growable) break;
-        HIPCHK(h, hipMemcpyAsync(h->d_filters, h->d_ov_priors, sizeof(LkFilter) * (size_t)S, hipMemcpyDeviceToDevice, st));
-        rc = ov_reserve(h, (uint32_t)S, max_scan_pts, (size_t)biggest, fmap, stt[0]);
-        if (rc) return rc;
-    }
-    if (!stt[0]) h->ov_hw_roots = stt[3], h->ov_hw_nodes = stt[1], h->ov_hw_blocks = stt[2], h->ov_hw_npts = max_scan_pts;
-    if (out) {
-        std::vector<lk_pose> tmp((size_t)S);
-        rc = fetch_poses(h, tmp.data(), S);
-        if (rc) return rc;
-        memcpy(out, tmp.data(), sizeof(lk_pose) * (size_t)S);
-    }
-    if (stt[0] & LK_E_KEY_RANGE) {
-        char buf[200];
-        snprintf(buf, sizeof(buf), "overlay replay: a point of slot %u lies in a voxel whose key is outside the +-2^20 range of the private root tables' packed keys (%.0f km from the origin at this voxel size)",
-                 stt[4], 1048576.0 * h->cfg.max_voxel_size / 1000.0);
-        return fail(h, LK_ERR_INVALID, buf);
-    }
-    if (stt[0]) {
-        const LkOverlay& ov = h->ov;
-        char buf[256];
-        snprintf(buf, sizeof(buf), "overlay pool overflow in slot %u (bits 0x%x: 1 private root table, 2 nodes, 4 point blocks, 8 work lists); largest use over the slots: %u nodes, %u blocks, %u roots; per-scan pools: %u root entries, %u child nodes, %u blocks (lk_overlay_reserve)",
-                 stt[4], stt[0], stt[1], stt[2], stt[3], ov.hash_cap, ov.nodes_cap - ov.hash_cap, ov.blocks_cap);
-        return fail(h, LK_ERR_CAPACITY, buf);
-    }
-    return LK_OK;
-}
-extern "C" {
-
-int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uint32_t* max_blocks) {
-    CHECK_H(h);
-    if (!h->ov_last_slots || !h->ov.counters) return fail(h, LK_ERR_STATE, "no overlay replay's pools are held by this handle (none has run, or lk_overlay_reserve released them)");
-    const unsigned int init[8] = {0u, 0u, 0u, 0u, 0xffffffffu, 0u, 0u, 0u};
-    unsigned int stt[8];
-    HIPCHK(h, hipMemcpyAsync(h->d_ov_status, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(lk_ov_status_kernel, dim3(std::min((h->ov_last_slots + 255u) / 256u, 64u)), dim3(256), 0, h->stream, h->ov, h->ov_last_slots, h->d_ov_status);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(stt, h->d_ov_status, sizeof(stt), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (max_nodes) *max_nodes = stt[1];
-    if (max_blocks) *max_blocks = stt[2];
-    if (max_roots) *max_roots = stt[3];
-    return LK_OK;
-}
-
-int lk_overlay_pool_bytes(lk_handle* h, uint64_t* bytes, uint32_t* root_entries, uint32_t* child_nodes, uint32_t* blocks) {
-    CHECK_H(h);
-    if (bytes) *bytes = (uint64_t)h->ov_pool_bytes;
-    if (root_entries) *root_entries = h->ov.hash_cap;
-    if (child_nodes) *child_nodes = h->ov.nodes_cap - h->ov.hash_cap;
-    if (blocks) *blocks = h->ov.blocks_cap;
     return LK_OK;
 }
 

@@ -220,12 +220,20 @@ __device__ void dev_kalman_apply(LkFilter* f, FilterSmem& sm, int M) {
     __syncthreads();
 }
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB) lk_predict_kernel(LkFilter* filters, const double* __restrict__ Q, double t);
+#else
 __global__ void __launch_bounds__(LK_FB) lk_predict_kernel(LkFilter* filters, const double* __restrict__ Q, double t) {
     __shared__ FilterSmem sm;
     dev_predict(&filters[blockIdx.x], Q, t, sm);
 }
+#endif
 
 // plain ESKF::predict(dt, prop_state, prop_cov) for the class-surface call (eskf.cc:83-89)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB)
+    lk_predict_dt_kernel(LkFilter* filters, const double* __restrict__ Q, double dt, int prop_state, int prop_cov);
+#else
 __global__ void __launch_bounds__(LK_FB)
     lk_predict_dt_kernel(LkFilter* filters, const double* __restrict__ Q, double dt, int prop_state, int prop_cov) {
     __shared__ FilterSmem sm;
@@ -263,8 +271,12 @@ __global__ void __launch_bounds__(LK_FB)
         f->last_predict_t = save[0], f->last_update_t = save[1];
     }
 }
+#endif
 
 // getFx / getFunctionf read-outs for the class surface
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void lk_fx_kernel(const LkFilter* filters, int slot, double dt, double* Fx, double* fvec);
+#else
 __global__ void lk_fx_kernel(const LkFilter* filters, int slot, double dt, double* Fx, double* fvec) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double* x = filters[slot].x;
@@ -289,6 +301,7 @@ __global__ void lk_fx_kernel(const LkFilter* filters, int slot, double dt, doubl
     for (int i = 0; i < 3; ++i) fvec[i] = dt * x[27 + i], fvec[3 + i] = dt * x[12 + i];
     fvec[6] = dt * (Ra.x + x[21]), fvec[7] = dt * (Ra.y + x[22]), fvec[8] = dt * (Ra.z + x[23]);
 }
+#endif
 
 // ---- information-form point update from A (21, upper tri), b (6):  eskf.cc:91-113 via
 //   S = I6 + A P66,  G = [A P[0:6,:] | b],  X = S^-1 G,  dx = P[:,0:6] X[:,30],  P -= P[:,0:6] X[:,0:30]
@@ -389,6 +402,11 @@ __device__ __forceinline__ void dev_update_reduce(LkFilter* f, const double* __r
         dev_predict(f, Q, t_next, sm);
     }
 }
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB)
+    lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
+                     const double* __restrict__ Q, double t_next, int do_predict);
+#else
 __global__ void __launch_bounds__(LK_FB)
     lk_update_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
                      const double* __restrict__ Q, double t_next, int do_predict) {
@@ -397,6 +415,7 @@ __global__ void __launch_bounds__(LK_FB)
     __shared__ double tot[LK_NPART];
     dev_update_reduce(&filters[blockIdx.x], partials + (size_t)blockIdx.x * slot_stride, nblk, t, Q, t_next, do_predict, sm, red, tot);
 }
+#endif
 // What the insert of a bucket needs of the posterior (load_bucket_const: R, p, the rotation / position blocks of P - all in rows
 // 0..5 of P - and `updated`), copied aside: in the pipelined stream path the insert runs on its own HIP stream while the main
 // stream already propagates filters[0] to the next bucket.
@@ -1161,15 +1180,26 @@ __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const
     }
 }
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+    lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
+                          const double* __restrict__ Q, double t_next, int mode);
+#else
 __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
     lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
                           const double* __restrict__ Q, double t_next, int mode) {
     __shared__ WaveSmem sm;
     dev_update_wave(&filters[blockIdx.x], sm, partials + (size_t)blockIdx.x * slot_stride, nblk, t, Q, t_next, mode);
 }
+#endif
 
 // Ragged batch: bucket b of every scan that has one (b == -1: the predict to each scan's first bucket); times, bucket
 // sizes and "is there a next bucket" come from the scan's own tables.
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+    lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
+                                 const double* __restrict__ Q, LkRagged rg, int b, int update_only = 0);
+#else
 __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
     lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
                                  const double* __restrict__ Q, LkRagged rg, int b, int update_only = 0) {
@@ -1193,13 +1223,23 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
     const bool has_next = b + 1 < nbk;
     dev_update_wave(&filters[slot], sm, part, (n + LK_WAVE - 1) / LK_WAVE, T[b], Q, has_next ? T[b + 1] : 0.0, has_next ? 3 : 1);
 }
+#endif
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void lk_set_times_ragged_kernel(LkFilter* filters, int n, const double* __restrict__ t_begin);
+#else
 __global__ void lk_set_times_ragged_kernel(LkFilter* filters, int n, const double* __restrict__ t_begin) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n) filters[s].last_predict_t = t_begin[s], filters[s].last_update_t = t_begin[s];
 }
+#endif
 
 // updateByPoints(ObsShared&) on caller rows (class-surface call): one block accumulates A, b
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_points_kernel(LkFilter* filters, int slot, const double* __restrict__ h6, const double* __restrict__ z,
+                         const double* __restrict__ R, int N);
+#else
 __global__ void __launch_bounds__(LK_FB)
     lk_obs_points_kernel(LkFilter* filters, int slot, const double* __restrict__ h6, const double* __restrict__ z,
                          const double* __restrict__ R, int N) {
@@ -1235,6 +1275,7 @@ __global__ void __launch_bounds__(LK_FB)
     __syncthreads();
     if (N > 0) dev_point_update(&filters[slot], sm, &tot[0], &tot[21]);
 }
+#endif
 
 // ---- IMU rows: z and R, KILO.cc:246-253 (thread 0), H = I on cols 9..14 and 18..23
 __device__ void dev_imu_rows(const LkFilter* f, const double* acc, const double* gyr, double acc_scale,
@@ -1255,6 +1296,9 @@ struct LkImuArgs {
 };
 
 // predictUpdateImu, KILO.cc:235-258 + updateByImu, eskf.cc:125-135
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB) lk_imu_kernel(LkFilter* filters, const double* __restrict__ Q, LkImuArgs a);
+#else
 __global__ void __launch_bounds__(LK_FB) lk_imu_kernel(LkFilter* filters, const double* __restrict__ Q, LkImuArgs a) {
     __shared__ FilterSmem sm;
     LkFilter* f = &filters[blockIdx.x];
@@ -1280,8 +1324,13 @@ __global__ void __launch_bounds__(LK_FB) lk_imu_kernel(LkFilter* filters, const 
     dev_kalman_apply(f, sm, 6);
     if (tid == 0) f->last_update_t = a.t;  // KILO.cc:256
 }
+#endif
 
 // updateByImu(ObsShared&) on caller rows, no predict (class-surface call)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_imu_kernel(LkFilter* filters, int slot, const double* __restrict__ z6, const double* __restrict__ R6);
+#else
 __global__ void __launch_bounds__(LK_FB)
     lk_obs_imu_kernel(LkFilter* filters, int slot, const double* __restrict__ z6, const double* __restrict__ R6) {
     __shared__ FilterSmem sm;
@@ -1307,6 +1356,7 @@ __global__ void __launch_bounds__(LK_FB)
     dev_solve(sm, 6, 31);
     dev_kalman_apply(f, sm, 6);
 }
+#endif
 
 // dense-H update shared by the kin path: sm.H (M x 30), sm.vec[32..] = z, sm.fac-free R in sm.B[0..M)
 __device__ void dev_dense_update(LkFilter* f, FilterSmem& sm, int M) {
@@ -1344,6 +1394,9 @@ struct LkKinArgs {
 };
 
 // predictUpdateKinImu, KILO.cc:260-314 + updateByKinImu, eskf.cc:137-145
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB) lk_kin_kernel(LkFilter* filters, const double* __restrict__ Q, LkKinArgs a);
+#else
 __global__ void __launch_bounds__(LK_FB) lk_kin_kernel(LkFilter* filters, const double* __restrict__ Q, LkKinArgs a) {
     __shared__ FilterSmem sm;
     __shared__ int sM;
@@ -1395,8 +1448,14 @@ __global__ void __launch_bounds__(LK_FB) lk_kin_kernel(LkFilter* filters, const 
     dev_dense_update(f, sm, sM);
     if (tid == 0) f->last_update_t = a.k.time_stamp;  // KILO.cc:312
 }
+#endif
 
 // updateByKinImu(ObsShared&) on caller rows, no predict (class-surface call)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_FB)
+    lk_obs_kin_kernel(LkFilter* filters, int slot, const double* __restrict__ ki_h, const double* __restrict__ ki_z,
+                      const double* __restrict__ ki_R, int M);
+#else
 __global__ void __launch_bounds__(LK_FB)
     lk_obs_kin_kernel(LkFilter* filters, int slot, const double* __restrict__ ki_h, const double* __restrict__ ki_z,
                       const double* __restrict__ ki_R, int M) {
@@ -1412,3 +1471,4 @@ __global__ void __launch_bounds__(LK_FB)
     __syncthreads();
     dev_dense_update(f, sm, M);
 }
+#endif

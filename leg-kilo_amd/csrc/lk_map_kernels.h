@@ -1482,6 +1482,10 @@ __global__ void __launch_bounds__(LK_MB, LK_ROOT_WAVES)
 // the root pass over its share of the touched roots; the workgroup that finishes LAST (a ticket) then applies whatever leaf groups
 // the roots with several groups emitted and runs the generic fallback items - both usually none.  Two launches of ~5 us each saved
 // per bucket on a dependent chain of ~25 us; not for large buckets, where hundreds of emitted groups want hundreds of workgroups.
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_MB)
+    lk_insert_small_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, int n);
+#else
 __global__ void __launch_bounds__(LK_MB)
     lk_insert_small_kernel(LkMap map, LkParams pr, const LkFilter* filters, const lk_point* __restrict__ pts, int n) {
     __shared__ int is_last;
@@ -1501,6 +1505,7 @@ __global__ void __launch_bounds__(LK_MB)
     __syncthreads();
     dev_insert_fallback<false>(map, pr, filters, pts, (const lk_pt_rec*)nullptr, n, (int)(threadIdx.x >> 6), LK_MB >> 6);
 }
+#endif
 // (Round 5, measured and not kept: apply + fallback as ONE launch - all workgroups apply, the last one (ticket) runs the fallback items.
 // A kernel that contains the fallback code needs 256 VGPRs + 6.3 KB of scratch per lane, and a 256-workgroup launch of THAT costs ~25 us
 // even when every workgroup leaves after two counter reads: 0.475 against 0.375 ms per 5 x 20 000-point scan.  profiles/EXPERIMENTS.md.)
@@ -1531,6 +1536,9 @@ __global__ void __launch_bounds__(LK_MB)
 }
 
 // hashing half of UpdateVoxelMap for caller-supplied pointWithVar records
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_queue_pv_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ pv, int n);
+#else
 __global__ void __launch_bounds__(256) lk_queue_pv_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ pv, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1540,9 +1548,16 @@ __global__ void __launch_bounds__(256) lk_queue_pv_kernel(LkMap map, LkParams pr
     if (root < 0) return;
     queue_point_on_root(map, root, i);
 }
+#endif
 
 // ------------------------------------------------------------------ first-frame build (voxel_map.cc:287-334)
 // per point: world point (f32 -> f64), first-frame variance (:303-307), root voxel id
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256)
+    lk_build_points_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const float* __restrict__ xyz_world,
+                           const float* __restrict__ xyz_body, int n, lk_pt_rec* __restrict__ bpts,
+                           unsigned int* __restrict__ root_of, int* __restrict__ idx);
+#else
 __global__ void __launch_bounds__(256)
     lk_build_points_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const float* __restrict__ xyz_world,
                            const float* __restrict__ xyz_body, int n, lk_pt_rec* __restrict__ bpts,
@@ -1572,8 +1587,13 @@ __global__ void __launch_bounds__(256)
     root_of[i] = (root < 0) ? 0xffffffffu : (unsigned int)root;
     idx[i] = i;
 }
+#endif
 
 // after the stable sort by root id: segment bounds per root, touched-root list
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256)
+    lk_build_segments_kernel(LkMap map, const unsigned int* __restrict__ keys, int n);
+#else
 __global__ void __launch_bounds__(256)
     lk_build_segments_kernel(LkMap map, const unsigned int* __restrict__ keys, int n) {
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -1587,6 +1607,7 @@ __global__ void __launch_bounds__(256)
     }
     if (s == n - 1 || keys[s + 1] != k) map.nodes[k].pad_[2] = (unsigned int)(s + 1);
 }
+#endif
 
 // init_octo_tree / cut_octo_tree over an index segment (points in bpts, indices idx_in[begin..begin+count))
 template <int L>
@@ -1676,6 +1697,10 @@ __device__ __noinline__ void dev_build_node(const LkMap m, const LkParams pr, in
     node_store(nd, r);
 }
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_MB)
+    lk_build_tree_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ bpts, int* idxA, int* idxB);
+#else
 __global__ void __launch_bounds__(LK_MB)
     lk_build_tree_kernel(LkMap map, LkParams pr, const lk_pt_rec* __restrict__ bpts, int* idxA, int* idxB) {
     const int wave = (blockIdx.x * LK_MB + threadIdx.x) >> 6;
@@ -1687,6 +1712,7 @@ __global__ void __launch_bounds__(LK_MB)
         dev_build_node<0>(map, pr, root, bpts, idxA, idxB, b, e - b);
     }
 }
+#endif
 
 // Start of a bucket's insert phase: clear the per-bucket counters and make the blocks retired during the previous
 // bucket allocatable (see pop_or_bump_block).  One workgroup.
@@ -1713,7 +1739,11 @@ __device__ __forceinline__ void dev_bucket_begin(const LkMap& map) {
         map.counters[LK_CTR_FREED] = 0;
     }
 }
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map);
+#else
 __global__ void __launch_bounds__(256) lk_bucket_begin_kernel(LkMap map) { dev_bucket_begin(map); }
+#endif
 // dev_bucket_begin for ONE WAVE of a larger workgroup (the scan-resident stream kernel's insert wave): no workgroup barrier
 __device__ __forceinline__ void dev_bucket_begin_wave(const LkMap& map) {
     const int lane = threadIdx.x & 63;
@@ -1753,6 +1783,9 @@ __device__ __forceinline__ void dev_stamp_dirty_roots(const LkMap& map, const Lk
 }
 
 // ------------------------------------------------------------------ pool initialisation
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned int n_hash);
+#else
 __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned int n_hash) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_hash) map.hash[i] = make_int4((int)0x80000000, (int)0x80000000, (int)0x80000000, LK_EMPTY);
@@ -1770,8 +1803,12 @@ __global__ void __launch_bounds__(256) lk_pool_init_kernel(LkMap map, unsigned i
     }
     if (i < LK_CTR_COUNT) map.counters[i] = 0;
 }
+#endif
 
 // ---- frozen-map grid (LkMap::grid): bounding box of the root keys, then one cell per root
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned int n_hash, int* __restrict__ mm /* min xyz, max xyz */);
+#else
 __global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned int n_hash, int* __restrict__ mm /* min xyz, max xyz */) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
@@ -1793,9 +1830,14 @@ __global__ void __launch_bounds__(256) lk_grid_bounds_kernel(LkMap map, unsigned
         atomicMax(&mm[3], hi[0]), atomicMax(&mm[4], hi[1]), atomicMax(&mm[5], hi[2]);
     }
 }
+#endif
 // One thread per root: a plane root's record goes into its cell; any other root gets a list header and its subtree's plane
 // nodes, in pre-order (children in index order, a plane is not descended into, nothing below max_layer), appended behind the
 // grid (`cursor` = next free record; the order of the lists among each other does not matter).
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned int n_hash, int max_layer, unsigned int* __restrict__ cursor,
+                                                           unsigned int cand_end);
+#else
 __global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned int n_hash, int max_layer, unsigned int* __restrict__ cursor,
                                                            unsigned int cand_end) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
@@ -1861,8 +1903,12 @@ __global__ void __launch_bounds__(256) lk_grid_fill_kernel(LkMap map, unsigned i
     }
     map.match[map.grid_base + c] = r;
 }
+#endif
 
 // derive the compact match records of imported planes (lk_map_import / lk_map_import_dev)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_derive_match_kernel(LkMap map, int n);
+#else
 __global__ void __launch_bounds__(256) lk_derive_match_kernel(LkMap map, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1871,8 +1917,12 @@ __global__ void __launch_bounds__(256) lk_derive_match_kernel(LkMap map, int n) 
     else
         map.match[i].flags = map.planes[i].flags;
 }
+#endif
 
 // rebuild the hash from imported root records (lk_map_import)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_hash_insert_kernel(LkMap map, LkParams pr, const lk_root_rec* __restrict__ roots, int n);
+#else
 __global__ void __launch_bounds__(256) lk_hash_insert_kernel(LkMap map, LkParams pr, const lk_root_rec* __restrict__ roots, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1889,6 +1939,7 @@ __global__ void __launch_bounds__(256) lk_hash_insert_kernel(LkMap map, LkParams
     }
     atomicOr(&map.counters[LK_CTR_ERR], LK_E_HASH_FULL);
 }
+#endif
 
 // ------------------------------------------------------------------ local map sliding (voxel_map.cc:552-594)
 // clearMemOutOfMap deletes every root voxel (and its whole octree) whose key lies strictly outside a key-space box.
@@ -1904,6 +1955,12 @@ struct LkSlideBox {
     int x_max, x_min, y_max, y_min, z_max, z_min;
 };
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256)
+    lk_slide_mark_kernel(LkMap map, LkSlideBox box, unsigned int n_hash, unsigned int* __restrict__ alive_node,
+                         unsigned int* __restrict__ alive_block, lk_root_rec* __restrict__ kept,
+                         unsigned int* __restrict__ cnt /* [0] kept, [1] removed */);
+#else
 __global__ void __launch_bounds__(256)
     lk_slide_mark_kernel(LkMap map, LkSlideBox box, unsigned int n_hash, unsigned int* __restrict__ alive_node,
                          unsigned int* __restrict__ alive_block, lk_root_rec* __restrict__ kept,
@@ -1948,7 +2005,14 @@ __global__ void __launch_bounds__(256)
         }
     }
 }
+#endif
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256)
+    lk_slide_move_nodes_kernel(LkMap map, unsigned int n_nodes, const unsigned int* __restrict__ alive_node,
+                               const unsigned int* __restrict__ new_node, const unsigned int* __restrict__ new_block,
+                               lk_node_rec* __restrict__ tn, lk_plane_rec* __restrict__ tp, lk_match_rec* __restrict__ tm);
+#else
 __global__ void __launch_bounds__(256)
     lk_slide_move_nodes_kernel(LkMap map, unsigned int n_nodes, const unsigned int* __restrict__ alive_node,
                                const unsigned int* __restrict__ new_node, const unsigned int* __restrict__ new_block,
@@ -1967,8 +2031,14 @@ __global__ void __launch_bounds__(256)
     tp[j] = map.planes[i];
     tm[j] = map.match[i];
 }
+#endif
 
 // one 64-thread workgroup per alive point block (3744 B = 234 x 16 B)
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(64)
+    lk_slide_move_blocks_kernel(LkMap map, const unsigned int* __restrict__ alive_block,
+                                const unsigned int* __restrict__ new_block, lk_block_rec* __restrict__ tb);
+#else
 __global__ void __launch_bounds__(64)
     lk_slide_move_blocks_kernel(LkMap map, const unsigned int* __restrict__ alive_block,
                                 const unsigned int* __restrict__ new_block, lk_block_rec* __restrict__ tb) {
@@ -1978,18 +2048,31 @@ __global__ void __launch_bounds__(64)
     uint4* dst = reinterpret_cast<uint4*>(&tb[new_block[b]]);
     for (unsigned int k = threadIdx.x; k < sizeof(lk_block_rec) / 16; k += 64) dst[k] = src[k];
 }
+#endif
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256) lk_slide_hash_clear_kernel(LkMap map, unsigned int n_hash);
+#else
 __global__ void __launch_bounds__(256) lk_slide_hash_clear_kernel(LkMap map, unsigned int n_hash) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_hash) map.hash[i] = make_int4((int)0x80000000, (int)0x80000000, (int)0x80000000, LK_EMPTY);
 }
+#endif
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(256)
+    lk_slide_remap_roots_kernel(lk_root_rec* __restrict__ kept, unsigned int n, const unsigned int* __restrict__ new_node);
+#else
 __global__ void __launch_bounds__(256)
     lk_slide_remap_roots_kernel(lk_root_rec* __restrict__ kept, unsigned int n, const unsigned int* __restrict__ new_node) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) kept[i].node = (int)new_node[kept[i].node];
 }
+#endif
 
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void lk_slide_counters_kernel(LkMap map, unsigned int n_nodes, unsigned int n_blocks, unsigned int n_roots);
+#else
 __global__ void lk_slide_counters_kernel(LkMap map, unsigned int n_nodes, unsigned int n_blocks, unsigned int n_roots) {
     map.counters[LK_CTR_NODES] = n_nodes;
     map.counters[LK_CTR_BLOCKS] = n_blocks;
@@ -1997,4 +2080,5 @@ __global__ void lk_slide_counters_kernel(LkMap map, unsigned int n_nodes, unsign
     map.counters[LK_CTR_FREE] = 0;
     map.counters[LK_CTR_FREED] = 0;
 }
+#endif
 

@@ -964,6 +964,11 @@ __device__ __forceinline__ void dev_reproject_point(const LkMap& map, const LkPa
     load_bucket_const<false>(f, pr, bc);   // R, p only matter here (no R * ext_R product, no covariance blocks used)
     dev_reproject_point_bc(map, pr, bc, world ? f->updated != 0 : false, pts, world, do_insert, i);
 }
+#ifdef LK_KERNELS_ELSEWHERE
+__global__ void __launch_bounds__(LK_PB)
+    lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
+                        int n, float* __restrict__ world /* n x 4 or null */, int do_insert);
+#else
 __global__ void __launch_bounds__(LK_PB)
     lk_reproject_kernel(LkMap map, LkParams pr, const LkFilter* __restrict__ filters, const lk_point* __restrict__ pts,
                         int n, float* __restrict__ world /* n x 4 or null */, int do_insert) {
@@ -971,3 +976,4 @@ __global__ void __launch_bounds__(LK_PB)
     if (i >= n) return;
     dev_reproject_point(map, pr, filters, pts, world, do_insert, i);
 }
+#endif
