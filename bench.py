@@ -713,6 +713,29 @@ def main():
         "survey_alg_bytes_per_point": ALG_BYTES_SURVEY, "alg_GBs_cache_served_at_survey_bytes": round(alg_GBs * ALG_BYTES_SURVEY / ALG_BYTES_RESIDUAL, 1),
         "other_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items() if k != "residual"},
     }
+    # where the kernel's waves wait: L1 / LDS / SQ counters of the same launch, profiles/r06_pmc_memory_pipe.json (tools/gpu_prof_mempipe.sh)
+    mp_file = os.path.join(ROOT, "profiles", "r06_pmc_memory_pipe.json")
+    if os.path.exists(mp_file):
+        try:
+            mp = json.load(open(mp_file))
+            dv = mp.get("cell", {}).get("derived", {})
+            waves_per_simd = 5
+            roofline["memory_pipe"] = {
+                "source": f"profiles/r06_pmc_memory_pipe.json (commit {mp.get('commit')})" + ("" if mp.get("kernel_sources_sha16") == kernel_sources_sha16() else " - STALE: kernel sources changed since"),
+                "wave_parked_frac": dv.get("sq_wait_any_frac_of_wave_cycles"), "wave_issue_stall_frac": dv.get("sq_wait_inst_any_frac_of_wave_cycles"),
+                "wave_executing_frac": dv.get("sq_active_inst_any_frac_of_wave_cycles"), "wave_valu_executing_frac": dv.get("sq_active_inst_valu_frac_of_wave_cycles"),
+                "vector_pipe_busy_at_5_waves_per_simd": None if dv.get("sq_active_inst_valu_frac_of_wave_cycles") is None else round(waves_per_simd * dv["sq_active_inst_valu_frac_of_wave_cycles"], 3),
+                "l1_hit_rate": dv.get("tcp_l1_hit_rate"), "l1_miss_to_l2_latency_cycles": dv.get("tcp_read_req_to_l2_latency_cycles"),
+                "l1_pending_stall_cycles_per_access": dv.get("tcp_pending_stall_cycles_per_cache_access"),
+                "lds_bank_conflict_cycles_per_lds_cycle": dv.get("lds_bank_conflict_cycles_per_lds_active_cycle"),
+                "tlb_misses_per_point": dv.get("utcl1_translation_misses_per_point"),
+                "verdict": "bound by fp64 VALU issue: every wave is parked ~47 % of its life, but five waves per SIMD keep the vector pipe ~0.87 busy; L1 hit rate 0.9, "
+                           "~290 cycles per L1 miss to L2, negligible L1 stall / tag-conflict / LDS-conflict / TLB shares - the memory pipe is not the limit "
+                           "(TA_* / TD_* counters cannot be collected on this pool: rocprofv3 never completes the first dispatch)",
+            }
+            roofline["bound"] = "fp64_valu_issue (memory pipe measured: not the limit)"
+        except Exception as e:  # noqa: BLE001
+            warnings.append(f"profiles/r06_pmc_memory_pipe.json unreadable: {e}")
 
     # ---- extra: the same batch WITH the map insert - every scan on its own copy-on-write overlay of the shared map (SURVEY 8d config 5,
     # "scan-local insert overlay"; KILO.cc:216-233 after every bucket): what KILO::process computes per scan, for the whole batch
