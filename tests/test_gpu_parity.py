@@ -902,6 +902,26 @@ def test_config2_batch_rows_resident(big, oracle_lib, hip_lib):
             assert np.array_equal(vh, v[a:b]) and np.array_equal(hh, h6[a:b]) and np.array_equal(zh, z[a:b]) and np.array_equal(Rh, R[a:b])
             g.batch_set_priors(xs, Ps)
     assert n_flips <= 2, n_flips
+    # the same launch with the roots looked up through the hash table instead of the frozen-map grid (LEGKILO_GRID=0: the <true, 0, false> instantiation): the same bits
+    os.environ["LEGKILO_GRID"] = "0"
+    try:
+        g0 = hip_lib.LegKiloHip(scene.cfg(n_slots=S))
+    finally:
+        del os.environ["LEGKILO_GRID"]
+    g0.map_import(g.map_export())
+    g0.init_process_cov_q()
+    d_pts0, d_rows0, d_v0 = g0.device_malloc(allpts.nbytes), g0.device_malloc(N * 64), g0.device_malloc(N)
+    g0.h2d(d_pts0, allpts)
+    g0.batch_set_priors(xs, Ps)
+    g0.batch_residuals_dev(d_pts0, S, n_pts, d_rows0, d_v0)
+    g0.synchronize()
+    rows0, v0 = np.zeros((N, 8)), np.zeros(N, dtype=np.uint8)
+    g0.d2h(rows0, d_rows0)
+    g0.d2h(v0, d_v0)
+    assert np.array_equal(v0, v) and np.array_equal(rows0, rows8)
+    for d in (d_pts0, d_rows0, d_v0):
+        g0.device_free(d)
+    g0.close()
     for d in (d_pts, d_rows, d_v):
         g.device_free(d)
     g.close()
@@ -1024,6 +1044,15 @@ def test_batch_sort_by_voxel(scene, oracle_lib, hip_lib):
     g.batch_changed()
     assert g.batch_order_stats() == (3, 2, 1)
     g.batch_order(1)
+    # lk_batch_prepare_dev: a caller who knows the batch will come back has the copy made at once (works in either mode); the very next replay reads it
+    g.h2d(d_in, allpts)
+    g.batch_set_priors(xa, Pa)
+    g.batch_prepare_dev(d_in, S, n_pts, off)
+    assert g.batch_order_stats() == (4, 3, 1), g.batch_order_stats()
+    (p_, X_), = replays(d_in, xa, Pa, 1)
+    assert np.array_equal(X_, X_sorted)
+    g.batch_prepare_dev(d_in, S, n_pts, off)            # prepared already: nothing to do
+    assert g.batch_order_stats() == (4, 3, 1)
     g.device_free(d_in)
     g.device_free(d_out)
     with pytest.raises(hip_lib.LegKiloError):   # buckets must cover the scan
