@@ -1,13 +1,14 @@
 // lk_internal.h - what the translation units of liblegkilo_hip.so share: the handle, the error / launch / allocation helpers, and the kernel
-// headers.  Round 6: the library is three units compiled side by side - legkilo_hip.hip (LK_TU_MAIN: the C-ABI but for the overlay entries, and every
-// kernel but the overlay's), lk_overlay.hip (LK_TU_OVERLAY: batch replay WITH insert - lk_overlay_kernels.h's kernels and the entries that launch
-// them), lk_prim.hip (rocPRIM).  A non-template kernel of a shared header is DEFINED in the main unit; the overlay unit sees its prototype
+// headers.  Round 6: the library is four units compiled side by side - legkilo_hip.hip (LK_TU_MAIN: the C-ABI but for the overlay entries, and every
+// kernel but the overlay's and the stream path's own), lk_stream.hip (LK_TU_STREAM: one live scan after the other with the map insert - the per-bucket
+// launches, the scan-resident / grid-resident / pipelined kernels, and the KILO-path entries that run them), lk_overlay.hip (LK_TU_OVERLAY: batch replay
+// WITH insert - lk_overlay_kernels.h's kernels and the entries that launch them), lk_prim.hip (rocPRIM).  A non-template kernel of a shared header is DEFINED in the main unit; the overlay unit sees its prototype
 // (LK_KERNELS_ELSEWHERE) and launches it through the main unit's host stub.  The overlay header's own kernels are compiled in the overlay unit only.
 #pragma once
-#if !defined(LK_TU_MAIN) && !defined(LK_TU_OVERLAY)
-#error "define LK_TU_MAIN or LK_TU_OVERLAY before including lk_internal.h"
+#if !defined(LK_TU_MAIN) && !defined(LK_TU_OVERLAY) && !defined(LK_TU_STREAM)
+#error "define LK_TU_MAIN, LK_TU_STREAM or LK_TU_OVERLAY before including lk_internal.h"
 #endif
-#ifdef LK_TU_OVERLAY
+#if defined(LK_TU_OVERLAY) || defined(LK_TU_STREAM)
 #define LK_KERNELS_ELSEWHERE 1
 #endif
 // legkilo_hip.hip — implementation of the C-ABI in include/legkilo_hip.h for gfx950.
@@ -293,6 +294,13 @@ extern "C" int spec_join(lk_handle* h);   // main unit: joins the pipelined stre
         if ((s) >= (h)->cfg.n_slots) return fail(h, LK_ERR_INVALID, "slot out of range"); \
     } while (0)
 
+#define LK_CTR_GRID_XCC 15   // LkMap.counters[15]: XCC ids (one bit each) the working blocks of the last one-XCD launch of the grid-resident stream kernel ran on
+static inline void imu_noise(const lk_config& c, double* Rn) {   // diag of R of an IMU observation (KILO.cc:251-253)
+    Rn[0] = Rn[1] = c.imu_acc_meas_noise;
+    Rn[2] = c.imu_acc_z_meas_noise;
+    Rn[3] = Rn[4] = Rn[5] = c.imu_gyr_meas_noise;
+}
+
 // ---- shared between the translation units (all with C linkage: they are defined inside the units' extern "C" regions)
 extern "C" {
 // main unit (legkilo_hip.hip)
@@ -305,6 +313,10 @@ int ragged_replay(lk_handle* h, const lk_point* d_pts, size_t n_scans, const uin
                   const double* bucket_dt, const double* t_begin, const uint32_t* n_imu, const void* imus, size_t msg_bytes, lk_pose* out, bool with_insert = false);
 __global__ void lk_set_times_kernel(LkFilter* filters, int n, double t);
 __global__ void __launch_bounds__(LK_WAVE, 2) lk_rag_advance_kernel(LkFilter* filters, const double* __restrict__ Q, LkRagged rg, int b, int msg_kind);
+int upload_xyz_as_points(lk_handle* h, const float* xyz, size_t n);   // n x 3 floats -> h->d_scan as lk_point records
+// stream unit (lk_stream.hip)
+int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n, double t_begin, const lk_imu* imus, size_t n_imu, const lk_kin_imu* kins,
+             size_t n_kin, float* xyz_world_out, lk_pose* out);          // the bucket loop of KILO::process on a sorted cloud that is in HBM (and on the host, for the bucket bounds)
 // overlay unit (lk_overlay.hip)
 void ov_free(lk_handle* h);
 int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb, const int* max_n,

@@ -194,7 +194,7 @@ __device__ __forceinline__ void ov_root_record_reset(lk_node_rec* nd) {   // a r
 #endif
 }
 // once per allocation: every table entry empty, every root record's queue fields clean
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_init_kernel(LkOverlay ov) {
     const unsigned int slot = blockIdx.y;
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) lk_ov_init_kernel(LkOverlay ov) {
 #endif
 // per replay: only the entries the PREVIOUS replay claimed are touched (a 100 000-point scan claims ~5 000 of 32 768: resetting every
 // root record cost 3 ms per 1024-scan batch, this pass reads the key tables - 8 B per entry - and rewrites the claimed records)
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_reset_kernel(LkOverlay ov) {
     const unsigned int slot = blockIdx.y;
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) lk_ov_reset_kernel(LkOverlay ov) {
 #endif
 
 // start of a bucket's insert in every slot
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE) lk_ov_begin_kernel(LkOverlay ov) {
     const LkMap pm = ov_slot_map(ov, blockIdx.x);
     dev_bucket_begin_wave(pm);
@@ -280,7 +280,7 @@ __device__ __forceinline__ bool ov_cell_of(const LkMap& base, const int* key, un
 // voxel_map.cc:199,232): UpdateOctoTree ignores every point that lands in one, for good - so no scan ever gets a private copy of such
 // a voxel, and the re-projection pass can drop those points (half of a scan on the bench's mature map) after ONE bit test instead of
 // the private-table probe, the base table probe and the walk.  One thread per entry of the base map's root table, once per replay.
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsigned int n_hash, int max_layer, unsigned int* __restrict__ frozen) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_hash) return;
@@ -359,7 +359,7 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
     }
     return k < (unsigned int)LK_SLOTS ? root : -1;
 }
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE)
     lk_ov_reproject_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
     const int i = blockIdx.x * LK_WAVE + threadIdx.x;
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 // private plane record (centre, normal = v_min; v_mid, v_max and the eigenvalues in the first nine plane_var words) for lk_ov_fit_lane_kernel,
 // which overwrites them with the finished plane.  Two kernels because the closed-form eigen-solver (acos, two cos) and the loop over the leaf's
 // points each fit 128 registers and together do not: the single kernel ran at two waves per SIMD.
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, L
     }
 }
 #endif
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     const unsigned int slot = blockIdx.y;
     const LkMap pm = ov_slot_map(ov, slot);
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
 #ifndef LK_FIT_GROUP
 #define LK_FIT_GROUP 8
 #endif
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_group_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     __shared__ int owner[LK_WAVE * 5];
     const unsigned int slot = blockIdx.y;
@@ -906,7 +906,7 @@ __device__ __forceinline__ bool ov_plane_decide(const double* s, int count, floa
     return !(b11 > 0.0 && m2 > 0.0 && m3 > 0.0);
 }
 // Before anything reads a slot's private blocks as whole blocks (lk_overlay_export): the leaves the fast root pass left split get their base part.
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_MB) lk_ov_merge_split_kernel(LkMap base, LkOverlay ov, unsigned int slot) {
     const LkMap pm = ov_slot_map(ov, slot);
     const unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_merge_split_kernel(LkMap base, Lk
 #endif
 
 // moment sums of the BASE map's root leaves that can still take points, once per replay: one thread per entry of the root table
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_base_sums_kernel(LkMap base, unsigned int n_hash, LkLeafSum* __restrict__ out) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_hash) return;
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void ov_point_geom_body(const LkOverlay& ov, const Lk
     d->var[0] = gm.var.xx, d->var[1] = gm.var.xy, d->var[2] = gm.var.xz;
     d->var[3] = gm.var.yy, d->var[4] = gm.var.yz, d->var[5] = gm.var.zz;
 }
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_point_geom_kernel(LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
     ov_point_geom_body(ov, pr, filters, src, blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
 }
@@ -1133,7 +1133,7 @@ __device__ __forceinline__ void ov_root_lane_body(const LkMap& base, const LkOve
         }
     }
 }
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base, LkOverlay ov, LkParams pr) {
     ov_root_lane_body(base, ov, pr, blockIdx.y, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
@@ -1175,7 +1175,7 @@ __global__ void __launch_bounds__(LK_MB, W)
                                  (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base,
                                  ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
 }
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_apply_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
     const LkMap pm = ov_slot_map(ov, blockIdx.y);
@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(LK_MB)
 // coalesced loads per thread) and builds the list of the slots that have items - in slot order, so that it is the SAME list in every
 // workgroup -; the workgroups then split that list by position, a slot's items are shared by the four waves of the workgroup that takes it.
 #define LK_OV_FB_LIST 4096
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_MB)
     lk_ov_insert_fallback_kernel(LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src, const int n_slots) {
     __shared__ int active[LK_OV_FB_LIST];
@@ -1275,7 +1275,7 @@ __global__ void LK_RES_BOUNDS
 
 // ---------------------------------------------------------------- status of all slots after a replay
 // out[0] = OR of the slots' error words, out[1..3] = largest node / block / root count of any slot, out[4] = first slot with an error
-#ifndef LK_TU_MAIN   // compiled in the overlay unit only (lk_internal.h)
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(256) lk_ov_status_kernel(LkOverlay ov, unsigned int n_slots, unsigned int* __restrict__ out) {
     for (unsigned int s = blockIdx.x * 256 + threadIdx.x; s < n_slots; s += gridDim.x * 256) {
         const unsigned int* c = ov.counters + (size_t)s * LK_CTR_COUNT;

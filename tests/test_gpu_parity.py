@@ -777,7 +777,7 @@ def test_scan_grid_kernel_equals_per_bucket_launches(scene, oracle_lib, hip_lib,
 
 def test_stream_pipeline_forced_conflicts(scene, oracle_lib, hip_lib):
     """The pipelined stream path (insert of bucket k on its own stream beside predict + residual of bucket k+1, verify pass,
-    legkilo_hip.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
+    lk_stream.hip `enqueue_bucket_spec`) with the conflicts FORCED: the five 20 000-point buckets of each scan are not azimuth
     sectors but a random partition of the whole scan, so every bucket's insert initialises / refits / cuts planes of root voxels
     that the next bucket's points match - on a young map (sparse first frame), where most leaves are still live.  The verify
     pass must find those tiles and evaluate them again after the insert: counts identical to the oracle on every scan, every state
