@@ -240,6 +240,14 @@ int lk_map_update(lk_handle* h, const double* pw, const double* var9, size_t n);
 /* Residual build of KILO.cc:122-210 with the CURRENT state of slot 0, no predict, no update, no
  * insert (config 2).  Outputs per input point: h6 n x 6 row-major, z, R, valid (0/1). */
 int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, double* z, double* R, uint8_t* valid);
+/* VoxelMapManager::build_single_residual(pv, root voxel at key, layer 0, is_success = false, prob = 0, single_ptpl)
+ * (voxel_map.cc:363-427, started the way KILO.cc:149-155 starts it) for n caller-held pointWithVar: keys3 n x 3 voxel keys,
+ * pw n x 3 (pv.point_w), var9 n x 9 (pv.var, row-major).  Outputs per point: found (a root voxel exists at the key), success
+ * (is_success), prob, and of the winning plane normal n x 3, center n x 3, d, dis_to_plane (signed, float as voxel_map.h:92 stores
+ * it) and layer (-1 and zeros when no plane was taken).  The map is not modified. */
+int lk_match_points(lk_handle* h, size_t n, const int32_t* keys3, const double* pw, const double* var9, uint8_t* found,
+                    uint8_t* success, double* prob, double* normal3, double* center3, double* d, float* dis_to_plane,
+                    int32_t* layer);
 int lk_map_stats(lk_handle* h, uint32_t* n_roots, uint32_t* n_nodes, uint32_t* n_blocks);
 int lk_map_export(lk_handle* h, void* blob, size_t* bytes);            /* blob==NULL: size query */
 int lk_map_import(lk_handle* h, const void* blob, size_t bytes);

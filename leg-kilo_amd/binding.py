@@ -18,7 +18,7 @@ EXPORTS = [
     "lk_abi_version", "lk_create", "lk_destroy", "lk_last_error", "lk_set_state", "lk_get_state", "lk_set_Q", "lk_get_Q",
     "lk_init_process_cov_q", "lk_set_times", "lk_get_times", "lk_set_acc_norm", "lk_get_acc_norm", "lk_get_fx", "lk_get_function_f",
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
-    "lk_residuals", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
+    "lk_residuals", "lk_match_points", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
     "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_residuals_dev", "lk_batch_order", "lk_batch_changed", "lk_batch_prepare_dev", "lk_batch_order_stats", "lk_batch_replay_dev", "lk_batch_sort_by_voxel_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats", "lk_stream_resident_stats", "lk_test_stall",
@@ -177,6 +177,19 @@ class LegKiloHip:
         h6, z, R, valid = np.zeros((n, 6)), np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.uint8)
         self._chk(self.L.lk_residuals(self.h, _p(b), C.c_size_t(n), _p(h6), _p(z), _p(R), _p(valid)))
         return h6, z, R, valid
+
+    def match_points(self, keys, pw, var):
+        """VoxelMapManager::build_single_residual (voxel_map.cc:363-427) for n points held as pointWithVar: keys n x 3 int32, pw n x 3,
+        var n x 3 x 3 -> dict(found, success, prob, normal, center, d, dis_to_plane, layer), arrays of length n."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
+        n = len(keys)
+        pw, var = _f64(pw).reshape(n, 3), _f64(var).reshape(n, 9)
+        found, ok = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        prob, d, dis, layer = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32)
+        normal, center = np.zeros((n, 3)), np.zeros((n, 3))
+        self._chk(self.L.lk_match_points(self.h, C.c_size_t(n), _p(keys), _p(pw), _p(var), _p(found), _p(ok), _p(prob), _p(normal), _p(center),
+                                         _p(d), _p(dis), _p(layer)))
+        return dict(found=found.astype(bool), success=ok.astype(bool), prob=prob, normal=normal, center=center, d=d, dis_to_plane=dis, layer=layer)
 
     def map_stats(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()

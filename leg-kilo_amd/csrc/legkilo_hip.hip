@@ -740,6 +740,50 @@ int lk_residuals(lk_handle* h, const float* xyz_body, size_t n, double* h6, doub
     return LK_OK;
 }
 
+// VoxelMapManager::build_single_residual (voxel_map.cc:363-427) for n caller-held pointWithVar: see lk_query_kernels.h
+int lk_match_points(lk_handle* h, size_t n, const int32_t* keys3, const double* pw, const double* var9, uint8_t* found, uint8_t* success,
+                    double* prob, double* normal3, double* center3, double* d, float* dis_to_plane, int32_t* layer) {
+    CHECK_H(h);
+    if (n == 0) return LK_OK;
+    if (!keys3 || !pw || !var9 || !found || !success || !prob || !normal3 || !center3 || !d || !dis_to_plane || !layer)
+        return fail(h, LK_ERR_INVALID, "lk_match_points: null argument");
+    if (n > (size_t)INT_MAX / 9) return fail(h, LK_ERR_INVALID, "lk_match_points: n too large");
+    int rc = join_side_streams(h);   // the map as every earlier call on this handle left it
+    if (rc) return rc;
+    DevTemps tmp;
+    int* d_keys = nullptr;
+    double *d_pw = nullptr, *d_var = nullptr, *d_f64 = nullptr;   // d_f64: prob | normal | center | d
+    float* d_dis = nullptr;
+    int* d_layer = nullptr;
+    unsigned char* d_u8 = nullptr;                                // found | success
+    HIPCHK(h, tmp.alloc(&d_keys, sizeof(int) * 3 * n));
+    HIPCHK(h, tmp.alloc(&d_pw, sizeof(double) * 3 * n));
+    HIPCHK(h, tmp.alloc(&d_var, sizeof(double) * 9 * n));
+    HIPCHK(h, tmp.alloc(&d_f64, sizeof(double) * 8 * n));
+    HIPCHK(h, tmp.alloc(&d_dis, sizeof(float) * n));
+    HIPCHK(h, tmp.alloc(&d_layer, sizeof(int) * n));
+    HIPCHK(h, tmp.alloc(&d_u8, 2 * n));
+    HIPCHK(h, hipMemcpyAsync(d_keys, keys3, sizeof(int) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_pw, pw, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_var, var9, sizeof(double) * 9 * n, hipMemcpyHostToDevice, h->stream));
+    LkMatchOut mo;
+    mo.found = d_u8, mo.success = d_u8 + n;
+    mo.prob = d_f64, mo.normal = d_f64 + n, mo.center = d_f64 + 4 * n, mo.d = d_f64 + 7 * n;
+    mo.dis_to_plane = d_dis, mo.layer = d_layer;
+    LAUNCH(h, "match_points", hipLaunchKernelGGL(lk_match_points_kernel, dim3((unsigned int)((n + 63) / 64)), dim3(64), 0, h->stream, h->map, h->pr,
+                                                 (const int*)d_keys, (const double*)d_pw, (const double*)d_var, (int)n, mo));
+    HIPCHK(h, hipMemcpyAsync(found, mo.found, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(success, mo.success, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(prob, mo.prob, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(normal3, mo.normal, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(center3, mo.center, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d, mo.d, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dis_to_plane, mo.dis_to_plane, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(layer, mo.layer, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LK_OK;
+}
+
 // clearMemOutOfMap (voxel_map.cc:571-594) as a pool compaction; see lk_map_kernels.h
 static int clear_outside(lk_handle* h, const LkSlideBox& box, uint32_t* n_removed) {
     if (n_removed) *n_removed = 0;

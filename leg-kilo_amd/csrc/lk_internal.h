@@ -37,6 +37,7 @@
 #include "lk_map_kernels.h"
 #ifdef LK_TU_MAIN
 #include "lk_pre_kernels.h"   // decode / voxel grid / ragged tables: launched by the main unit only
+#include "lk_query_kernels.h" // per-point build_single_residual: launched by the main unit only
 #endif
 #include "lk_overlay_kernels.h"
 

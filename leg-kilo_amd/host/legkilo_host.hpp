@@ -97,6 +97,14 @@ struct pointWithVar {
     Mat3D var{};
 };
 
+// PointToPlane (voxel_map.h:80-94): what build_single_residual writes into it and KILO.cc:160-210 reads of it
+struct PointToPlane {
+    Vec3D point_w_{}, normal_{}, center_{};
+    int layer_ = -1;
+    double d_ = 0.0;
+    float dis_to_plane_ = 0.0f;
+};
+
 // PointType (pcl_types.h:11) fields the path touches
 struct PointType {
     float x = 0, y = 0, z = 0, intensity = 0, curvature = 0;
@@ -238,6 +246,32 @@ class VoxelMapManager {
     // voxel_map.cc:571-594
     void clearMemOutOfMap(const int& x_max, const int& x_min, const int& y_max, const int& y_min, const int& z_max, const int& z_min) {
         dev_->check(lk_map_clear_outside(dev_->h(), x_max, x_min, y_max, y_min, z_max, z_min, nullptr));
+    }
+    // voxel_map.cc:363-427 for points the caller holds as pointWithVar, each started on the root voxel at keys[i] with
+    // is_success = false, prob = 0 (KILO.cc:149-155).  found[i]: the find of KILO.cc:149 hit.  The reference's argument
+    // `const VoxelOctoTree* current_octo` has no host-side counterpart (the octrees live in HBM): the key stands in for it.
+    void build_single_residual(const std::vector<pointWithVar>& pv, const std::vector<std::array<int32_t, 3>>& keys, std::vector<uint8_t>& found,
+                               std::vector<uint8_t>& is_success, std::vector<double>& prob, std::vector<PointToPlane>& single_ptpl) {
+        const size_t n = pv.size();
+        if (keys.size() != n) throw std::runtime_error("build_single_residual: one key per point");
+        std::vector<int32_t> k(3 * n);
+        std::vector<double> pw(3 * n), var(9 * n), nrm(3 * n), ctr(3 * n), d(n);
+        std::vector<float> dis(n);
+        std::vector<int32_t> layer(n);
+        for (size_t i = 0; i < n; ++i) {
+            std::copy(keys[i].begin(), keys[i].end(), k.begin() + 3 * i);
+            std::copy(pv[i].point_w.begin(), pv[i].point_w.end(), pw.begin() + 3 * i);
+            std::copy(pv[i].var.m, pv[i].var.m + 9, var.begin() + 9 * i);
+        }
+        found.assign(n, 0), is_success.assign(n, 0), prob.assign(n, 0.0), single_ptpl.assign(n, PointToPlane());
+        dev_->check(lk_match_points(dev_->h(), n, k.data(), pw.data(), var.data(), found.data(), is_success.data(), prob.data(), nrm.data(), ctr.data(),
+                                    d.data(), dis.data(), layer.data()));
+        for (size_t i = 0; i < n; ++i) {
+            PointToPlane& t = single_ptpl[i];
+            t.point_w_ = pv[i].point_w;
+            for (int c = 0; c < 3; ++c) t.normal_[c] = nrm[3 * i + c], t.center_[c] = ctr[3 * i + c];
+            t.layer_ = layer[i], t.d_ = d[i], t.dis_to_plane_ = dis[i];
+        }
     }
     // Residual build of KILO.cc:122-210 for a whole bucket (replaces the per-point build_single_residual calls).
     void BuildResidualList(const PointCloudType& body, size_t i0, size_t i1, ObsShared& obs, std::vector<uint8_t>& valid) {

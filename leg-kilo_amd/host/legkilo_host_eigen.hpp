@@ -273,6 +273,22 @@ typedef struct pointWithVar {
     }
 } pointWithVar;
 
+// voxel_map.h:80-94
+typedef struct PointToPlane {
+    Eigen::Vector3d point_b_, point_w_, normal_, center_;
+    Eigen::Matrix<double, 3, 3> point_crossmat_;
+    Eigen::Matrix<double, 6, 6> plane_var_;   // not fetched from the device: zero (KILO.cc reads it only through sigma_l, which the device has evaluated)
+    Eigen::Matrix3d body_cov_;
+    int layer_;
+    double d_, eigen_value_;
+    bool is_valid_;
+    float dis_to_plane_;
+    double dis_r;
+    PointToPlane() : layer_(-1), d_(0), eigen_value_(0), is_valid_(false), dis_to_plane_(0), dis_r(0) {
+        point_b_.setZero(), point_w_.setZero(), normal_.setZero(), center_.setZero(), point_crossmat_.setZero(), plane_var_.setZero(), body_cov_.setZero();
+    }
+} PointToPlane;
+
 class VoxelMapManager {
    public:
     VoxelMapManager(VoxelMapConfig& config_setting, legkilo_hip::VoxelMapManager* dev) : config_setting_(config_setting), dev_(dev) {
@@ -315,6 +331,29 @@ class VoxelMapManager {
     }
     void clearMemOutOfMap(const int& x_max, const int& x_min, const int& y_max, const int& y_min, const int& z_max, const int& z_min) {
         dev_->clearMemOutOfMap(x_max, x_min, y_max, y_min, z_max, z_min);
+    }
+    // voxel_map.cc:363-427 on the root voxel at `position` (the key of voxel_map_, voxel_map.h:186), entered like KILO.cc:149-155 with the caller's
+    // is_success / prob; returns whether a root voxel exists there (the find of KILO.cc:149).  `position` stands in for the reference's
+    // `const VoxelOctoTree* current_octo, const int current_layer`: the octrees live in HBM.
+    bool build_single_residual(pointWithVar& pv, const Eigen::Vector3i& position, bool& is_success, double& prob, PointToPlane& single_ptpl) {
+        std::vector<legkilo_hip::pointWithVar> v(1);
+        v[0].point_w = hip_glue::to_hip(Vec3D(pv.point_w)), v[0].var = hip_glue::to_hip(Mat3D(pv.var));
+        std::vector<std::array<int32_t, 3>> key(1, std::array<int32_t, 3>{{position[0], position[1], position[2]}});
+        std::vector<uint8_t> found, ok;
+        std::vector<double> pr;
+        std::vector<legkilo_hip::PointToPlane> pl;
+        dev_->build_single_residual(v, key, found, ok, pr, pl);
+        if (!found[0]) return false;
+        if (ok[0]) is_success = true;
+        if (ok[0] && pr[0] > prob) {   // voxel_map.cc:389-406
+            prob = pr[0];
+            for (int c = 0; c < 3; ++c) single_ptpl.normal_[c] = pl[0].normal_[c], single_ptpl.center_[c] = pl[0].center_[c];
+            pv.normal = single_ptpl.normal_;
+            single_ptpl.body_cov_ = pv.body_var, single_ptpl.point_b_ = pv.point_b, single_ptpl.point_w_ = pv.point_w;
+            single_ptpl.point_crossmat_ = pv.point_crossmat;
+            single_ptpl.d_ = pl[0].d_, single_ptpl.layer_ = pl[0].layer_, single_ptpl.dis_to_plane_ = pl[0].dis_to_plane_;
+        }
+        return true;
     }
     // the residual build of KILO.cc:122-210 for one bucket [i0, i1) of a cloud (stands in for the per-point build_single_residual calls)
     void BuildResidualList(const PointCloudType& body, size_t i0, size_t i1, ObsShared& obs, std::vector<uint8_t>& valid) {

@@ -258,6 +258,52 @@ def test_residuals_on_imported_map(pair, scene):
     scenes.rows_close(hg, zg, Rg, ho, zo, Ro, vo)
 
 
+def test_build_single_residual_per_point(pair, scene, oracle_lib):
+    """lk_match_points == VoxelMapManager::build_single_residual (voxel_map.cc:363-427) of the oracle, point by point, on the same map:
+    caller-held world points with caller-held covariances, on their home voxel and two neighbouring keys (the searches of KILO.cc:149-185),
+    keys without a root voxel, covariances small (most candidates fail the 3-sigma gate) and large (several planes of a cut voxel pass and
+    the probability decides)."""
+    o, g = pair
+    t0 = 1.0
+    blob = mature_oracle_map(o, scene, t0)
+    g.map_import(blob)
+    rng = np.random.default_rng(41)
+    ts = t0 + 1.0
+    pts = synth.dense_scan(scene.world, scenes.Frozen(scene.traj, ts), ts, scene.P, n=3000, n_buckets=1)
+    xs, _ = o.get_state()
+    Rw, tw = np.asarray(xs[:9]).reshape(3, 3), np.asarray(xs[9:12])
+    pw = (scenes.xyz_of(pts).astype(np.float64) + np.asarray(scene.P["extrinsic_T"])) @ Rw.T + tw + rng.normal(0, 0.03, (len(pts), 3))
+    pw = np.concatenate([pw, rng.uniform(-30, 30, (300, 3))])
+    vs = float(scene.P["voxel_size"])
+    keys, P, V = [], [], []
+    for i, p in enumerate(pw):
+        k0 = oracle_lib.key_floor(p, vs)
+        A = rng.normal(size=(3, 3))
+        var = (A @ A.T) * (1e-5 if i % 3 else 4e-3) + np.eye(3) * 1e-6
+        for dk in ((0, 0, 0), (1, 0, 0), (0, -1, 0), (0, 0, 1)):
+            keys.append([a + b for a, b in zip(k0, dk)]), P.append(p), V.append(var)
+    keys, P, V = np.array(keys, dtype=np.int32), np.array(P), np.array(V)
+    mg = g.match_points(keys, P, V)
+    n_found = n_ok = n_deep = 0
+    for i in range(len(keys)):
+        mo = o.match_voxel(keys[i], P[i], V[i].reshape(9))
+        assert (mo["found"], mo["success"]) == (bool(mg["found"][i]), bool(mg["success"][i])), (i, keys[i], mo, {k: v[i] for k, v in mg.items()})
+        n_found += mo["found"]
+        if mo["success"]:
+            n_ok += 1
+            n_deep += mo["layer"] > 0
+            assert mo["layer"] == mg["layer"][i]
+            assert np.array_equal(mo["normal"], mg["normal"][i]) and np.array_equal(mo["center"], mg["center"][i])   # the same plane of the same map
+            assert mo["d"] == mg["d"][i]
+            assert np.isclose(mo["dis_to_plane"], mg["dis_to_plane"][i], rtol=1e-6, atol=1e-9)
+            assert np.isclose(mo["prob"], mg["prob"][i], rtol=1e-9), (mo["prob"], mg["prob"][i])
+        else:
+            assert mg["layer"][i] == -1 and mg["prob"][i] == 0.0
+    assert n_found > 3000 and n_ok > 1500 and n_deep > 20, (n_found, n_ok, n_deep)
+    assert n_found < len(keys)
+    scenes.compare_maps(blob, g.map_export())   # the query left the map alone
+
+
 def test_update_points_bucket_and_insert(pair, scene):
     o, g = pair
     t0 = 1.0
