@@ -8,7 +8,8 @@
 //
 // Same method names, argument meaning and (void / bool) error behaviour as the reference.  Differences forced
 // by the state living in HBM: state()/cov()/Q() return COPIES (use setState/setCov/setQ to write back), and
-// build_single_residual is not a per-point host call — BuildResidualList() runs the whole bucket on the GPU.
+// build_single_residual takes the voxel KEY where the reference takes a VoxelOctoTree* (a batch of points per call; a bucket of the path
+// goes through BuildResidualList(), which never leaves the GPU).
 // Configuration errors throw std::runtime_error like YamlHelper does (yaml_helper.hpp:42,50).
 #pragma once
 #include <algorithm>

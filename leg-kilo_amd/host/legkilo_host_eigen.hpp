@@ -19,8 +19,8 @@
 //     (state_initial.hpp:66-70) work as written - the proxy IS a State / StateCov and stores itself to the device when it goes out of
 //     scope, if it was changed.  A proxy bound to a long-lived name keeps the value it was created with: read again after a call
 //     that moves the filter.
-//   * VoxelMapManager::voxel_map_ (the unordered_map of octrees) does not exist on the host; build_single_residual is a whole-bucket
-//     call (BuildResidualList).
+//   * VoxelMapManager::voxel_map_ (the unordered_map of octrees) does not exist on the host; build_single_residual takes the voxel's
+//     key instead of its octree, and a bucket goes through one call (BuildResidualList).
 //   * errors of the C-ABI become std::runtime_error, like YamlHelper's configuration errors (yaml_helper.hpp:42,50).
 #pragma once
 #define LEGKILO_HOST_NAMESPACE legkilo_hip

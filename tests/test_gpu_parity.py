@@ -265,15 +265,19 @@ def test_build_single_residual_per_point(pair, scene, oracle_lib):
     the probability decides)."""
     o, g = pair
     t0 = 1.0
-    blob = mature_oracle_map(o, scene, t0)
-    g.map_import(blob)
+    mature_oracle_map(o, scene, t0)
     rng = np.random.default_rng(41)
+    clutter = scenes.corner_clutter(rng, n_cells=40, per_cell=70)   # cuts voxels down to layer 2: candidates below the root, several per voxel
+    cvar = np.tile((np.eye(3) * 4e-4).reshape(1, 9), (len(clutter), 1))
+    o.map_update(clutter, cvar)
+    blob = o.map_export()
+    g.map_import(blob)
     ts = t0 + 1.0
     pts = synth.dense_scan(scene.world, scenes.Frozen(scene.traj, ts), ts, scene.P, n=3000, n_buckets=1)
     xs, _ = o.get_state()
     Rw, tw = np.asarray(xs[:9]).reshape(3, 3), np.asarray(xs[9:12])
     pw = (scenes.xyz_of(pts).astype(np.float64) + np.asarray(scene.P["extrinsic_T"])) @ Rw.T + tw + rng.normal(0, 0.03, (len(pts), 3))
-    pw = np.concatenate([pw, rng.uniform(-30, 30, (300, 3))])
+    pw = np.concatenate([pw, clutter[:1200] + rng.normal(0, 0.01, (1200, 3)), rng.uniform(-30, 30, (300, 3))])
     vs = float(scene.P["voxel_size"])
     keys, P, V = [], [], []
     for i, p in enumerate(pw):
