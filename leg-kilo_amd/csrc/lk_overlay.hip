@@ -3,6 +3,11 @@
 #define LK_TU_OVERLAY 1
 #include "lk_internal.h"
 
+static int ov_root_bits() {   // LEGKILO_OV_ROOT_BITS=0: no "takes the point at the root" bit for the re-projection pass (A/B)
+    static const int v = getenv("LEGKILO_OV_ROOT_BITS") == nullptr || atoi(getenv("LEGKILO_OV_ROOT_BITS")) != 0;
+    return v;
+}
+
 // Round 6: the FRONT of a bucket index of the ragged batch with insert as ONE launch when every bucket holds <= LK_SCAN_WAVE_MAX points (a recorded
 // scan's 2 ms bins): lk_rag_advance_kernel (messages + predict), lk_ov_residual_kernel, lk_update_wave_ragged_kernel, lk_ov_begin_kernel and
 // lk_ov_reproject_kernel were five one-wave-per-scan launches, each paying a launch boundary (~5 us for 1 024 one-wave workgroups whatever they do) and
@@ -237,7 +242,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.newroot, (size_t)(LK_NEWROOT_MASK + 1) * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.spec, LK_SPEC_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
-    if (e == hipSuccess) e = get(&o.frozen, (size_t)n.bit_words * sizeof(unsigned int));
+    if (e == hipSuccess) e = get(&o.frozen, (size_t)2 * n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
     if (e == hipSuccess) e = get(&o.sums, s * n.hash_cap * sizeof(LkLeafSum));
     if (e == hipSuccess) e = get(&o.base_sums, (size_t)h->map.max_nodes * sizeof(LkLeafSum));
@@ -339,9 +344,9 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     rc = zero_scan_counters(h, 0, (uint32_t)S);
     if (rc) return rc;
     hipLaunchKernelGGL(lk_set_times_kernel, dim3((S + 63) / 64), dim3(64), 0, st, h->d_filters, S, t_begin);
-    HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
+    HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)2 * ov.bit_words * sizeof(unsigned int), st));
     static const bool frozen_bits = getenv("LEGKILO_OV_FROZEN_BITS") == nullptr || atoi(getenv("LEGKILO_OV_FROZEN_BITS")) != 0;   // 0: every point through the probes and the walk (A/B)
-    if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
+    if (frozen_bits) LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen, ov_root_bits()));
     static const bool xid_enable = getenv("LEGKILO_XID") == nullptr || atoi(getenv("LEGKILO_XID")) != 0;
     const auto res_kernel = (h->pr.ext_identity && xid_enable) ? lk_ov_residual_kernel<true> : lk_ov_residual_kernel<false>;
     // root pass: the fast path (lk_ov_point_geom_kernel + lk_ov_root_lane_kernel: root leaves that append / refit / freeze) and the generic pass over what it leaves
@@ -523,8 +528,8 @@ int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S_, const 
         rc = zero_scan_counters(h, 0, (uint32_t)S);
         if (rc) return rc;
         hipLaunchKernelGGL(lk_set_times_ragged_kernel, dim3((S + 63) / 64), dim3(64), 0, st, fl, S, d_tbegin);
-        HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)ov.bit_words * sizeof(unsigned int), st));
-        LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen));
+        HIPCHK(h, hipMemsetAsync(ov.frozen, 0, (size_t)2 * ov.bit_words * sizeof(unsigned int), st));
+        LAUNCH(h, "ov_frozen_bits", hipLaunchKernelGGL(lk_ov_frozen_bits_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, h->pr.max_layer, ov.frozen, ov_root_bits()));
         LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
         {
             const unsigned int per = std::max(std::max(ov.hash_cap, ov.bit_words), (unsigned int)LK_CTR_COUNT);

@@ -93,7 +93,9 @@ struct LkOverlay {
     unsigned int* newroot;       // one shared dummy table (epoch 0: only ever written with 0)
     unsigned int* spec;          // one shared dummy
     unsigned int* bits;          // [S][bit_words]: bit c = the slot has a private root at base grid cell c
-    unsigned int* frozen;        // [bit_words], shared by all slots: bit c = the BASE map's voxel at grid cell c is a frozen leaf (lk_ov_frozen_bits_kernel)
+    unsigned int* frozen;        // [2 * bit_words], shared by all slots: TWO bits per grid cell c of the BASE map (lk_ov_frozen_bits_kernel): bit 0 = its voxel is a
+                                 // frozen leaf (UpdateOctoTree ignores the point), bit 1 = its voxel takes the point AT THE ROOT (a live leaf, or not initialised
+                                 // yet): not ignored, and nothing below the root to look at - the re-projection needs no read of the base tree for it
     struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
     struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_lane_kernel)
     struct LkLeafSum* base_sums; // [base max_nodes], shared: the same for the BASE map's root leaves, once per replay (lk_ov_base_sums_kernel)
@@ -281,17 +283,22 @@ __device__ __forceinline__ bool ov_cell_of(const LkMap& base, const int* key, un
 // a voxel, and the re-projection pass can drop those points (half of a scan on the bench's mature map) after ONE bit test instead of
 // the private-table probe, the base table probe and the walk.  One thread per entry of the base map's root table, once per replay.
 #ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
-__global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsigned int n_hash, int max_layer, unsigned int* __restrict__ frozen) {
+__global__ void __launch_bounds__(256) lk_ov_frozen_bits_kernel(LkMap base, unsigned int n_hash, int max_layer, unsigned int* __restrict__ frozen, int root_bits) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_hash) return;
     const int4 e = base.hash[i];
     if (e.w < 0) return;
     const unsigned int st = base.nodes[e.w].state, pf = base.planes[e.w].flags;
-    if (!(st & LK_NODE_INIT_OCTO) || (st & LK_NODE_UPDATE_ENABLE)) return;
-    if (!((pf & LK_PLANE_IS_PLANE) != 0 || base.nodes[e.w].layer >= max_layer)) return;   // the leaf test of ov_walk_ignored at the root
+    // ov_walk_ignored at the root: not initialised -> the point is taken here; a leaf (plane, or max_layer) -> ignored iff update_enable_ is off;
+    // anything else descends (no bit: the re-projection walks the tree)
+    unsigned int cls;
+    if (!(st & LK_NODE_INIT_OCTO)) cls = 2u;
+    else if ((pf & LK_PLANE_IS_PLANE) != 0 || base.nodes[e.w].layer >= max_layer) cls = (st & LK_NODE_UPDATE_ENABLE) ? 2u : 1u;
+    else return;
+    if (cls == 2u && !root_bits) return;   // LEGKILO_OV_ROOT_BITS=0 (A/B): such a voxel through the walk, as before round 6
     const int key[3] = {e.x, e.y, e.z};
     unsigned int cell;
-    if (ov_cell_of(base, key, &cell)) atomicOr(&frozen[cell >> 5], 1u << (cell & 31u));
+    if (ov_cell_of(base, key, &cell)) atomicOr(&frozen[cell >> 4], cls << (2u * (cell & 15u)));
 }
 #endif
 
@@ -319,7 +326,9 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
     unsigned int cell = 0;
     const bool in_grid = ov_cell_of(base, key, &cell);
     // the base voxel of this key is a frozen leaf: the point is ignored, and no private voxel of that key can exist
-    if (in_grid && ((ov.frozen[cell >> 5] >> (cell & 31u)) & 1u)) return -1;
+    const unsigned int cls = in_grid ? (ov.frozen[cell >> 4] >> (2u * (cell & 15u))) & 3u : 0u;
+    if (cls & 1u) return -1;
+    const bool base_takes_at_root = (cls & 2u) != 0;   // a base voxel exists and takes the point at its root: no walk, its node id only for the lane that claims the key
     const unsigned int hk = ov_slot_hash(key[0], key[1], key[2]);
     int root = ov_key_find(keys, pm.hash_mask, pk, hk);
     if (root >= 0 && pm.nodes[root].pad_[LK_PAD_LIVE] != 0) {
@@ -328,11 +337,11 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
         // the base map's voxel of this key: its node id sits in the frozen-map grid cell (arithmetic index, 4 bytes; a key outside the grid's
         // box has no base voxel) - no probe of the base table
         int broot = -1;
-        if (in_grid) {
+        if (in_grid && !base_takes_at_root) {
             const unsigned int bnode = base.match[(size_t)base.grid_base + cell].pad_;
             if (bnode != LK_GRID_EMPTY) broot = (int)bnode;
+            if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return -1;
         }
-        if (broot >= 0 && ov_walk_ignored(base, broot, pw, pr.max_layer)) return -1;
         if (root < 0) {
             bool claimed;
             root = ov_key_claim(keys, pm.hash_mask, pk, hk, &claimed);
@@ -342,7 +351,10 @@ __device__ __forceinline__ int ov_reproject_point(const LkMap& base, const LkOve
             }
             // what the materialise pass copies into this root (no lookup there): stored by the ONE lane that claimed the key - a store
             // per point cost 2.8 ms per 1024-scan batch
-            if (claimed) pm.nodes[root].pad_[LK_PAD_BASE] = (unsigned int)(broot + 1);
+            if (claimed) {
+                if (base_takes_at_root) broot = (int)base.match[(size_t)base.grid_base + cell].pad_;
+                pm.nodes[root].pad_[LK_PAD_BASE] = (unsigned int)(broot + 1);
+            }
         }
     }
     // queue_point_on_root with the POINT in the slot line ({x, y, z, index}): the root pass gets a root's points with one coalesced read
