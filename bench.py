@@ -977,6 +977,8 @@ def main():
             extra["config1_overlay_ragged_scans_per_s"] = round(S1o / el1o, 1)
             extra["config1_overlay_ragged_batch"] = int(S1o)
             extra["config1_overlay_ragged_mean_n_effect"] = round(float(p1ov["n_effect"].astype(np.float64).mean()), 1)
+            # launches of the scan-resident kernel (1 + the most fallback stops of any scan); 0: the batch ran launch by launch (LEGKILO_RAG_RESIDENT=0, or a bucket over 512 points)
+            extra["config1_overlay_ragged_resident_launches"] = g.overlay_resident_rounds()
         except Exception as e:  # noqa: BLE001
             extra["config1_overlay_ragged_error"] = f"{type(e).__name__}: {str(e)[:200]}"
             warnings.append("config-1 overlay replay failed: " + extra["config1_overlay_ragged_error"])

@@ -401,6 +401,12 @@ int lk_overlay_stats(lk_handle* h, uint32_t* max_roots, uint32_t* max_nodes, uin
 /* What the overlay pools hold right now: total bytes in HBM and the per-scan capacities (root-table entries = root node records,
  * child nodes, point blocks); all 0 before the first overlay replay / after lk_overlay_reserve released them. */
 int lk_overlay_pool_bytes(lk_handle* h, uint64_t* bytes, uint32_t* root_entries, uint32_t* child_nodes, uint32_t* blocks);
+/* lk_batch_replay_overlay_ragged_dev runs a batch whose buckets all hold <= 512 points (a recorded scan's 2 ms bins, KILO.cc:375-378)
+ * SCAN-RESIDENT: one launch carries every scan through its whole bucket chain incl. the insert; a scan whose bucket needs the
+ * insert's fallback code stops behind it, the fallback launch runs, and the scans are launched again.  *rounds = launches of the
+ * scan kernel in the handle's last such replay (1 + the largest number of stops of any scan), 0 when that replay ran launch by
+ * launch (a bucket over 512 points, or LEGKILO_RAG_RESIDENT=0).  Same results either way, bit for bit. */
+int lk_overlay_resident_rounds(lk_handle* h, uint32_t* rounds);
 
 /* Ragged batch: the scans of a recorded run differ in size, in their time buckets (KILO.cc:375-378) and in their start
  * time.  Scan s = d_pts[scan_off[s] .. scan_off[s+1]) (scan_off: n_scans + 1 entries) on filter slot s; n_buckets[s] buckets

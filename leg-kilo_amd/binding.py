@@ -20,7 +20,7 @@ EXPORTS = [
     "lk_predict", "lk_update_by_points", "lk_update_by_imu", "lk_update_by_kin_imu", "lk_map_build", "lk_map_update",
     "lk_residuals", "lk_match_points", "lk_map_slide", "lk_map_clear_outside", "lk_map_slide_position", "lk_map_stats", "lk_map_export", "lk_map_import", "lk_map_export_dev", "lk_map_import_dev",
     "lk_update_points", "lk_update_imu", "lk_update_kin_imu", "lk_process_scan", "lk_process_scan_dev",
-    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_residuals_dev", "lk_batch_order", "lk_batch_changed", "lk_batch_prepare_dev", "lk_batch_order_stats", "lk_batch_replay_dev", "lk_batch_sort_by_voxel_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
+    "lk_decode_scan", "lk_decode_scan_dev", "lk_preprocess_scan", "lk_preprocess_scan_dev", "lk_process_raw_scan", "lk_batch_set_priors", "lk_batch_set_priors_dev", "lk_batch_get_states", "lk_batch_get_states_dev", "lk_batch_residuals_dev", "lk_batch_order", "lk_batch_changed", "lk_batch_prepare_dev", "lk_batch_order_stats", "lk_batch_replay_dev", "lk_batch_sort_by_voxel_dev", "lk_batch_replay_async_dev", "lk_batch_replay_ragged_dev", "lk_batch_replay_ragged_imu_dev", "lk_batch_replay_ragged_kin_dev", "lk_batch_replay_scans_dev", "lk_batch_replay_overlay_dev", "lk_batch_replay_overlay_ragged_dev", "lk_overlay_reserve", "lk_overlay_export", "lk_overlay_stats", "lk_overlay_pool_bytes", "lk_overlay_resident_rounds", "lk_profile_enable", "lk_profile_get", "lk_profile_reset",
     "lk_device_malloc", "lk_device_free", "lk_memcpy_h2d", "lk_memcpy_d2h", "lk_synchronize", "lk_stream", "lk_stream_pipeline", "lk_stream_resident", "lk_stream_grid", "lk_stream_grid_placement", "lk_stream_stats", "lk_stream_resident_stats", "lk_test_stall",
 ]
 
@@ -459,6 +459,12 @@ class LegKiloHip:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._chk(self.L.lk_overlay_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def overlay_resident_rounds(self):
+        """Launches of the scan-resident kernel in the last recorded-run replay with insert (0: it ran launch by launch)."""
+        r = C.c_uint32(0)
+        self._chk(self.L.lk_overlay_resident_rounds(self.h, C.byref(r)))
+        return int(r.value)
 
     def overlay_pool_bytes(self):
         """(bytes the overlay pools hold, per-scan root-table entries, child nodes, point blocks)."""

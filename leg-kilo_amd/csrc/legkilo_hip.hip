@@ -161,7 +161,7 @@ void lk_destroy(lk_handle* h) {
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp,
-                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids, h->d_fbackup, h->d_ov_priors};
+                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids, h->d_fbackup, h->d_ov_priors, h->d_ov_res};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,

@@ -134,6 +134,9 @@ struct lk_handle {
     size_t ov_pool_bytes = 0;                             // bytes the overlay pools hold (lk_overlay_pool_bytes)
     LkFilter* d_ov_priors = nullptr;                      // the batch's priors, kept for the retry after a pool overflow
     size_t ov_priors_cap = 0;
+    int* d_ov_res = nullptr;                              // scan-resident recorded-run replay with insert: [S] next bucket, [S] bucket with fallback items, stopped-scan counter
+    size_t ov_res_cap = 0;
+    unsigned int ov_res_rounds = 0;                       // launches of the scan-resident kernel in the last such replay
     unsigned int* d_ov_status = nullptr;
     // input order of device-resident batches (lk_batch_order): the batches the frozen-map batch entries have seen, with the library's voxel-ordered copy
     struct OrdEntry {

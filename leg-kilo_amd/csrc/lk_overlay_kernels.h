@@ -55,6 +55,7 @@ struct LkPtSrc {
     const unsigned long long* pt_off;   // null: uniform
     const unsigned int* nb;
     int ldb, b;
+    const int* b_slot;                  // optional [S]: every slot its OWN bucket index (the scan-resident replay: a launch behind it finds the slots at different buckets); null: b
 };
 __device__ __forceinline__ int ov_pt_src(const LkPtSrc& s, unsigned int slot, const lk_point** p) {
     if (!s.pt_off) {
@@ -62,10 +63,11 @@ __device__ __forceinline__ int ov_pt_src(const LkPtSrc& s, unsigned int slot, co
         return s.n;
     }
     *p = s.pts;
-    if (s.b >= (int)s.nb[slot]) return 0;
+    const int b = s.b_slot ? s.b_slot[slot] : s.b;
+    if (b < 0 || b >= (int)s.nb[slot]) return 0;
     const unsigned long long* po = s.pt_off + (size_t)slot * (size_t)(s.ldb + 1);
-    *p = s.pts + po[s.b];
-    return (int)(po[s.b + 1] - po[s.b]);
+    *p = s.pts + po[b];
+    return (int)(po[b + 1] - po[b]);
 }
 
 // The overlay pools of all slots, passed by value.  Slot s owns element range [s * cap, (s + 1) * cap) of every array.
@@ -474,14 +476,15 @@ __device__ __forceinline__ void ov_copy_node(const LkMap& pm, const LkMap& base,
 // pass keeps matching the base grid cell (the bit is set by the root pass when it refits the leaf or hands the root to the generic pass, which
 // also gets the match record made first); the sums are read from the base map's (LK_PAD_SUMSRC).  35 -> 15 memory requests per new root.
 template <bool LEAN>
-__device__ __forceinline__ void ov_materialise_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot_, const int bx_, const int gx_, const int tid_) {
+__device__ __forceinline__ void ov_materialise_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot_, const int bx_, const int gx_, const int tid_,
+                                                    const int mb_ = LK_MB /* threads per workgroup */) {
     const unsigned int slot = slot_;
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
     const unsigned long long* keys = ov.keys + (size_t)slot * ov.hash_cap;
     unsigned int* bits = ov.bits + (size_t)slot * ov.bit_words;
     const int lane = tid_ & 63;
-    const int wave = (int)((bx_ * LK_MB + tid_) >> 6), nwaves = (int)((gx_ * LK_MB) >> 6);
+    const int wave = (int)((bx_ * mb_ + tid_) >> 6), nwaves = (int)((gx_ * mb_) >> 6);
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     for (int t0 = wave * LK_WAVE; t0 < n_touched; t0 += nwaves * LK_WAVE) {
         const int tt = t0 + lane;
@@ -642,14 +645,13 @@ __global__ void __launch_bounds__(LK_MB) lk_ov_materialise_kernel(LkMap base, Lk
 // private plane record (centre, normal = v_min; v_mid, v_max and the eigenvalues in the first nine plane_var words) for lk_ov_fit_lane_kernel,
 // which overwrites them with the finished plane.  Two kernels because the closed-form eigen-solver (acos, two cos) and the loop over the leaf's
 // points each fit 128 registers and together do not: the single kernel ran at two waves per SIMD.
-#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
-__global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, LkOverlay ov, LkParams pr) {
-    const unsigned int slot = blockIdx.y;
+// (thread i_first of i_stride over the slot's jobs: the kernel below, and one phase of lk_ov_tail_kernel)
+__device__ __forceinline__ void ov_fit_eig_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot, const int i_first, const int i_stride) {
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
-    for (int i = blockIdx.x * LK_WAVE + threadIdx.x; i < n_touched * LK_INLINE_GROUPS; i += gridDim.x * LK_WAVE) {
+    for (int i = i_first; i < n_touched * LK_INLINE_GROUPS; i += i_stride) {
         const int g = i / n_touched, t = i - g * n_touched;
         const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
         const int4 hd = *reinterpret_cast<const int4*>(job);
@@ -684,6 +686,10 @@ __global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, L
         for (int k = 0; k < 3; ++k) pl->center[k] = fit.c[k], pl->normal[k] = fit.vmin[k], pl->plane_var[k] = fit.vmid[k], pl->plane_var[3 + k] = fit.vmax[k];
         pl->plane_var[6] = fit.emin, pl->plane_var[7] = fit.emid, pl->plane_var[8] = fit.emax;
     }
+}
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
+__global__ void __launch_bounds__(LK_WAVE, 5) lk_ov_fit_eig_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    ov_fit_eig_body(base, ov, pr, blockIdx.y, (int)(blockIdx.x * LK_WAVE + threadIdx.x), (int)(gridDim.x * LK_WAVE));
 }
 #endif
 #ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
@@ -781,17 +787,16 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
 #ifndef LK_FIT_GROUP
 #define LK_FIT_GROUP 8
 #endif
-#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
-__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_group_kernel(LkMap base, LkOverlay ov, LkParams pr) {
-    __shared__ int owner[LK_WAVE * 5];
-    const unsigned int slot = blockIdx.y;
+// (wave w_first of w_stride over the slot's jobs, `owner` = LK_WAVE * 5 ints of LDS that belong to this wave: the kernel below, and one phase of lk_ov_tail_kernel)
+__device__ __forceinline__ void ov_fit_group_body(const LkMap& base, const LkOverlay& ov, const LkParams& pr, const unsigned int slot, int* owner, const int w_first,
+                                                  const int w_stride, const int lane) {
     const LkMap pm = ov_slot_map(ov, slot);
     if (pm.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;   // entry [g][t]: inline leaf group g of touched root t
-    const int lane = threadIdx.x, sub = lane & (LK_FIT_GROUP - 1), grp = lane / LK_FIT_GROUP;
+    const int sub = lane & (LK_FIT_GROUP - 1), grp = lane / LK_FIT_GROUP;
     const int total = n_touched * LK_INLINE_GROUPS;
-    for (int i0 = blockIdx.x * LK_WAVE; i0 < total; i0 += gridDim.x * LK_WAVE) {   // wave-uniform
+    for (int i0 = w_first * LK_WAVE; i0 < total; i0 += w_stride * LK_WAVE) {   // wave-uniform
         const int i = i0 + lane;
         int4 hd = make_int4(0, 0, 0, 0);
         int2 bs = make_int2(0, 0);
@@ -886,6 +891,11 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_group_kernel(
         __builtin_amdgcn_wave_barrier();   // owner[] is rewritten by the next round
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
+__global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_group_kernel(LkMap base, LkOverlay ov, LkParams pr) {
+    __shared__ int owner[LK_WAVE * 5];
+    ov_fit_group_body(base, ov, pr, blockIdx.y, owner, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
 #endif
 
@@ -1156,15 +1166,15 @@ __global__ void __launch_bounds__(LK_WAVE, 4) lk_ov_root_lane_kernel(LkMap base,
 template <bool LEAN>
 __global__ void __launch_bounds__(LK_MB) lk_ov_mid_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* __restrict__ filters, LkPtSrc src) {
     const unsigned int slot = blockIdx.x;
-    const int tid = (int)threadIdx.x;
-    ov_materialise_body<LEAN>(base, ov, pr, slot, 0, 1, tid);
+    const int tid = (int)threadIdx.x, T = (int)blockDim.x;   // launched with 64 .. LK_MB threads (a multiple of 64 that divides 256)
+    ov_materialise_body<LEAN>(base, ov, pr, slot, 0, 1, tid, T);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     {
         const lk_point* pts;
         const int n = ov_pt_src(src, slot, &pts);
-        for (int bx = 0; bx * 256 < n; ++bx) ov_point_geom_body(ov, pr, filters, src, slot, bx, tid);
+        for (int i0 = 0; i0 < n; i0 += T) ov_point_geom_body(ov, pr, filters, src, slot, (i0 + tid) >> 8, (i0 + tid) & 255);   // (the body's point index = 256 bx + tid)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -1197,6 +1207,37 @@ __global__ void __launch_bounds__(LK_MB)
     if (n == 0) return;
     dev_insert_apply<false>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                             (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6));
+}
+#endif
+// Round 6, small buckets (the recorded-run batch, every bucket <= LK_SCAN_WAVE_MAX points): what follows the fast root pass - the generic root pass over the
+// roots it left (lk_ov_insert_root_kernel<.., CPLX>), both halves of the plane fits, the apply pass - of ONE slot as one workgroup of one launch.  As four
+// launches each costs its slowest slot's chain plus a launch (7.5 + 9.0 + 9.2 + 5.4 us per bucket index, profiles/r06_ragged_overlay_pmc.json) whatever the
+// slot at hand has to do - mostly nothing: a slot without work leaves here after its counter reads, and one with work runs its phases back to back.  The
+// registers are the apply pass's (two waves per SIMD); what a phase writes the next one reads through the same CU's L1 (workgroup-scope fences).
+#ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
+__global__ void __launch_bounds__(LK_MB, 2) lk_ov_tail_kernel(LkMap base, LkOverlay ov, LkParams pr, const LkFilter* filters, LkPtSrc src) {
+    __shared__ int owner[(LK_MB / LK_WAVE) * LK_WAVE * 5];
+    const unsigned int slot = blockIdx.x;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, nw = (int)blockDim.x >> 6, lane = tid & 63;   // launched with 1 .. LK_MB / 64 waves
+    const LkMap pm = ov_slot_map(ov, slot);
+    if (pm.counters[LK_CTR_ERR]) return;   // this slot's pools overflowed: the call fails, nothing more is built on clamped ids
+    const lk_point* pts;
+    const int n = ov_pt_src(src, slot, &pts);
+    if (n != 0)
+        dev_insert_root<false, true, true>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, wave, nw, &base,
+                                           ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ov_fit_eig_body(base, ov, pr, slot, tid, (int)blockDim.x);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ov_fit_group_body(base, ov, pr, slot, owner + wave * (LK_WAVE * 5), wave, nw, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (n != 0 && !pm.counters[LK_CTR_ERR]) dev_insert_apply<false>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, wave, nw);
 }
 #endif
 // A FEW workgroups for the whole batch.  The code needs 254 + 126 registers and 6.3 KB of scratch per lane, and a launch with a workgroup per

@@ -1439,6 +1439,101 @@ def test_batch_replay_overlay(scene, oracle_lib, hip_lib, case):
 
 
 @pytest.mark.parametrize("mode", ["plain", "imu", "kin"])
+def test_batch_replay_overlay_ragged_scan_resident(scene, oracle_lib, hip_lib, mode, monkeypatch):
+    """The scan-resident form of lk_batch_replay_overlay_ragged_dev (every bucket <= 512 points: ONE launch carries a scan through its whole bucket
+    chain with the insert; a scan whose bucket leaves items for the insert's fallback code stops there, the fallback launch runs, the scans go on):
+    on a YOUNG map - voxels are created, cut and refitted all the time, so scans do stop - the same bits as the launch-by-launch form
+    (LEGKILO_RAG_RESIDENT=0: states, covariances, every private voxel), and per slot the oracle's KILO::process on a private copy of the map:
+    counts exact, state 1e-6, private voxels equal.  Shapes: config-1 scans, a scan of 40 buckets of ~150 points, a one-point scan."""
+    if mode == "kin":
+        sc = scenes.Scene(params=dict(config.DITER, voxel_grid_resolution=0.3), **CAPS)
+        o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=False)
+    else:
+        sc = scene
+        o = oracle_lib.Oracle(sc.cfg(), imu_mode_only=True)
+    t0 = 2.0
+    x0 = scenes.init_filter(o, sc, t0)
+    scenes.first_frame(o, sc, t0, x0)   # a first frame only: most of what the scans see is new
+    o.map_import(o.map_export())
+    blob = o.map_export()
+    base = scenes.canon_map(blob)
+    rng = np.random.default_rng(717171)
+    shapes = [None, (6000, 40), "clutter", (1, 1), None, "clutter"]
+    scans, tbs, xs, Ps, msgs = [], [], [], [], []
+    for s, shp in enumerate(shapes):
+        tb = t0 + 0.4 + 0.23 * s
+        x_prior = synth.initial_state(sc.traj, tb, sc.P, rng, 0.02, 0.5)
+        if shp is None:
+            pts = scenes.vlp_scan_input(sc, tb, 180 + s)
+        elif shp == "clutter":
+            # a config-1 scan with volumetric clutter in front of the robot in 30 of its buckets: voxels that are NOT planes - cut down to layer 2,
+            # leftover points, the insert's fallback items (what stops a scan in the resident launch); the scan's own points keep the state well determined
+            pts = scenes.vlp_scan_input(sc, tb, 180 + s)
+            R0, p0 = x_prior[:9].reshape(3, 3), x_prior[9:12]
+            eR, eT = np.asarray(sc.P["extrinsic_R"], dtype=np.float64).reshape(3, 3), np.asarray(sc.P["extrinsic_T"], dtype=np.float64)
+            pw = scenes.corner_clutter(rng, n_cells=30, per_cell=60, origin=tuple(p0 + np.array([1.5, -1.0, -0.2])))
+            pb = ((pw - p0) @ R0 - eT) @ eR
+            cl = np.zeros(len(pb), dtype=synth.POINT_DTYPE)
+            cl["x"], cl["y"], cl["z"] = pb[:, 0], pb[:, 1], pb[:, 2]
+            stamps = np.unique(pts["curvature"])
+            cl["curvature"] = stamps[((np.arange(len(pb)) // 60) * (len(stamps) // 31)) % len(stamps)]   # 60 at a time, in 30 of the scan's buckets
+            pts = np.concatenate([pts, cl])
+            pts = pts[np.argsort(pts["curvature"], kind="stable")]
+        else:
+            pts = synth.dense_scan(sc.world, sc.traj, tb, sc.P, n=shp[0], n_buckets=shp[1], seed_scan=7600 + s, seed_noise=7700 + s)
+        assert np.diff(synth.buckets_of(pts)[0].astype(np.int64)).max() <= 512
+        scans.append(pts)
+        tbs.append(tb)
+        xs.append(x_prior)
+        Ps.append(1e-4 * np.eye(30))
+        if mode == "imu":
+            msgs.append(synth.imu_stream(sc.traj, tb, tb + 0.1, seed=9500 + s))
+        elif mode == "kin":
+            msgs.append(synth.kin_stream(sc.traj, tb, tb + 0.1, sc.P, seed=9600 + s))
+    S = len(scans)
+    g = hip_lib.LegKiloHip(sc.cfg(n_slots=S))
+    g.map_import(blob)
+    g.init_process_cov_q()
+    g.set_acc_norm(9.81)
+    o.set_acc_norm(9.81)
+    kw = {"imus": msgs} if mode == "imu" else {"kins": msgs} if mode == "kin" else {}
+    monkeypatch.delenv("LEGKILO_RAG_RESIDENT", raising=False)
+    poses = g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
+    rounds = g.overlay_resident_rounds()
+    Xall, Pall = g.batch_get_states(0, S)
+    exports = [g.overlay_export(s) for s in range(S)]
+    assert rounds >= 2, f"no scan stopped for the fallback launch ({rounds} launch): the protocol is not exercised"
+    monkeypatch.delenv("LEGKILO_RAG_RESIDENT", raising=False)
+    for s in range(S):
+        o.map_import(blob)
+        o.set_map_insert(True)
+        o.set_state(xs[s], Ps[s])
+        o.set_times(tbs[s], tbs[s])
+        okw = {"imus": msgs[s]} if mode == "imu" else {"kins": msgs[s]} if mode == "kin" else {}
+        po, _ = o.process_scan(scans[s], tbs[s], **okw)
+        xo, Po = o.get_state()
+        assert (po.n_buckets, po.n_updates, int(po.n_effect)) == (poses[s].n_buckets, poses[s].n_updates, int(poses[s].n_effect)), \
+            (mode, s, po.n_buckets, po.n_updates, po.n_effect, poses[s].n_buckets, poses[s].n_updates, poses[s].n_effect)
+        xtol = 1e-6
+        assert np.abs(xo - Xall[s]).max() < xtol, (mode, s, np.abs(xo - Xall[s]).max())
+        assert np.abs(Pall[s] - Po).max() <= xtol * np.abs(Po).max(), (mode, s)
+        # (stored points: the state's 1e-6 times the lever arm of a voxel 25 m away)
+        st = scenes.compare_overlay(exports[s], base, scenes.canon_map(o.map_export()), (mode, s), rtol=1e-4, ptol=2e-6)
+        print(f"scan-resident overlay {mode} slot {s}: {len(scans[s])} points, {po.n_buckets} buckets, n_effect {int(po.n_effect)}, private roots {st['private_roots']}, "
+              f"max |dx| {np.abs(xo - Xall[s]).max():.2e}; {rounds} launches")
+    monkeypatch.setenv("LEGKILO_RAG_RESIDENT", "0")
+    poses0 = g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
+    assert g.overlay_resident_rounds() == 0
+    X0, P0 = g.batch_get_states(0, S)
+    assert np.array_equal(Xall, X0) and np.array_equal(Pall, P0), "scan-resident and launch-by-launch replay differ"
+    for s in range(S):
+        assert (poses0[s].n_buckets, poses0[s].n_updates, int(poses0[s].n_effect)) == (poses[s].n_buckets, poses[s].n_updates, int(poses[s].n_effect))
+        assert scenes.maps_identical(g.overlay_export(s), exports[s]), (mode, s)
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "imu", "kin"])
 def test_batch_replay_overlay_ragged(scene, oracle_lib, hip_lib, mode):
     """lk_batch_replay_overlay_ragged_dev: a recorded run's scans - every scan its own size, time buckets and start time, optionally its IMU
     (only_imu_use) or kinematic + IMU (leg fusion, KILO.cc:379-390) messages between the buckets - replayed WITH the map insert, each scan on

@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("lk_rag_ov_front_kernel", "lk_ov_mid_kernel", "lk_ov_insert_root_kernel", "lk_ov_fit_eig_kernel", "lk_ov_fit_group_kernel", "lk_ov_insert_apply_kernel",
+KERNELS = ("lk_rag_ov_scan_kernel", "lk_rag_ov_front_kernel", "lk_ov_mid_kernel", "lk_ov_insert_root_kernel", "lk_ov_fit_eig_kernel", "lk_ov_fit_group_kernel", "lk_ov_insert_apply_kernel",
            "lk_ov_insert_fallback_kernel", "lk_ov_reset_kernel", "lk_ov_frozen_bits_kernel", "lk_ov_base_sums_kernel", "lk_ov_status_kernel")
 
 
@@ -41,7 +41,7 @@ def main():
     if not replays:
         print("no overlay replay in the trace")
         return 1
-    indices = n_disp.get("lk_rag_ov_front_kernel", 0) / replays
+    indices = n_disp.get("lk_rag_ov_front_kernel", 0) / replays   # 0 in the scan-resident form: the whole chain is lk_rag_ov_scan_kernel
     try:
         e = json.loads(open(line).read().strip().splitlines()[-1])["extra"]
         unprof = {k: v for k, v in e.items() if k.startswith("config1_overlay_ragged")}
