@@ -119,6 +119,17 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 // lk_ov_insert_fallback_kernel): a scan whose bucket leaves fallback items stops behind that bucket (cur[slot] = the next one, fb_b[slot] = this one), the host
 // runs the fallback launch for the stopped scans and launches again - LkResume's protocol of the stream path.  Same device functions in the same order per
 // scan: bit-identical to the launch-by-launch form (test_batch_replay_overlay_ragged; LEGKILO_RAG_RESIDENT=0 is the A/B).
+// Between two phases of the scan kernel: workgroup-scope fence + barrier, as in the fused kernels above.  (Its workgroup IS one wave, so a wavefront-scope fence
+// + wave barrier - the compiler keeps the order, nothing is waited for - would do: -DLK_SCAN_SYNC_WG=0, measured 10.86 against 10.85 ms per batch, green.  The
+// waits are not what a bucket costs; the stronger form stays.)
+#ifndef LK_SCAN_SYNC_WG
+#define LK_SCAN_SYNC_WG 1
+#endif
+#if LK_SCAN_SYNC_WG
+#define LK_SCAN_PHASE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); } while (0)
+#else
+#define LK_SCAN_PHASE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 template <bool XID>
 __global__ void __launch_bounds__(LK_WAVE, 2)
     lk_rag_ov_scan_kernel(LkMap base, LkOverlay ov, LkParams pr, LkFilter* filters, const double* __restrict__ Q, LkRagged rg, const lk_point* __restrict__ d_pts,
@@ -205,43 +216,39 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
             t_upd = tb;
         }
         __syncthreads();
-        for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
+        // the insert reads the posterior through the filter record (see lk_rag_ov_front_kernel) - of the covariance only what load_bucket_const takes, the two 3 x 3
+        // blocks of rotation and position: those twelve entries and the state go out every bucket, the whole covariance when the scan leaves the launch
+        if (lane < 12) {
+            const int e = lane < 3 ? lane : lane < 5 ? 28 + lane : lane == 5 ? 62 : lane < 9 ? 87 + lane : lane < 11 ? 115 + lane : 155;   // 0 1 2 31 32 62 | 93 94 95 124 125 155
+            f->P[e] = sm.P[e];
+        }
         if (lane < 36) f->x[lane] = sm.x[lane];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the insert reads the posterior through the filter record (see lk_rag_ov_front_kernel)
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         dev_bucket_begin_wave(pm);
         for (int i = lane; i < n; i += LK_WAVE) {
             const int r = ov_reproject_point(base, ov, pr, filters, pts, i, (unsigned int)slot);
             ov.ptroot[(size_t)slot * ov.scan_cap + i] = r;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         // ---- middle (lk_ov_mid_kernel<true>)
         const LkPtSrc src = {d_pts, 0, 0, rg.pt_off, rg.nb, rg.ldb, b, nullptr};
         ov_materialise_body<true>(base, ov, pr, (unsigned int)slot, 0, 1, lane, LK_WAVE);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         for (int i0 = 0; i0 < n; i0 += LK_WAVE) ov_point_geom_body(ov, pr, filters, src, (unsigned int)slot, (i0 + lane) >> 8, (i0 + lane) & 255);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         ov_root_lane_body(base, ov, pr, (unsigned int)slot, 0, 1, lane);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         // ---- tail (lk_ov_tail_kernel)
         if (!pm.counters[LK_CTR_ERR] && n != 0)
             dev_insert_root<false, true, true>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, 0, 1, &base,
                                                ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         ov_fit_eig_body(base, ov, pr, (unsigned int)slot, lane, LK_WAVE);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         ov_fit_group_body(base, ov, pr, (unsigned int)slot, owner, 0, 1, lane);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         if (!pm.counters[LK_CTR_ERR] && n != 0) dev_insert_apply<false>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, 0, 1);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        LK_SCAN_PHASE_SYNC();
         // ---- what this launch cannot do: the fallback items of this bucket, or a pool that has run over (the call fails / grows and starts again)
         const unsigned int err = pm.counters[LK_CTR_ERR], nfb = pm.counters[LK_CTR_FALLBACK];
         if (err) {
@@ -249,6 +256,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
             return;
         }
         if (nfb) {
+            for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
             if (lane == 0) {
                 cur[slot] = b + 1, fb_b[slot] = b;
                 atomicAdd(pending, 1u);
@@ -256,6 +264,7 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
             return;
         }
     }
+    for (int e = lane; e < 900; e += LK_WAVE) f->P[e] = sm.P[e];
     dev_bucket_begin_wave(pm);   // finished: the launches behind this one find its work lists empty
     if (lane == 0) cur[slot] = nbk, fb_b[slot] = -1;
 }
