@@ -130,8 +130,11 @@ __global__ void __launch_bounds__(LK_WAVE, 2)
 #else
 #define LK_SCAN_PHASE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+#ifndef LK_SCAN_WAVES
+#define LK_SCAN_WAVES 1   // waves per SIMD the register allocation aims at
+#endif
 template <bool XID>
-__global__ void __launch_bounds__(LK_WAVE, 2)
+__global__ void __launch_bounds__(LK_WAVE, LK_SCAN_WAVES)
     lk_rag_ov_scan_kernel(LkMap base, LkOverlay ov, LkParams pr, LkFilter* filters, const double* __restrict__ Q, LkRagged rg, const lk_point* __restrict__ d_pts,
                           int msg_kind, int* __restrict__ cur, int* __restrict__ fb_b, unsigned int* __restrict__ pending) {
     __shared__ WaveSmem sm;
