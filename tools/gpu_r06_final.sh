@@ -9,8 +9,9 @@ cd $REPO
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/suite.log 2>&1; echo "suite: $(tail -n 1 $OUT/suite.log)"
 LEGKILO_POISON_POOLS=1 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q > $OUT/suite_poisoned.log 2>&1; echo "poisoned: $(tail -n 1 $OUT/suite_poisoned.log)"
 LK_PROF_COMMIT=$C timeout 1500 python tools/parity_all_slots.py --out $OUT/r06_parity_all_slots.json > $OUT/parity.log 2>&1; echo "parity_all_slots rc $?"; tail -n 2 $OUT/parity.log | cut -c1-500
-bash tools/gpu_prof_overlay_r05.sh r06p 'stats fetch write sq' $C > $OUT/ovprof.log 2>&1; tail -n 2 $OUT/ovprof.log
-cp $REPO/gpurun_out/prof_overlay_r06p/latest_overlay_pmc.json $REPO/profiles/latest_overlay_pmc.json   # the bench lines below read it
+bash tools/gpu_prof_overlay_r05.sh r06r 'stats fetch write sq' $C > $OUT/ovprof.log 2>&1; tail -n 2 $OUT/ovprof.log
+cp $REPO/gpurun_out/prof_overlay_r06r/latest_overlay_pmc.json $REPO/profiles/latest_overlay_pmc.json   # the bench lines below read it
 cd $REPO
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "driver line rc $?"
 timeout 600 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default line rc $?"
+bash tools/gpu_prof_ragov.sh r06r $C > $OUT/ragov.log 2>&1; tail -n 3 $OUT/ragov.log | cut -c1-400
