@@ -1521,6 +1521,19 @@ def test_batch_replay_overlay_ragged_scan_resident(scene, oracle_lib, hip_lib, m
         st = scenes.compare_overlay(exports[s], base, scenes.canon_map(o.map_export()), (mode, s), rtol=1e-4, ptol=2e-6)
         print(f"scan-resident overlay {mode} slot {s}: {len(scans[s])} points, {po.n_buckets} buckets, n_effect {int(po.n_effect)}, private roots {st['private_roots']}, "
               f"max |dx| {np.abs(xo - Xall[s]).max():.2e}; {rounds} launches")
+    if mode == "plain":
+        # pools far too small for what a scan touches, poisoned: the resident launch leaves the scan at its overflow, the call fails loudly with
+        # LK_ERR_CAPACITY (no fault, no hang), and the handle replays the same batch to the same bits once the pools may grow again
+        monkeypatch.setenv("LEGKILO_POISON_POOLS", "1")
+        g.overlay_reserve(64, 128, 64)
+        with pytest.raises(hip_lib.LegKiloError, match="overlay pool overflow"):
+            g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
+        monkeypatch.delenv("LEGKILO_POISON_POOLS", raising=False)
+        g.overlay_reserve(0, 0, 0)
+        g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
+        assert g.overlay_resident_rounds() == rounds
+        Xr, Pr = g.batch_get_states(0, S)
+        assert np.array_equal(Xall, Xr) and np.array_equal(Pall, Pr)
     monkeypatch.setenv("LEGKILO_RAG_RESIDENT", "0")
     poses0 = g.batch_replay_overlay_ragged(scans, tbs, xs, Ps, **kw)
     assert g.overlay_resident_rounds() == 0
