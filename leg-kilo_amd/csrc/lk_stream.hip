@@ -272,6 +272,20 @@ __device__ unsigned long long lk_res_ts[6][1024];   // per bucket: 0 filter post
 #define RS_STAMP(k) do { } while (0)
 #define RS_FLUSH(o) do { } while (0)
 #endif
+// The message updates of the scan-resident stream kernel as CALLS (-DLK_MSG_CALL=1; A/B): a kinematic + IMU message is an 18-column Gauss-Jordan in registers,
+// run a few dozen times per scan; inlined, its register demand is the whole kernel's (256 + 240 B of scratch for MSG == 2 against 96 B without messages) and the
+// per-bucket code pays the spills.
+#ifndef LK_MSG_CALL
+#define LK_MSG_CALL 0
+#endif
+#if LK_MSG_CALL
+__device__ __attribute__((noinline)) void stream_kin_update_call(WaveSmem& sm, double* scratch, const double* msg, double acc_scale, const double* Rn6, double kin_noise, int lane) {
+    wave_kin_update_core<true>(sm, scratch, msg, acc_scale, Rn6, kin_noise, lane);
+}
+__device__ __attribute__((noinline)) void stream_imu_update_call(WaveSmem& sm, const double* acc, const double* gyr, double acc_scale, const double* Rn6, int lane) {
+    wave_imu_update_core<true>(sm, acc, gyr, acc_scale, Rn6, lane);
+}
+#endif
 template <int MSG, bool XID>
 __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     lk_scan_stream_kernel(LkMap map, LkParams pr, LkFilter* filters, const lk_point* __restrict__ pts, LkRagged rg, const double* __restrict__ Q,
@@ -395,10 +409,17 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         RS_STAMP(0);
         if (is_msg) {   // predictUpdateImu, KILO.cc:235-258 / predictUpdateKinImu, KILO.cc:260-314
             const double* mm = rg.imu + mstride * (size_t)qi;
+#if LK_MSG_CALL
+            if (MSG == 2)
+                stream_kin_update_call(sm, rows, mm, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
+            else
+                stream_imu_update_call(sm, mm + 1, mm + 4, rg.acc_scale, rg.Rn, lane);
+#else
             if (MSG == 2)
                 wave_kin_update_core<true>(sm, rows, mm, rg.acc_scale, rg.Rn, rg.kin_noise, lane);
             else
                 wave_imu_update_core<true>(sm, mm + 1, mm + 4, rg.acc_scale, rg.Rn, lane);
+#endif
             t_upd = t;  // KILO.cc:256 / :312
             ++qi;
             RS_STAMP(6);
