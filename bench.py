@@ -66,6 +66,8 @@ OV_KERNEL_SOURCES = ("lk_overlay_kernels.h", "lk_map_kernels.h", "lk_device.h")
 OUSTER_MSG_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<u4")])
 OUSTER_MSG_LAYOUT = dict(point_step=16, off_x=0, off_y=4, off_z=8, off_time=12, lidar_type=2)
 T0_CONFIG4 = 3.0
+RAGOV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_ragged_overlay_pmc.json")
+RAGOV_KERNEL_SOURCES = ("lk_overlay.hip", "lk_overlay_kernels.h", "lk_map_kernels.h", "lk_filter_kernels.h", "lk_point_kernels.h", "lk_device.h")   # what the scan-resident overlay kernel is made of
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
 
 
@@ -979,6 +981,26 @@ def main():
             extra["config1_overlay_ragged_mean_n_effect"] = round(float(p1ov["n_effect"].astype(np.float64).mean()), 1)
             # launches of the scan-resident kernel (1 + the most fallback stops of any scan); 0: the batch ran launch by launch (LEGKILO_RAG_RESIDENT=0, or a bucket over 512 points)
             extra["config1_overlay_ragged_resident_launches"] = g.overlay_resident_rounds()
+            # counter-derived figures of that replay (tools/gpu_prof_ragov.sh -> profiles/latest_ragged_overlay_pmc.json), time from THIS run
+            rr = {"bound": "latency: one wave per scan runs the scan's whole bucket chain - a dependent chain of wave instructions and memory round trips, not bandwidth",
+                  "ms_per_batch": extra["config1_overlay_ragged_ms_per_batch"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            if os.path.exists(RAGOV_PMC_FILE):
+                rp = json.load(open(RAGOV_PMC_FILE))
+                rr["pmc_source"] = f"profiles/latest_ragged_overlay_pmc.json (tag {rp.get('tag')}, commit {rp.get('commit')})"
+                if rp.get("kernel_sources_sha16") != kernel_sources_sha16(RAGOV_KERNEL_SOURCES):
+                    warnings.append(f"recorded-run overlay counters (profiles/latest_ragged_overlay_pmc.json, tag {rp.get('tag')}) were collected on a different version of "
+                                    f"{', '.join(RAGOV_KERNEL_SOURCES)}: re-run tools/gpu_prof_ragov.sh")
+                k = (rp.get("kernels") or {}).get("lk_rag_ov_scan_kernel")
+                if k and extra["config1_overlay_ragged_resident_launches"]:
+                    scans_prof = (rp.get("unprofiled_line") or {}).get("config1_overlay_ragged_batch") or S1o
+                    rr.update({"kernel": "lk_rag_ov_scan_kernel", "launches_per_batch": k["launches_per_replay"], "kernel_ms_under_profiler": round(k["ms_per_replay"], 3),
+                               "traffic": k["hbm_MB_per_replay"] * 1e6, "achieved": round(k["hbm_MB_per_replay"] * 1e6 / (el1o) / 1e9, 1),
+                               "frac": round(k["hbm_MB_per_replay"] * 1e6 / el1o / 1e9 / HBM_PEAK_GBS, 4),
+                               "valu_wave_insts_per_scan": round(k["valu_insts_per_replay"] / scans_prof), "wait_any_frac_of_wave_cycles": k["wait_any_frac_of_wave_cycles"]})
+            else:
+                rr["pmc_source"] = None
+                warnings.append("profiles/latest_ragged_overlay_pmc.json missing: extra.config1_overlay_ragged_roofline has the time only (tools/gpu_prof_ragov.sh)")
+            extra["config1_overlay_ragged_roofline"] = rr
         except Exception as e:  # noqa: BLE001
             extra["config1_overlay_ragged_error"] = f"{type(e).__name__}: {str(e)[:200]}"
             warnings.append("config-1 overlay replay failed: " + extra["config1_overlay_ragged_error"])

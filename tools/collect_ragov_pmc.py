@@ -61,13 +61,17 @@ def main():
         tot_ms += ms
         tot_b += b
         print(f"{k:32s} {n_disp[k] / replays:7.1f} launches  {t_ns[k] / 1e3 / n_disp[k]:7.1f} us each  {ms:7.2f} ms/replay  HBM {b / 1e6:8.1f} MB/replay")
-    res = {"tag": tag, "commit": os.environ.get("LK_PROF_COMMIT", "unknown"),
+    sys.path.insert(0, ROOT)
+    import bench  # noqa: E402
+
+    res = {"tag": tag, "commit": os.environ.get("LK_PROF_COMMIT", "unknown"), "kernel_sources_sha16": bench.kernel_sources_sha16(bench.RAGOV_KERNEL_SOURCES),
            "what": "tools/gpu_prof_ragov.sh: rocprofv3 kernel trace + PMC passes of bench.py with only the recorded-run batch WITH insert on (1 024 config-1 scans); counters summed "
                    "over all dispatches of a kernel and divided by the replays in the run (= launches of lk_ov_reset_kernel); FETCH_SIZE / WRITE_SIZE in KiB, reads doubled (gfx950)",
            "replays_profiled": replays, "bucket_indices_per_replay": indices, "unprofiled_line": unprof, "kernels": kernels,
            "sum_of_kernel_ms_per_replay": tot_ms, "kernel_us_per_bucket_index": tot_ms * 1e3 / indices if indices else None,
            "hbm_GB_per_replay": tot_b / 1e9, "hbm_frac_of_8TBs_over_kernel_time": (tot_b / 1e9) / (tot_ms / 1e3) / 8000.0 if tot_ms else None}
     json.dump(res, open(os.path.join(out, f"{tag}_ragged_overlay_pmc.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(out, "latest_ragged_overlay_pmc.json"), "w"), indent=1)   # what bench.py's extra.config1_overlay_ragged_roofline reads
     print({k: v for k, v in res.items() if k not in ("kernels", "what")})
     return 0
 
