@@ -524,11 +524,12 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
     static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
-    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 3): the scans are independent, and the passes of a bucket are of two
+    // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 4 - round 6, same box: 15.14 / 13.48 / 13.02 / 12.74 ms with 1 / 2 / 3 / 4 groups, 14.8 / 14.2 with
+    // 6 / 8: beyond four streams the queues share hardware): the scans are independent, and the passes of a bucket are of two
     // kinds - the root pass issues VALU work at 2.8 TB/s of HBM traffic, the others (re-projection, copy-on-write, plane fits) only move
     // bytes - so one group's root pass runs beside the other group's memory passes.  A group is the same launches with every per-slot
     // array offset to its first slot (ov_at).  Profiling mode (per-launch events + sync) and small batches stay on one stream.
-    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 3;
+    static const int ov_groups_env = getenv("LEGKILO_OV_GROUPS") ? std::min(std::max(atoi(getenv("LEGKILO_OV_GROUPS")), 1), (int)lk_handle::kMaxGroups) : 4;
     const int ngroups = (!h->profiling && S >= 64 * ov_groups_env) ? ov_groups_env : 1;
     hipStream_t streams[lk_handle::kMaxGroups];
     streams[0] = h->stream;
