@@ -67,7 +67,7 @@ OUSTER_MSG_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<u
 OUSTER_MSG_LAYOUT = dict(point_step=16, off_x=0, off_y=4, off_z=8, off_time=12, lidar_type=2)
 T0_CONFIG4 = 3.0
 RAGOV_PMC_FILE = os.path.join(ROOT, "profiles", "latest_ragged_overlay_pmc.json")
-RAGOV_KERNEL_SOURCES = ("lk_overlay.hip", "lk_overlay_kernels.h", "lk_map_kernels.h", "lk_filter_kernels.h", "lk_point_kernels.h", "lk_device.h")   # what the scan-resident overlay kernel is made of
+RAGOV_KERNEL_SOURCES = ("lk_ovscan.hip", "lk_overlay_kernels.h", "lk_map_kernels.h", "lk_filter_kernels.h", "lk_point_kernels.h", "lk_device.h")   # what the scan-resident overlay kernel is made of
 KERNEL_SOURCES = ("lk_point_kernels.h", "lk_device.h")   # where the batch residual kernel lives (lk_residual_kernel, residual_tile, geometry)
 
 

@@ -1,14 +1,14 @@
 // lk_internal.h - what the translation units of liblegkilo_hip.so share: the handle, the error / launch / allocation helpers, and the kernel
-// headers.  Round 6: the library is four units compiled side by side - legkilo_hip.hip (LK_TU_MAIN: the C-ABI but for the overlay entries, and every
+// headers.  Round 6: the library is five units compiled side by side - legkilo_hip.hip (LK_TU_MAIN: the C-ABI but for the overlay entries, and every
 // kernel but the overlay's and the stream path's own), lk_stream.hip (LK_TU_STREAM: one live scan after the other with the map insert - the per-bucket
 // launches, the scan-resident / grid-resident / pipelined kernels, and the KILO-path entries that run them), lk_overlay.hip (LK_TU_OVERLAY: batch replay
-// WITH insert - lk_overlay_kernels.h's kernels and the entries that launch them), lk_prim.hip (rocPRIM).  A non-template kernel of a shared header is DEFINED in the main unit; the overlay unit sees its prototype
+// WITH insert - lk_overlay_kernels.h's kernels and the entries that launch them), lk_ovscan.hip (LK_TU_OVSCAN: that replay's scan-resident kernel for small buckets), lk_prim.hip (rocPRIM).  A non-template kernel of a shared header is DEFINED in the main unit; the overlay unit sees its prototype
 // (LK_KERNELS_ELSEWHERE) and launches it through the main unit's host stub.  The overlay header's own kernels are compiled in the overlay unit only.
 #pragma once
-#if !defined(LK_TU_MAIN) && !defined(LK_TU_OVERLAY) && !defined(LK_TU_STREAM)
-#error "define LK_TU_MAIN, LK_TU_STREAM or LK_TU_OVERLAY before including lk_internal.h"
+#if !defined(LK_TU_MAIN) && !defined(LK_TU_OVERLAY) && !defined(LK_TU_STREAM) && !defined(LK_TU_OVSCAN)
+#error "define LK_TU_MAIN, LK_TU_STREAM, LK_TU_OVERLAY or LK_TU_OVSCAN before including lk_internal.h"
 #endif
-#if defined(LK_TU_OVERLAY) || defined(LK_TU_STREAM)
+#if defined(LK_TU_OVERLAY) || defined(LK_TU_STREAM) || defined(LK_TU_OVSCAN)
 #define LK_KERNELS_ELSEWHERE 1
 #endif
 // legkilo_hip.hip — implementation of the C-ABI in include/legkilo_hip.h for gfx950.
@@ -323,6 +323,9 @@ int run_scan(lk_handle* h, const lk_point* pts, const lk_point* d_pts, size_t n,
              size_t n_kin, float* xyz_world_out, lk_pose* out);          // the bucket loop of KILO::process on a sorted cloud that is in HBM (and on the host, for the bucket bounds)
 // overlay unit (lk_overlay.hip)
 void ov_free(lk_handle* h);
+// lk_ovscan.hip (LK_TU_OVSCAN: the scan-resident kernel of the recorded-run replay with insert, a unit of its own for the build time): one launch of it
+int ov_scan_launch(lk_handle* h, bool xid, int S, hipStream_t st, const LkMap& fmap, const LkOverlay& ov, LkFilter* fl, const LkRagged& rg, const lk_point* d_pts, int msg_kind,
+                   int* cur, int* fb_b, unsigned int* pending);
 int overlay_ragged_launch(lk_handle* h, const lk_point* d_pts, size_t S, const LkRagged& rg, const double* d_tbegin, int biggest, size_t ldb, const int* max_n,
                           size_t max_scan_pts, int msg_kind, lk_pose* out);
 }
