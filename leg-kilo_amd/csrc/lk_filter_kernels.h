@@ -1180,12 +1180,17 @@ __device__ __forceinline__ void dev_update_wave(LkFilter* f, WaveSmem& sm, const
     }
 }
 
+// Register budget of the one-wave update / predict kernels of the batch entries, in waves per SIMD.  A batch launches one wave per scan - 1 024 waves on 1 024
+// SIMDs - so occupancy buys nothing here, and at the residual kernel's five waves (96 registers) the filter cores spilled 76-100 B per lane.
+#ifndef LK_UPD_WAVES
+#define LK_UPD_WAVES 2
+#endif
 #ifdef LK_KERNELS_ELSEWHERE
-__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+__global__ void __launch_bounds__(LK_WAVE, LK_UPD_WAVES)
     lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
                           const double* __restrict__ Q, double t_next, int mode);
 #else
-__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+__global__ void __launch_bounds__(LK_WAVE, LK_UPD_WAVES)
     lk_update_wave_kernel(LkFilter* filters, const double* __restrict__ partials, int nblk, size_t slot_stride, double t,
                           const double* __restrict__ Q, double t_next, int mode) {
     __shared__ WaveSmem sm;
@@ -1196,11 +1201,11 @@ __global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
 // Ragged batch: bucket b of every scan that has one (b == -1: the predict to each scan's first bucket); times, bucket
 // sizes and "is there a next bucket" come from the scan's own tables.
 #ifdef LK_KERNELS_ELSEWHERE
-__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+__global__ void __launch_bounds__(LK_WAVE, LK_UPD_WAVES)
     lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
                                  const double* __restrict__ Q, LkRagged rg, int b, int update_only = 0);
 #else
-__global__ void __launch_bounds__(LK_WAVE, LK_OPT_WAVES)
+__global__ void __launch_bounds__(LK_WAVE, LK_UPD_WAVES)
     lk_update_wave_ragged_kernel(LkFilter* filters, const double* __restrict__ partials, size_t slot_stride,
                                  const double* __restrict__ Q, LkRagged rg, int b, int update_only = 0) {
     __shared__ WaveSmem sm;
