@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--map-warm", type=int, default=20, help="warm-up scans that build the shared map (SURVEY 8d: K0 = 20)")
     ap.add_argument("--stream-scans", type=int, default=24, help="consecutive scans of the single-stream (config 3) measurement")
     ap.add_argument("--cpu-sample", type=int, default=240, help="scans the oracle replays for cpu_baseline and parity_check (0 = skip)")
+    ap.add_argument("--config1-overlay-repeat", type=int, default=3, help="replays of the config-1 batch WITH insert (the last one is timed; all must give the same bits)")
     ap.add_argument("--config1-scans", type=int, default=2048, help="scans of the ragged config-1 batch measured as an extra (0 = skip)")
     ap.add_argument("--sustained-s", type=float, default=1.2, help="length of the sustained run reported in extra (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) variant of the step")
@@ -969,11 +970,17 @@ def main():
                 g.batch_set_priors_dev(d_x1.data_ptr(), d_P1.data_ptr(), S1o)
                 return g.batch_replay_overlay_ragged_dev(d_c1.data_ptr(), tables1o)
 
-            run_c1_ov()
-            run_c1_ov()
+            first = bytes(run_c1_ov())
+            same = 0
+            for _ in range(max(1, args.config1_overlay_repeat - 2)):   # the same batch again: the same bits every time (the overlays start empty)
+                same += int(bytes(run_c1_ov()) == first)
             tc = time.perf_counter()
             poses1o = run_c1_ov()
             el1o = time.perf_counter() - tc
+            same += int(bytes(poses1o) == first)
+            extra["config1_overlay_ragged_replays_identical"] = f"{same} / {max(1, args.config1_overlay_repeat - 2) + 1}"
+            if same != max(1, args.config1_overlay_repeat - 2) + 1:
+                warnings.append("config-1 overlay replay: a repeated replay of the same batch gave other results")
             p1ov = np.frombuffer(poses1o, dtype=_abi.pose_dtype()).copy()
             extra["config1_overlay_ragged_ms_per_batch"] = round(el1o * 1e3, 2)
             extra["config1_overlay_ragged_scans_per_s"] = round(S1o / el1o, 1)
