@@ -161,7 +161,7 @@ void lk_destroy(lk_handle* h) {
     void* ptrs[] = {h->map.hash, h->map.planes, h->map.match, h->map.nodes, h->map.blocks, h->map.counters, h->map.touched, h->map.heavy,
                     h->map.next, h->map.slots, h->map.scratch, h->map.groups, h->map.gidx, h->map.free_list, h->map.freed_next, h->d_filters, h->d_Q, h->d_partials, h->d_scan, h->d_world,
                     h->d_rows, h->d_valid, h->d_tmp, h->d_poses, h->d_rag, h->d_grid_mm, h->d_ragdev, h->d_ragtmp,
-                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids, h->d_fbackup, h->d_ov_priors, h->d_ov_res};
+                    h->map.dirty, h->map.newroot, h->map.spec, h->d_snap, h->d_ids, h->d_fbackup, h->d_ov_priors, h->d_ov_res, h->d_query};
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* pre[] = {h->pre_raw, h->pre_cells, h->pre_out, h->pre_k0, h->pre_k1, h->pre_flags, h->pre_pos, h->pre_misc,
@@ -750,19 +750,25 @@ int lk_match_points(lk_handle* h, size_t n, const int32_t* keys3, const double* 
     if (n > (size_t)INT_MAX / 9) return fail(h, LK_ERR_INVALID, "lk_match_points: n too large");
     int rc = join_side_streams(h);   // the map as every earlier call on this handle left it
     if (rc) return rc;
-    DevTemps tmp;
-    int* d_keys = nullptr;
-    double *d_pw = nullptr, *d_var = nullptr, *d_f64 = nullptr;   // d_f64: prob | normal | center | d
-    float* d_dis = nullptr;
-    int* d_layer = nullptr;
-    unsigned char* d_u8 = nullptr;                                // found | success
-    HIPCHK(h, tmp.alloc(&d_keys, sizeof(int) * 3 * n));
-    HIPCHK(h, tmp.alloc(&d_pw, sizeof(double) * 3 * n));
-    HIPCHK(h, tmp.alloc(&d_var, sizeof(double) * 9 * n));
-    HIPCHK(h, tmp.alloc(&d_f64, sizeof(double) * 8 * n));
-    HIPCHK(h, tmp.alloc(&d_dis, sizeof(float) * n));
-    HIPCHK(h, tmp.alloc(&d_layer, sizeof(int) * n));
-    HIPCHK(h, tmp.alloc(&d_u8, 2 * n));
+    // one device buffer for the inputs and outputs of a query, kept by the handle and grown on demand (a caller of the class surface may ask point by point):
+    // doubles first, then the 4-byte arrays, then the bytes
+    const size_t need = sizeof(double) * (3 + 9 + 8) * n + sizeof(int) * (3 + 1) * n + sizeof(float) * n + 2 * n;
+    if (h->query_cap < need) {
+        if (h->d_query) {
+            HIPCHK(h, hipFree(h->d_query));
+            h->d_query = nullptr, h->query_cap = 0;
+        }
+        const size_t cap = std::max(need + need / 2, (size_t)65536);
+        HIPCHK(h, lk_hip_malloc(&h->d_query, cap));
+        h->query_cap = cap;
+    }
+    double* d_pw = reinterpret_cast<double*>(h->d_query);
+    double* d_var = d_pw + 3 * n;
+    double* d_f64 = d_var + 9 * n;   // prob | normal | center | d
+    int* d_keys = reinterpret_cast<int*>(d_f64 + 8 * n);
+    int* d_layer = d_keys + 3 * n;
+    float* d_dis = reinterpret_cast<float*>(d_layer + n);
+    unsigned char* d_u8 = reinterpret_cast<unsigned char*>(d_dis + n);   // found | success
     HIPCHK(h, hipMemcpyAsync(d_keys, keys3, sizeof(int) * 3 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_pw, pw, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_var, var9, sizeof(double) * 9 * n, hipMemcpyHostToDevice, h->stream));

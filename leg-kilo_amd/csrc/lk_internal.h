@@ -134,6 +134,8 @@ struct lk_handle {
     size_t ov_pool_bytes = 0;                             // bytes the overlay pools hold (lk_overlay_pool_bytes)
     LkFilter* d_ov_priors = nullptr;                      // the batch's priors, kept for the retry after a pool overflow
     size_t ov_priors_cap = 0;
+    void* d_query = nullptr;                              // lk_match_points: inputs + outputs of a query, grown on demand
+    size_t query_cap = 0;
     int* d_ov_res = nullptr;                              // scan-resident recorded-run replay with insert: [S] next bucket, [S] bucket with fallback items, stopped-scan counter
     size_t ov_res_cap = 0;
     unsigned int ov_res_rounds = 0;                       // launches of the scan-resident kernel in the last such replay
