@@ -278,6 +278,10 @@ __device__ unsigned long long lk_res_ts[6][1024];   // per bucket: 0 filter post
 #ifndef LK_MSG_CALL
 #define LK_MSG_CALL 0
 #endif
+// -DLK_PT_PREFETCH=1 (A/B, measured: no gain): the filter wave asks for the next bucket's scan points as soon as the current bucket's tiles are done
+#ifndef LK_PT_PREFETCH
+#define LK_PT_PREFETCH 0
+#endif
 #if LK_MSG_CALL
 __device__ __attribute__((noinline)) void stream_kin_update_call(WaveSmem& sm, double* scratch, const double* msg, double acc_scale, const double* Rn6, double kin_noise, int lane) {
     wave_kin_update_core<true>(sm, scratch, msg, acc_scale, Rn6, kin_noise, lane);
@@ -394,6 +398,10 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
     constexpr size_t mstride = MSG == 2 ? 33 : 7;
     RS_DECL;
     bool predicted = stage1_0 != 0;   // picked up behind a predict (LkResume::stage1)
+#if LK_PT_PREFETCH
+    const unsigned long long pts_end = po[nbk];   // one past the scan's last point
+    float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     bool stopped = false;             // left the loop in a wait for the insert team
     int b = bf0;
     while (b < nbk) {
@@ -455,6 +463,14 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
         }
         double totv = (lane < 29) ? (((0.0 + a0) + a1) + a2) + a3 : 0.0;  // tot[j] in lanes 0..31
         RS_STAMP(1);
+#if LK_PT_PREFETCH
+        // the NEXT bucket's points, requested now: their trip runs beside this bucket's wait, update and predict instead of at the head of the next tile (the
+        // value is only kept until the update is done - the tile's own load then finds the lines in the CU's L1)
+        {
+            const unsigned long long q = base + (unsigned long long)n + (unsigned long long)lane;
+            if (q < pts_end) pf = reinterpret_cast<const float4*>(pts)[q];
+        }
+#endif
         if (b > 0) {
             RS_TS(3, b - 1);
             if (!FLAG_WAIT_X(f_decided, b - 1)) { stopped = true; break; }   // the stamps of insert b - 1 are final (and insert b - 2 is complete)
@@ -493,6 +509,9 @@ __global__ void __launch_bounds__((1 + LK_INS_WAVES) * LK_WAVE)
             wave_update_core<true>(sm, totv, N, lane);
         }
         core_sync<true>();
+#if LK_PT_PREFETCH
+        asm volatile("" ::"v"(pf.x), "v"(pf.y), "v"(pf.z), "v"(pf.w));   // the request has to exist; nothing reads the value
+#endif
         RS_STAMP(4);
         // the posterior for the insert (dev_snapshot_posterior's fields): the buffer of bucket b - 2 is free once that insert is done
         if (b >= 2 && !FLAG_WAIT(f_done, b - 2)) break;   // (never behind a team that has left: its f_decided(b - 1) came after f_done(b - 2))
