@@ -361,7 +361,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (ov_fast) LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
     static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
-    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 8;
+    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 6;   // round 6, groups of eight lanes per fit: 2 / 4 / 6 / 8 / 16 / 32 waves per scan -> fit pass 2.19 / 2.03 / 1.89 / 2.07 / 2.33 / 3.56 ms
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
     // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 4 - round 6, same box: 15.14 / 13.48 / 13.02 / 12.74 ms with 1 / 2 / 3 / 4 groups, 14.8 / 14.2 with
     // 6 / 8: beyond four streams the queues share hardware): the scans are independent, and the passes of a bucket are of two
