@@ -718,8 +718,10 @@ static_assert(sizeof(LkGroup) == 64, "group descriptor must be 64 B");
 #ifndef LK_INLINE_GROUPS
 #define LK_INLINE_GROUPS 3   // roots with at most this many leaf groups are finished by their own wave, group after group (>= 1)
 #endif
+// Round 6: the four header words {leaf, block, cnt, decided} live in a DENSE int4 array of their own (LkOverlay::jobhdr, same [g][t] index): the fit passes look at
+// every touched root's three job slots and nearly all are empty - at a 96-B stride that scan was half of their HBM traffic.  The words below stay for the layout.
 struct LkFitJob {   // 96 B: a plane fit the overlay replay's root pass leaves to lk_ov_fit_lane_kernel (apply_leaf<DEFER>)
-    int leaf, block, cnt, decided;   // cnt = points of the leaf's last refit event (0: no fit), block = where they are, decided = is_plane of that event
+    int leaf, block, cnt, decided;   // (header, now in jobhdr) cnt = points of the leaf's last refit event (0: no fit), block = where they are, decided = is_plane of that event
     double s9[9];                    // its moment sums (sum p, sum p p^T)
     int base_block, n_base;          // a SPLIT leaf (lk_ov_root_lane_kernel): its first n_base points are in the base map's block base_block; else n_base = 0
 };
@@ -787,7 +789,7 @@ __device__ __forceinline__ void insert_defer(const LkMap& map, int leaf, int do_
 template <bool DEFER = false, typename PointAt, typename StoreIdx>
 __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr, const int Tn, const int Tp, const int To, const int g,
                                            const int root, const LeafInfo& li, int off, PointAt point_at, StoreIdx store_idx,
-                                           const lk_pt_rec* cow_src = nullptr, LkFitJob* job = nullptr) {
+                                           const lk_pt_rec* cow_src = nullptr, LkFitJob* job = nullptr, int4* job_hdr = nullptr) {
     const int lane = threadIdx.x & 63;
     bool cow_done = false;
 #ifdef LK_DEBUG_INS
@@ -931,10 +933,10 @@ __device__ __forceinline__ bool apply_leaf(const LkMap& map, const LkParams& pr,
             if (fitted) {
                 if (DEFER) {
                     if (lane == 0) {
-                        job->leaf = leaf, job->block = r.block, job->decided = fit.is_plane ? 1 : 0, job->base_block = -1, job->n_base = 0;
+                        job->base_block = -1, job->n_base = 0;
 #pragma unroll
                         for (int q = 0; q < 9; ++q) job->s9[q] = fit.s9[q];
-                        job->cnt = fit_count;
+                        *job_hdr = make_int4(leaf, r.block, fit_count, fit.is_plane ? 1 : 0);   // {leaf, block, cnt, decided}: the dense header array (LkFitJob)
                     }
                 } else {
                 // the one full fit of this leaf in this bucket: the state of its LAST refit event
@@ -1039,7 +1041,7 @@ __device__ __forceinline__ bool root_is_light(const LkParams& pr, int m, unsigne
 template <bool FROM_PV, bool OV = false, bool CPLX = false>
 __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams& pr, const LkFilter* filters, const lk_point* __restrict__ pts,
                                                 const lk_pt_rec* __restrict__ pv, int n, const int wave, const int nwaves, const LkMap* cow_base = nullptr,
-                                                LkFitJob* jobs = nullptr, const size_t job_stride = 0, unsigned int* dyn_next = nullptr) {
+                                                LkFitJob* jobs = nullptr, const size_t job_stride = 0, unsigned int* dyn_next = nullptr, int4* jobhdr = nullptr) {
     // dyn_next (not OV): a wave's FIRST root is its own index in the touched list, every further one the next nobody has taken (a ticket
     // counter, zero at the start of the pass) instead of index + nwaves: a wave that drew a plane fit (12-16 us) does not also own the
     // root nwaves further on while its neighbours, done with an append after 2 us, idle at the barrier (grid-resident stream kernel)
@@ -1126,7 +1128,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
         const lk_pt_rec* cow_src = nullptr;
         // this root's fit jobs (apply_leaf<DEFER>): none yet.  Entry [g][t] = its g-th inline leaf group: nearly every root is ONE group, so
         // plane 0 is dense for lk_ov_fit_lane_kernel's lanes (job_stride = entries per plane)
-        if (OV && lane < LK_INLINE_GROUPS) jobs[(size_t)lane * job_stride + tix].cnt = 0;
+        if (OV && lane < LK_INLINE_GROUPS) jobhdr[(size_t)lane * job_stride + tix].z = 0;
         int job_i = 0;
         int cow_n = 0;   // old points that still sit in the base block
         if (OV) {
@@ -1324,7 +1326,7 @@ __device__ __forceinline__ void dev_insert_root(const LkMap& map, const LkParams
                     if (lane < g) map.gidx[gb + lane] = cidx;
                 };
                 const bool cow_done = apply_leaf<OV>(map, pr, Tn, Tp, To, g, root, li, -1, point_at, store_idx, OV ? cow_src : nullptr,
-                                                     OV ? &jobs[(size_t)job_i * job_stride + tix] : nullptr);
+                                                     OV ? &jobs[(size_t)job_i * job_stride + tix] : nullptr, OV ? &jobhdr[(size_t)job_i * job_stride + tix] : nullptr);
                 ++job_i;
                 if (OV && cow_src) {
                     if (cow_done) cow_src = nullptr;

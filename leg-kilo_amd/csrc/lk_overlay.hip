@@ -153,7 +153,7 @@ int lk_overlay_export(lk_handle* h, uint32_t slot, void* blob, size_t* bytes) {
 void ov_free(lk_handle* h) {
     LkOverlay& o = h->ov;
     void* ptrs[] = {o.keys, o.planes, o.match, o.nodes, o.blocks, o.counters, o.touched, o.next, o.scratch, o.gidx, o.groups, o.slots,
-                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.frozen, o.sums, o.base_sums, o.cplx, o.ptroot};
+                    o.free_list, o.freed_next, o.dirty, o.newroot, o.spec, o.bits, o.jobs, o.jobhdr, o.frozen, o.sums, o.base_sums, o.cplx, o.ptroot};
     for (void* q : ptrs)
         if (q) hipFree(q);
     memset(&o, 0, sizeof(o));
@@ -245,6 +245,7 @@ static int ov_reserve(lk_handle* h, uint32_t S, size_t n_pts_scan, size_t bigges
     if (e == hipSuccess) e = get(&o.bits, s * n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.frozen, (size_t)2 * n.bit_words * sizeof(unsigned int));
     if (e == hipSuccess) e = get(&o.jobs, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(LkFitJob));
+    if (e == hipSuccess) e = get(&o.jobhdr, s * n.hash_cap * LK_INLINE_GROUPS * sizeof(int4));
     if (e == hipSuccess) e = get(&o.sums, s * n.hash_cap * sizeof(LkLeafSum));
     if (e == hipSuccess) e = get(&o.base_sums, (size_t)h->map.max_nodes * sizeof(LkLeafSum));
     if (e == hipSuccess) e = get(&o.cplx, s * n.scan_cap * 2 * sizeof(int));
@@ -297,6 +298,7 @@ static LkOverlay ov_at(const LkOverlay& o, size_t s0) {
     r.dirty += s0 * o.hash_cap;
     r.bits += s0 * o.bit_words;
     r.jobs += s0 * o.hash_cap * LK_INLINE_GROUPS;
+    r.jobhdr += s0 * o.hash_cap * LK_INLINE_GROUPS;
     r.sums += s0 * o.hash_cap;
     r.cplx += s0 * o.scan_cap * 2;
     r.ptroot += s0 * o.scan_cap;
@@ -361,7 +363,7 @@ int lk_batch_replay_overlay_dev(lk_handle* h, const lk_point* d_pts, size_t n_sc
     if (ov_fast) LAUNCH(h, "ov_base_sums", hipLaunchKernelGGL(lk_ov_base_sums_kernel, dim3((h->hash_cap + 255) / 256), dim3(256), 0, st, fmap, h->hash_cap, ov.base_sums));
     static const int ov_mat_wg = getenv("LEGKILO_OV_MAT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_MAT_WG"))) : 0;
     static const int ov_root_wg = getenv("LEGKILO_OV_ROOT_WG") ? std::max(1, atoi(getenv("LEGKILO_OV_ROOT_WG"))) : 0;
-    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 6;   // round 6, groups of eight lanes per fit: 2 / 4 / 6 / 8 / 16 / 32 waves per scan -> fit pass 2.19 / 2.03 / 1.89 / 2.07 / 2.33 / 3.56 ms
+    static const int fit_blocks = getenv("LEGKILO_OV_FIT_BLOCKS") ? std::max(1, atoi(getenv("LEGKILO_OV_FIT_BLOCKS"))) : 12;   // round 6: with the job headers in a dense array 6 / 8 / 12 / 16 / 24 waves per scan -> fit pass 1.75 / 1.92 / 1.61 / 2.12 / 1.71 ms (before: best at 6, 1.89)
     static const int ov_waves_per_slot = getenv("LEGKILO_OV_WG_PER_SLOT") ? std::max(1, atoi(getenv("LEGKILO_OV_WG_PER_SLOT"))) : 0;
     // Slot groups on separate HIP streams (LEGKILO_OV_GROUPS, default 4 - round 6, same box: 15.14 / 13.48 / 13.02 / 12.74 ms with 1 / 2 / 3 / 4 groups, 14.8 / 14.2 with
     // 6 / 8: beyond four streams the queues share hardware): the scans are independent, and the passes of a bucket are of two

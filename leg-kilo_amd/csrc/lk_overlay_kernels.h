@@ -99,6 +99,7 @@ struct LkOverlay {
                                  // frozen leaf (UpdateOctoTree ignores the point), bit 1 = its voxel takes the point AT THE ROOT (a live leaf, or not initialised
                                  // yet): not ignored, and nothing below the root to look at - the re-projection needs no read of the base tree for it
     struct LkFitJob* jobs;       // [S][hash_cap][LK_INLINE_GROUPS]: the plane fits the root pass leaves to lk_ov_fit_lane_kernel (current bucket)
+    int4* jobhdr;                // [S][LK_INLINE_GROUPS][hash_cap]: their headers {leaf, block, cnt, decided}, dense (what the fit passes scan)
     struct LkLeafSum* sums;      // [S][hash_cap]: moment sums of a leading part of a private ROOT leaf's points (lk_ov_root_lane_kernel)
     struct LkLeafSum* base_sums; // [base max_nodes], shared: the same for the BASE map's root leaves, once per replay (lk_ov_base_sums_kernel)
     int* cplx;                   // [S][2 * scan_cap]: {root, index in the touched list} of the roots the fast root pass leaves to the generic one
@@ -651,10 +652,11 @@ __device__ __forceinline__ void ov_fit_eig_body(const LkMap& base, const LkOverl
     if (pm.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
+    const int4* jhdr = ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
     for (int i = i_first; i < n_touched * LK_INLINE_GROUPS; i += i_stride) {
         const int g = i / n_touched, t = i - g * n_touched;
         const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
-        const int4 hd = *reinterpret_cast<const int4*>(job);
+        const int4 hd = jhdr[(size_t)g * ov.hash_cap + t];
         const int root = hd.x, cnt = hd.z;
         if (cnt <= 0) continue;
         lk_plane_rec* pl = &pm.planes[root];
@@ -702,7 +704,7 @@ __global__ void __launch_bounds__(LK_WAVE, LK_FIT_WAVES) lk_ov_fit_lane_kernel(L
     for (int i = blockIdx.x * LK_WAVE + threadIdx.x; i < n_touched * LK_INLINE_GROUPS; i += gridDim.x * LK_WAVE) {
         const int g = i / n_touched, t = i - g * n_touched;
         const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
-        const int4 hd = *reinterpret_cast<const int4*>(job);
+        const int4 hd = (ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS)[(size_t)g * ov.hash_cap + t];
         const int root = hd.x /* the leaf's node id */, block = hd.y, cnt = hd.z;
         if (cnt <= 0) continue;
         if (hd.w == 0) continue;   // the event said "not a plane": lk_ov_fit_eig_kernel has cleared the flag, there is no plane_var to make
@@ -794,6 +796,7 @@ __device__ __forceinline__ void ov_fit_group_body(const LkMap& base, const LkOve
     if (pm.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)pm.counters[LK_CTR_TOUCHED];
     const LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;   // entry [g][t]: inline leaf group g of touched root t
+    const int4* jhdr = ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
     const int sub = lane & (LK_FIT_GROUP - 1), grp = lane / LK_FIT_GROUP;
     const int total = n_touched * LK_INLINE_GROUPS;
     for (int i0 = w_first * LK_WAVE; i0 < total; i0 += w_stride * LK_WAVE) {   // wave-uniform
@@ -803,7 +806,7 @@ __device__ __forceinline__ void ov_fit_group_body(const LkMap& base, const LkOve
         if (i < total) {
             const int g = i / n_touched, t = i - g * n_touched;
             const LkFitJob* job = &jobs[(size_t)g * ov.hash_cap + t];
-            hd = *reinterpret_cast<const int4*>(job);
+            hd = jhdr[(size_t)g * ov.hash_cap + t];
             if (hd.z > 0 && hd.w != 0) bs = make_int2(job->base_block, job->n_base);
         }
         const bool has = hd.z > 0 && hd.w != 0;   // ("not a plane" events ended in lk_ov_fit_eig_kernel)
@@ -1039,6 +1042,7 @@ __device__ __forceinline__ void ov_root_lane_body(const LkMap& base, const LkOve
     if (map.counters[LK_CTR_ERR]) return;
     const int n_touched = (int)map.counters[LK_CTR_TOUCHED];
     LkFitJob* jobs = ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
+    int4* jhdr = ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS;
     const size_t job_stride = ov.hash_cap;
     LkLeafSum* sums = ov.sums + (size_t)slot * ov.hash_cap;
     const int thr = pr.layer_init_num[0];
@@ -1137,11 +1141,11 @@ __device__ __forceinline__ void ov_root_lane_body(const LkMap& base, const LkOve
         reinterpret_cast<int4*>(nd)[6] = make_int4(0, qw.y, qw.z, 1);          // queue consumed; complete
         if (thin) nd->pad_[LK_PAD_SPLIT] = (unsigned int)n0;                    // the n0 old points stay in the base block
 #pragma unroll
-        for (int g = 1; g < LK_INLINE_GROUPS; ++g) jobs[(size_t)g * job_stride + t].cnt = 0;
+        for (int g = 1; g < LK_INLINE_GROUPS; ++g) jhdr[(size_t)g * job_stride + t].z = 0;
         LkFitJob* jb = &jobs[t];
         if (fitted) {
             const int nb = thin ? n0 : split0;
-            *reinterpret_cast<int4*>(jb) = make_int4(root, rblock, fit_count, 1);
+            jhdr[t] = make_int4(root, rblock, fit_count, 1);
 #pragma unroll
             for (int q = 0; q < 9; ++q) jb->s9[q] = sev[q];
             jb->base_block = nb > 0 ? cow_blk : -1, jb->n_base = nb > 0 ? nb : 0;
@@ -1151,7 +1155,7 @@ __device__ __forceinline__ void ov_root_lane_body(const LkMap& base, const LkOve
             sr->n = fit_count;
             if (cw.w != 0) nd->pad_[LK_PAD_SUMSRC] = 0;   // the root has its own sums record now
         } else {
-            jb->cnt = 0;
+            jhdr[t].z = 0;
         }
     }
 }
@@ -1195,7 +1199,8 @@ __global__ void __launch_bounds__(LK_MB, W)
     if (n == 0) return;
     dev_insert_root<false, true, CPLX>(pm, pr, filters + blockIdx.y, pts, (const lk_pt_rec*)nullptr, n,
                                  (int)((blockIdx.x * LK_MB + threadIdx.x) >> 6), (int)((gridDim.x * LK_MB) >> 6), &base,
-                                 ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
+                                 ov.jobs + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap, nullptr,
+                                 ov.jobhdr + (size_t)blockIdx.y * ov.hash_cap * LK_INLINE_GROUPS);
 }
 #ifdef LK_TU_OVERLAY   // compiled in the overlay unit only (lk_internal.h)
 __global__ void __launch_bounds__(LK_MB)
@@ -1225,7 +1230,8 @@ __global__ void __launch_bounds__(LK_MB, 2) lk_ov_tail_kernel(LkMap base, LkOver
     const int n = ov_pt_src(src, slot, &pts);
     if (n != 0)
         dev_insert_root<false, true, true>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, wave, nw, &base,
-                                           ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
+                                           ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap, nullptr,
+                                           ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(LK_WAVE, LK_SCAN_WAVES)
         // ---- tail (lk_ov_tail_kernel)
         if (!pm.counters[LK_CTR_ERR] && n != 0)
             dev_insert_root<false, true, true>(pm, pr, filters + slot, pts, (const lk_pt_rec*)nullptr, n, 0, 1, &base,
-                                               ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap);
+                                               ov.jobs + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS, ov.hash_cap, nullptr,
+                                               ov.jobhdr + (size_t)slot * ov.hash_cap * LK_INLINE_GROUPS);
         LK_SCAN_PHASE_SYNC();
         ov_fit_eig_body(base, ov, pr, (unsigned int)slot, lane, LK_WAVE);
         LK_SCAN_PHASE_SYNC();
